@@ -1,0 +1,307 @@
+/*
+ * n1k.h — C ABI of the MI355X-native Filter -> Group -> Aggregate pipeline.
+ *
+ * This is the drop-in boundary for ONE hot path of the N1QL engine
+ * (pavel-paulau/query): the chain
+ *
+ *     Parallel{ Sequence[ Filter, InitialGroup ] } -> IntermediateGroup -> FinalGroup
+ *
+ * Every entry point names the reference interface it replaces (paths are
+ * relative to the reference tree).  The reference has no FFI of its own (it is
+ * 100 % Go); the cgo stub a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are caller-owned unless stated;
+ *   - every function returns an n1k_status; the message for the last failure
+ *     of a handle is n1k_last_error(h);
+ *   - one handle == one operator copy (reference: Operator.Copy(),
+ *     execution/parallel.go:67-73).  A handle is NOT re-entrant, different
+ *     handles may be driven from different OS threads concurrently;
+ *     n1k_stop() alone may be called concurrently with a push on the same
+ *     handle (reference: SendStop, execution/base.go:313-338).
+ *   - the library never falls back to a CPU implementation: if no HIP device
+ *     is usable every compute call fails with N1K_DEVICE_ERROR.
+ */
+#ifndef N1K_H
+#define N1K_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define N1K_ABI_VERSION 1
+
+/* ---------------------------------------------------------------- status -- */
+
+typedef enum n1k_status {
+    N1K_OK = 0,
+    N1K_UNSUPPORTED = 1,      /* plan/expression outside the device subset: caller keeps the reference operators */
+    N1K_EVAL_ERROR = 2,       /* ≙ errors.NewEvaluationError (execution/filter.go:51-54, group_initial.go:62-65) */
+    N1K_DEVICE_ERROR = 3,     /* HIP failure or no device; ≙ context.Fatal */
+    N1K_OOM = 4,              /* host/device allocation failed or group-table capacity exceeded */
+    N1K_STOPPED = 5,          /* n1k_stop() was observed (≙ processItem returning false after SendStop) */
+    N1K_INVALID = 6,          /* bad argument / batch shape */
+    N1K_UNSUPPORTED_DATA = 7  /* a value met at run time is outside the device subset (see n1k_tag) */
+} n1k_status;
+
+/* ------------------------------------------------------------ value tags -- */
+
+/*
+ * Value tags.  Order == N1QL type order (value/value.go:69-79:
+ * MISSING < NULL < BOOLEAN < NUMBER < STRING < ARRAY < OBJECT < BINARY), with
+ * BOOLEAN and NUMBER split into their two representations:
+ * FALSE<TRUE (value/boolean.go:99-113), INT/FLOAT = intValue/floatValue
+ * (value/integer.go, value/float.go).
+ */
+typedef enum n1k_tag {
+    N1K_T_MISSING = 0,
+    N1K_T_NULL = 1,
+    N1K_T_FALSE = 2,
+    N1K_T_TRUE = 3,
+    N1K_T_INT = 4,    /* payload = int64 */
+    N1K_T_FLOAT = 5,  /* payload = IEEE-754 binary64 bits; never integral-in-int64-range for parsed input
+                         (NewValue folds those to INT, value/value.go:377-382) */
+    N1K_T_STRING = 6, /* payload = code in the handle's string dictionary */
+    N1K_T_ARRAY = 7,  /* payload = dictionary code of the canonical JSON text (group keys / COUNT only) */
+    N1K_T_OBJECT = 8  /* idem */
+} n1k_tag;
+
+/* DICT32 columns carry no tag byte: these two codes stand for MISSING / NULL */
+#define N1K_CODE_MISSING 0xFFFFFFFFu
+#define N1K_CODE_NULL 0xFFFFFFFEu
+
+/* A tagged scalar as returned in results (16 bytes). */
+typedef struct n1k_value {
+    uint8_t tag; /* n1k_tag */
+    uint8_t pad[7];
+    union {
+        int64_t i;
+        double f;
+        uint64_t code; /* STRING/ARRAY/OBJECT: dictionary code */
+    } v;
+} n1k_value;
+
+/* --------------------------------------------------------- column batches -- */
+
+typedef enum n1k_col_kind {
+    N1K_COL_TAGGED64 = 0, /* tags[nrows] (1 B) + payload[nrows] (8 B) */
+    N1K_COL_DICT32 = 1    /* codes[nrows] (4 B): string code, N1K_CODE_MISSING or N1K_CODE_NULL */
+} n1k_col_kind;
+
+typedef struct n1k_col {
+    uint32_t kind;           /* n1k_col_kind */
+    uint32_t reserved;
+    const uint8_t *tags;     /* TAGGED64 */
+    const uint64_t *payload; /* TAGGED64 */
+    const uint32_t *codes;   /* DICT32 */
+} n1k_col;
+
+/*
+ * One batch of rows, column-wise.  Column i holds, for every row, the value of
+ * leaf path i of the plan (n1k_num_columns / n1k_column_path): what
+ * Field.Apply / Identifier.Evaluate would return for that row
+ * (expression/nav_field.go:134-160, identifier.go:48-51).
+ */
+typedef struct n1k_batch {
+    uint64_t nrows;
+    uint32_t ncols;
+    uint32_t reserved;
+    const n1k_col *cols;
+} n1k_batch;
+
+/* ----------------------------------------------------------------- results -- */
+
+/* Raw, mergeable accumulators of one aggregate of one group (the reference's
+ * "partial" values: algebra/aggregate.go:25-40). */
+typedef struct n1k_partial {
+    int64_t count;      /* COUNT/COUNTN: the count.  SUM/AVG: number of NUMBER operands */
+    int64_t isum;       /* SUM/AVG: exact integer part of the sum when int_exact != 0 */
+    double fsum;        /* SUM/AVG: sum of the FLOAT operands (plus the integer part when int_exact == 0) */
+    uint8_t int_exact;  /* 1: no FLOAT operand seen and the integer sum fits int64 */
+    uint8_t has_float;  /* 1: at least one FLOAT operand */
+    uint8_t pad[6];
+    n1k_value extreme;  /* MIN/MAX: current winner (NULL when none) */
+    int64_t distinct;   /* COUNT(DISTINCT)/COUNTN(DISTINCT): set size; SUM/AVG(DISTINCT): set size */
+} n1k_partial;
+
+typedef struct n1k_result {
+    uint64_t ngroups;
+    uint32_t nkeys;
+    uint32_t naggs;
+    const n1k_value *keys;       /* [ngroups][nkeys]  group key values (MISSING keys stay MISSING) */
+    const n1k_value *aggs;       /* [ngroups][naggs]  ComputeFinal() values, plan order */
+    const n1k_partial *partials; /* [ngroups][naggs]  */
+    const uint64_t *rep_row;     /* [ngroups] smallest input row ordinal of the group (the reference keeps the
+                                    first row it met as carrier, execution/group_initial.go:69-72) */
+    uint64_t nselected;          /* Filter-only plans: number of rows that passed */
+    const uint64_t *selected;    /* Filter-only plans: their row ordinals, ascending */
+} n1k_result;
+
+typedef struct n1k_stats {
+    uint64_t rows_in;       /* ≙ #itemsIn  (execution/base.go:32-46) */
+    uint64_t rows_selected; /* rows that passed the Filter (≙ Filter #itemsOut) */
+    uint64_t groups_out;    /* ≙ FinalGroup #itemsOut */
+    uint64_t batches;
+    double device_ms;       /* hipEvent time of all device work (≙ execTime) */
+    uint64_t bytes_scanned; /* algorithmic column bytes read by the scan kernel */
+    uint32_t agg_mode;      /* n1k_agg_mode actually used by the last batch */
+    uint32_t reserved;
+} n1k_stats;
+
+typedef enum n1k_agg_mode {
+    N1K_MODE_AUTO = 0,
+    N1K_MODE_LDS_HASH = 1,  /* open-addressed LDS table per workgroup, global atomic merge */
+    N1K_MODE_LDS_DIRECT = 2,/* perfect-hash LDS table (small dictionary-coded key domain), slab merge */
+    N1K_MODE_GLOBAL = 3     /* no LDS stage: global open-addressed table only (high cardinality) */
+} n1k_agg_mode;
+
+typedef struct n1k_handle n1k_handle;
+
+/* ------------------------------------------------------------ life cycle -- */
+
+/*
+ * Build an operator from the reference's own plan JSON.
+ * Replaces: execution.builder.VisitParallel / VisitFilter / VisitInitialGroup
+ *           (execution/build.go:281-296, 457-491) + NewFilter / NewInitialGroup /
+ *           NewIntermediateGroup / NewFinalGroup.
+ * plan_json is ONE of
+ *   {"#operator":"Sequence","~children":[{"#operator":"Filter","condition":"…"},
+ *                                        {"#operator":"InitialGroup","group_keys":[…],"aggregates":[…]}]}
+ *   {"#operator":"InitialGroup", …}            (no Filter)
+ *   {"#operator":"Filter","condition":"…"}     (Filter only: result = selected row ordinals)
+ *   {"#operator":"Parallel","~child":<one of the above>, "maxParallelism":n}
+ * exactly as plan.(*Filter).MarshalJSON (plan/filter.go:46-53),
+ * plan.(*InitialGroup).MarshalJSON (plan/group.go:54-70), plan/sequence.go:48-57 and
+ * plan/parallel.go:54-67 emit them; expressions are expression.Stringer text.
+ * Returns N1K_UNSUPPORTED (and *out == NULL) for anything outside the device subset.
+ */
+n1k_status n1k_create(const char *plan_json, size_t len, n1k_handle **out);
+
+/* ≙ Operator.Done() (execution/execution.go:26-64): frees host + device state. */
+void n1k_destroy(n1k_handle *h);
+
+/* ≙ reopen() (execution/group_initial.go:117-120): drop all groups, keep plan + dictionary. */
+n1k_status n1k_reset(n1k_handle *h);
+
+/* ≙ SendStop() (execution/base.go:313-338): safe from any thread. */
+void n1k_stop(n1k_handle *h);
+
+const char *n1k_last_error(const n1k_handle *h);
+/* message of a failed n1k_create (thread-local) */
+const char *n1k_create_error(void);
+
+/* --------------------------------------------------------------- binding -- */
+
+/* Leaf paths of the plan, in column order: stringer text such as
+ * "(`default`.`price`)".  The caller evaluates exactly these per row. */
+uint32_t n1k_num_columns(const n1k_handle *h);
+const char *n1k_column_path(const n1k_handle *h, uint32_t i);
+uint32_t n1k_num_keys(const n1k_handle *h);
+uint32_t n1k_num_aggregates(const n1k_handle *h);
+/* agg.String() of aggregate i — the key of the reference's "aggregates"
+ * attachment map (execution/group_initial.go:74-79). */
+const char *n1k_aggregate_name(const n1k_handle *h, uint32_t i);
+
+/* ------------------------------------------------------------ dictionary -- */
+
+/* Intern n strings (bytes[offsets[i]..offsets[i+1])) into the handle's
+ * dictionary; out_codes[i] receives the code.  Equal byte strings always get
+ * equal codes (string equality ≙ value/string.go:82-96). */
+n1k_status n1k_dict_intern(n1k_handle *h, uint32_t n, const uint64_t *offsets, const char *bytes,
+                           uint32_t *out_codes);
+uint32_t n1k_dict_size(const n1k_handle *h);
+n1k_status n1k_dict_get(const n1k_handle *h, uint32_t code, const char **ptr, size_t *len);
+
+/* ---------------------------------------------------------------- options -- */
+
+/* name ∈ {"agg_mode" (n1k_agg_mode), "max_groups" (capacity hint, default 1<<22),
+ *         "grid_blocks" (0 = auto), "device" (ordinal; before the first push),
+ *         "compact" (0/1: LDS-staged compaction of filter survivors),
+ *         "wave_reduce" (0/1: wavefront pre-reduction of equal keys)} */
+n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);
+
+/* ----------------------------------------------------------------- data ---- */
+
+/*
+ * ≙ processItem() over a batch (execution/filter.go:49-61 +
+ * execution/group_initial.go:56-100).  Host pointers; the call copies them to
+ * the device before returning (cgo rule: no Go pointer is retained).
+ */
+n1k_status n1k_push_batch(n1k_handle *h, const n1k_batch *batch);
+
+/* Same, but every pointer in the batch is a DEVICE pointer on the handle's
+ * device (columns already resident in HBM); nothing is copied.  The call is
+ * asynchronous on the handle's stream; the buffers must stay valid until
+ * n1k_finish / n1k_sync. */
+n1k_status n1k_push_device_batch(n1k_handle *h, const n1k_batch *batch);
+
+/* Wait for all queued device work of the handle. */
+n1k_status n1k_sync(n1k_handle *h);
+
+/*
+ * ≙ afterItems() of InitialGroup + the whole IntermediateGroup and FinalGroup
+ * (execution/group_intermediate.go:56-104, group_final.go:55-118): merges,
+ * finalises (ComputeFinal) and returns all groups; emits the default row when
+ * there are no keys and no input (group_final.go:108-117).  The result memory
+ * is owned by the handle and valid until the next finish/reset/destroy.
+ */
+n1k_status n1k_finish(n1k_handle *h, n1k_result *out);
+
+n1k_status n1k_get_stats(const n1k_handle *h, n1k_stats *out);
+
+/* ------------------------------------------------- multi-GPU (one per rank) -- */
+
+/*
+ * Hash-partition step of the 8-GPU path (no reference analogue: replaces the
+ * Parallel -> IntermediateGroup fan-in, execution/exchange.go:161-251).
+ * Evaluates the Filter on a device-resident batch and scatters every surviving
+ * row's referenced columns into `nparts` regions by hash(group key) % nparts.
+ * Row record = 16 bytes per referenced column pair is NOT used; instead each
+ * column keeps its own layout so the receiving rank can push the received
+ * buffers straight into n1k_push_device_batch of a handle created with
+ * n1k_create_partitioned().
+ *
+ * out_cols[c] are device buffers with room for `capacity_rows` rows per part
+ * (part p starts at row p*capacity_rows); out_counts (device, nparts x u64)
+ * receives the number of rows written to each part.
+ */
+n1k_status n1k_partition_device_batch(n1k_handle *h, const n1k_batch *batch, uint32_t nparts,
+                                      uint64_t capacity_rows, const n1k_col *out_cols, uint64_t *out_counts);
+
+/*
+ * ≙ CumulateIntermediate over another handle's/rank's groups
+ * (execution/group_intermediate.go:91-101): merge an exported group table into
+ * this handle.  `blob` is what n1k_export_groups produced (host memory).
+ */
+n1k_status n1k_export_groups(n1k_handle *h, const void **blob, size_t *len);
+n1k_status n1k_merge_groups(n1k_handle *h, const void *blob, size_t len);
+
+/* ------------------------------------------------------------- utilities -- */
+
+/* Device-side synthetic column generator of SURVEY.md §8(d) (bench/test input;
+ * the same generator exists on the CPU in oracle/ for parity).  All outputs are
+ * device pointers with room for nrows elements; any may be NULL. */
+typedef struct n1k_synth_spec {
+    uint64_t seed;
+    uint64_t first_row;  /* global ordinal of row 0 of this call (sharding) */
+    uint64_t nrows;
+    uint64_t total_rows; /* N of the whole data set (user_id range = N/10) */
+    uint32_t k_cat;      /* number of categories */
+    uint32_t zipf;       /* 0 = uniform, 1 = Zipf(s=1) via cdf */
+    const double *cat_cdf; /* device pointer, k_cat entries, only for zipf */
+} n1k_synth_spec;
+n1k_status n1k_synth_columns(int device, void *stream, const n1k_synth_spec *spec, uint32_t *cat_codes,
+                             uint8_t *price_tags, uint64_t *price_payload, uint8_t *user_tags,
+                             uint64_t *user_payload, uint8_t *region_tags, uint64_t *region_payload);
+
+int n1k_abi_version(void);
+/* number of visible HIP devices (0 when none); never initialises a context */
+int n1k_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* N1K_H */

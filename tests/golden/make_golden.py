@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Build tests/golden/*.json from the reference's own test DATA files.
+
+Run in the build container only (the reference tree does not travel to the GPU
+box):  python tests/golden/make_golden.py [/root/reference]
+
+What is copied is data — the documents of the tiny test keyspaces and the
+expected `results` of the reference's JSON case files — never source code.
+No reference code is imported or executed (it is Go).
+
+For every case the SQL statement is kept as documentation; the plan strings
+(`condition`, `group_keys`, `aggregates`) are what planner/build_select_sub.go
+:209-296 emits for that statement, written in expression.Stringer syntax
+(expression/stringer.go), derived by hand: the keyspace alias is the keyspace
+name, WHERE becomes Filter.condition, GROUP BY terms become group_keys and the
+aggregates are de-duplicated and sorted by their text
+(planner/build_select_sub.go:551-558).  HAVING / projection / ORDER BY / LIMIT
+sit downstream of the hot path and are replayed by the test
+harness (tests/golden_util.py) from the `post` section.
+"""
+import glob
+import json
+import os
+import re
+import sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+FS = os.path.join(REF, "test/filestore/json/default")
+MS = os.path.join(REF, "test/multistore/test_cases")
+
+
+def load_keyspace(name):
+    docs = []
+    for f in sorted(glob.glob(os.path.join(FS, name, "*.json"))):
+        with open(f) as fh:
+            docs.append({"key": os.path.basename(f)[:-5], "doc": json.load(fh)})
+    return docs
+
+
+def load_inserts(path):
+    """INSERT INTO ks (KEY,VALUE) VALUES("k", {json}) statements -> {ks: [docs]}"""
+    out = {}
+    for st in json.load(open(path)):
+        s = st["statements"]
+        m = re.match(r'\s*INSERT INTO (\w+)\s*\(KEY,VALUE\)\s*VALUES\(\s*"([^"]+)"\s*,\s*(\{.*\})\s*\)\s*$', s, re.S)
+        if not m:
+            continue
+        out.setdefault(m.group(1), []).append({"key": m.group(2), "doc": json.loads(m.group(3))})
+    return out
+
+
+def keep_fields(docs, fields):
+    return [{"key": d["key"], "doc": {k: v for k, v in d["doc"].items() if k in fields}} for d in docs]
+
+
+def cases_of(path):
+    return json.load(open(path))
+
+
+def F(alias, *path):
+    """stringer text of a field path: ((`a`.`b`).`c`)"""
+    s = "`%s`" % alias
+    for p in path:
+        s = "(%s.`%s`)" % (s, p)
+    return s
+
+
+def main():
+    data = {}
+    for ks in ("catalog", "orders", "user_profile", "jobs", "tags", "contacts", "game"):
+        data[ks] = load_keyspace(ks)
+    agg = load_inserts(os.path.join(MS, "aggregate_functions/insert.json"))
+    data["ms_product"] = keep_fields(agg["product"], {"test_id", "color", "unitPrice", "categories"})
+    data["ms_orders"] = agg["orders"]
+    ints = load_inserts(os.path.join(MS, "integers/insert.json"))
+    data["ms_int_orders"] = ints["orders"]
+
+    gbh = cases_of(os.path.join(FS, "cases/case_group_by_having.json"))
+    whr = cases_of(os.path.join(FS, "cases/case_where.json"))
+    ms_gbh = cases_of(os.path.join(MS, "aggregate_functions/case_group_by_having.json"))
+    ms_dis = cases_of(os.path.join(MS, "aggregate_functions/case_distinct.json"))
+    ms_int = cases_of(os.path.join(MS, "integers/case_select.json"))
+
+    cases = []
+
+    def add(src_name, src_cases, idx, keyspace, plan, post):
+        c = src_cases[idx]
+        cases.append({
+            "id": "%s#%d" % (src_name, idx),
+            "source": src_name,
+            "index": idx,
+            "statement": c["statements"],
+            "keyspace": keyspace,
+            "plan": plan,
+            "post": post,
+            "results": c["results"],
+        })
+
+    # ---------------------------------------------------------------- G1: filestore case_group_by_having.json
+    g1 = "filestore/case_group_by_having.json"
+    cat_list = F("catalog", "pricing", "list")
+    aggs5 = sorted(["min(%s)" % cat_list, "max(%s)" % cat_list, "avg(%s)" % cat_list, "sum(%s)" % cat_list,
+                    "count(%s)" % cat_list])
+    ix = {a.split("(")[0]: i for i, a in enumerate(aggs5)}
+    proj5 = [{"as": n, "agg": ix[n]} for n in ("min", "max", "avg", "sum", "count")]
+    add(g1, gbh, 0, "catalog",
+        {"condition": None, "group_keys": [F("catalog", "type")], "aggregates": ["count(*)"]},
+        {"project": [{"as": "type", "key": 0}, {"as": "count", "agg": 0}], "order": [[{"key": 0}, "asc"]]})
+    add(g1, gbh, 1, "catalog", {"condition": None, "group_keys": [], "aggregates": aggs5}, {"project": proj5})
+    add(g1, gbh, 2, "catalog", {"condition": None, "group_keys": [F("catalog", "type")], "aggregates": aggs5},
+        {"project": [{"as": "type", "key": 0}] + proj5, "order": [[{"key": 0}, "asc"]]})
+    add(g1, gbh, 3, "catalog", {"condition": None, "group_keys": [F("catalog", "type")], "aggregates": aggs5},
+        {"having": [{"agg": ix["count"]}, ">", 1], "project": [{"as": "type", "key": 0}] + proj5,
+         "order": [[{"key": 0}, "asc"]]})
+    add(g1, gbh, 5, "orders",
+        {"condition": None, "group_keys": ["(%s[1])" % F("orders", "orderlines")], "aggregates": ["count(*)"]},
+        {"project": [{"as": "$1", "key": 0}, {"as": "count", "agg": 0}], "order": [[{"agg": 0}, "asc"]]})
+    add(g1, gbh, 6, "orders",
+        {"condition": None, "group_keys": [F("orders", "orderlines")], "aggregates": ["count(*)"]},
+        {"project": [{"as": "orderlines", "key": 0}, {"as": "count", "agg": 0}], "order": [[{"key": 0}, "asc"]]})
+    add(g1, gbh, 9, "user_profile",
+        {"condition": None,
+         "group_keys": [F("user_profile", "personal_details", "state"),
+                        F("user_profile", "profile_details", "loyalty", "membership_type")],
+         "aggregates": ["count(*)"]},
+        {"having": [{"key": 1}, "=", "Gold"],
+         "project": [{"as": "state", "key": 0}, {"as": "membership_type", "key": 1}, {"as": "gold_members", "agg": 0}],
+         "order": [[{"key": 0}, "asc"]]})
+    theme = F("user_profile", "profile_details", "prefs", "ui_theme")
+    add(g1, gbh, 10, "user_profile", {"condition": None, "group_keys": [theme], "aggregates": ["count(*)"]},
+        {"project": [{"as": "ui_theme", "key": 0}, {"as": "theme_usage", "agg": 0}], "order": [[{"key": 0}, "asc"]]})
+    jt = F("jobs", "job_title")
+    add(g1, gbh, 11, "jobs",
+        {"condition": None, "group_keys": [F("jobs", "join_yr")], "aggregates": ["count(distinct %s)" % jt]},
+        {"project": [{"as": "distinct_title_count", "agg": 0}, {"as": "join_yr", "key": 0}],
+         "order": [[{"key": 0}, "asc"]]})
+    a13 = sorted(["count(distinct %s)" % jt, "count(%s)" % jt])
+    add(g1, gbh, 13, "jobs", {"condition": None, "group_keys": [F("jobs", "join_yr")], "aggregates": a13},
+        {"project": [{"as": "distinct_title_count", "agg": a13.index("count(distinct %s)" % jt)},
+                     {"as": "title_count", "agg": a13.index("count(%s)" % jt)}, {"as": "join_yr", "key": 0}],
+         "order": [[{"key": 0}, "asc"]]})
+    add(g1, gbh, 15, "user_profile", {"condition": None, "group_keys": [theme], "aggregates": ["count(*)"]},
+        {"project": [{"as": "ui_theme", "key": 0}, {"as": "theme_usage", "agg": 0}],
+         "order": [[{"agg": 0}, "asc"], [{"key": 0}, "asc"]]})
+
+    # ---------------------------------------------------------------- G2: multistore aggregate_functions
+    g2 = "multistore/aggregate_functions/case_group_by_having.json"
+    o_filter = '(%s = "agg_func")' % F("orders", "test_id")
+    p_filter = '(%s = "agg_func")' % F("product", "test_id")
+    up = F("product", "unitPrice")
+    paggs = sorted(["min(%s)" % up, "max(%s)" % up, "avg(%s)" % up, "sum(%s)" % up, "count(%s)" % up])
+    pix = {a.split("(")[0]: i for i, a in enumerate(paggs)}
+    pproj = [{"as": "min", "agg": pix["min"]}, {"as": "max", "agg": pix["max"]},
+             {"as": "avg", "agg": pix["avg"], "round": 5}, {"as": "sum", "agg": pix["sum"], "round": 5},
+             {"as": "count", "agg": pix["count"]}]
+    add(g2, ms_gbh, 0, "ms_orders",
+        {"condition": o_filter, "group_keys": [F("orders", "custId")], "aggregates": ["count(*)"]},
+        {"project": [{"as": "custId", "key": 0}, {"as": "c", "agg": 0}],
+         "order": [[{"agg": 0}, "asc"], [{"key": 0}, "asc"]]})
+    add(g2, ms_gbh, 1, "ms_product", {"condition": p_filter, "group_keys": [], "aggregates": paggs},
+        {"project": pproj})
+    add(g2, ms_gbh, 2, "ms_product", {"condition": p_filter, "group_keys": [F("product", "color")], "aggregates": paggs},
+        {"project": [{"as": "product_color", "key": 0}] + pproj,
+         "order": [[{"agg": pix["min"]}, "asc"], [{"agg": pix["avg"]}, "asc"]], "limit": 5})
+    add(g2, ms_gbh, 3, "ms_product", {"condition": p_filter, "group_keys": [F("product", "color")], "aggregates": paggs},
+        {"having": [{"agg": pix["count"]}, ">", 34], "project": [{"as": "product_colori", "key": 0}] + pproj,
+         "order": [[{"agg": pix["min"]}, "asc"], [{"agg": pix["avg"]}, "asc"]]})
+    add(g2, ms_gbh, 5, "ms_orders",
+        {"condition": o_filter, "group_keys": ["(%s[1])" % F("orders", "orderlines")], "aggregates": ["count(*)"]},
+        {"project": [{"as": "$1", "key": 0}, {"as": "count", "agg": 0}], "order": [[{"agg": 0}, "asc"]]})
+    add(g2, ms_gbh, 6, "ms_orders",
+        {"condition": o_filter, "group_keys": [F("orders", "orderlines")], "aggregates": ["count(*)"]},
+        {"project": [{"as": "orderlines", "key": 0}, {"as": "count", "agg": 0}], "order": [[{"key": 0}, "asc"]]})
+
+    g2d = "multistore/aggregate_functions/case_distinct.json"
+    pc = F("product", "categories")
+    add(g2d, ms_dis, 1, "ms_product",
+        {"condition": p_filter, "group_keys": [pc], "aggregates": ["count(distinct %s)" % F("product", "color")]},
+        {"project": [{"as": "numcolors", "agg": 0}, {"as": "category", "key": 0}],
+         "order": [[{"agg": 0}, "asc"], [{"key": 0}, "desc"]], "limit": 3})
+    a3 = sorted(["count(distinct %s)" % F("product", "color"), "count(%s)" % pc])
+    add(g2d, ms_dis, 3, "ms_product", {"condition": p_filter, "group_keys": [], "aggregates": a3},
+        {"project": [{"as": "totcolors", "agg": a3.index("count(distinct %s)" % F("product", "color"))},
+                     {"as": "totcategories", "agg": a3.index("count(%s)" % pc)}]})
+    add(g2d, ms_dis, 5, "ms_product", {"condition": p_filter, "group_keys": [pc], "aggregates": ["count(*)"]},
+        {"having": [{"agg": 0}, "between", [15, 30]],
+         "project": [{"as": "CATG", "key": 0}, {"as": "numprods", "agg": 0}],
+         "order": [[{"key": 0}, "asc"], [{"agg": 0}, "asc"]], "limit": 3})
+    add(g2d, ms_dis, 6, "ms_product", {"condition": p_filter, "group_keys": [pc], "aggregates": ["count(*)"]},
+        {"project": [{"as": "CATG", "key": 0}, {"as": "numprods", "agg": 0}],
+         "order": [[{"key": 0}, "asc"], [{"agg": 0}, "asc"]], "limit": 3})
+    add(g2d, ms_dis, 7, "ms_product", {"condition": p_filter, "group_keys": [pc], "aggregates": ["count(*)"]},
+        {"project": [{"as": "CATG", "key": 0}, {"as": "numprods", "agg": 0}],
+         "order": [[{"agg": 0}, "asc"], [{"key": 0}, "asc"]], "limit": 3})
+    cn = F("orders", "cntn")
+    a8 = sorted(["countn(%s)" % cn, "countn(distinct %s)" % cn, "count(%s)" % cn, "count(distinct %s)" % cn])
+    add(g2d, ms_dis, 8, "ms_orders",
+        {"condition": '(%s = "cntn_agg_func")' % F("orders", "test_id"), "group_keys": [], "aggregates": a8},
+        {"project": [{"as": "cntn", "agg": a8.index("countn(%s)" % cn)},
+                     {"as": "dcntn", "agg": a8.index("countn(distinct %s)" % cn)},
+                     {"as": "cnt", "agg": a8.index("count(%s)" % cn)},
+                     {"as": "dcnt", "agg": a8.index("count(distinct %s)" % cn)}]})
+
+    # ---------------------------------------------------------------- G3: multistore integers
+    g3 = "multistore/integers/case_select.json"
+    ifilter = '((%s = "select_big_int") and (%s = "aggr"))' % (F("orders", "test_id"), F("orders", "type"))
+    add(g3, ms_int, 4, "ms_int_orders",
+        {"condition": ifilter, "group_keys": [F("orders", "type")], "aggregates": ["sum(%s)" % F("orders", "num")]},
+        {"project": [{"as": "total", "agg": 0}, {"as": "type", "key": 0}]})
+    add(g3, ms_int, 5, "ms_int_orders",
+        {"condition": '((%s = "select_big_int") and (90 < %s))' % (F("orders", "test_id"), F("orders", "num")),
+         "group_keys": [], "aggregates": ["count(1)"]},
+        {"project": [{"as": "total", "agg": 0}]})
+
+    # ---------------------------------------------------------------- G4: filestore case_where.json (Filter only)
+    g4 = "filestore/case_where.json"
+
+    def fo(idx, ks, cond, fields, order):
+        add(g4, whr, idx, ks, {"condition": cond, "filter_only": True},
+            {"project": [{"as": f[-1], "doc": list(f)} for f in fields],
+             "order": [[{"doc": list(order)}, "asc"]]})
+
+    bo = F("tags", "banned-on")
+    fo(0, "tags", "(%s is not missing)" % bo, [("banned-on",)], ("banned-on",))
+    fo(1, "tags", "(%s is not null)" % bo, [("banned-on",)], ("banned-on",))
+    fo(2, "tags", "(%s is null)" % bo, [("banned-on",)], ("banned-on",))
+    fo(8, "contacts", '(%s = "dave")' % F("contact", "name"), [("name",)], ("name",))
+    fo(9, "catalog", "(%s = 799)" % F("catalog", "pricing", "list"), [("dimensions", "height")], ("dimensions", "height"))
+    so = F("orders", "shipped-on")
+    fo(14, "orders", "(%s is not valued)" % so, [("id",)], ("id",))
+    fo(15, "orders", "(%s is valued)" % so, [("id",)], ("id",))
+    fo(16, "orders", "(%s is not null)" % so, [("id",)], ("id",))
+    fo(17, "orders", "(%s is null)" % so, [("id",)], ("id",))
+    fo(18, "orders", "(%s is not missing)" % so, [("id",)], ("id",))
+    fo(19, "orders", "(%s is missing)" % so, [("id",)], ("id",))
+    fo(20, "contacts", '(not (%s = "dave"))' % F("contacts", "name"), [("name",)], ("name",))
+    fo(21, "game", "(%s <= 8)" % F("game", "score"), [("score",)], ("score",))
+    fo(22, "game", "(10 <= %s)" % F("game", "score"), [("score",)], ("score",))
+    fo(23, "contacts", '((%s = "dave") or (%s = "earl"))' % (F("contacts", "name"), F("contacts", "name")),
+       [("name",)], ("name",))
+    # contact alias differs in case 8 ("FROM default:contacts AS contact")
+    used = sorted({c["keyspace"] for c in cases})
+    with open(os.path.join(OUT, "cases.json"), "w") as fh:
+        json.dump(cases, fh, indent=1, sort_keys=True)
+    for ks in used:
+        with open(os.path.join(OUT, "data_%s.json" % ks), "w") as fh:
+            json.dump(data[ks], fh, separators=(",", ":"), sort_keys=True)
+    print("wrote %d cases, %d keyspaces" % (len(cases), len(used)))
+
+
+if __name__ == "__main__":
+    main()
