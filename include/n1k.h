@@ -259,10 +259,9 @@ n1k_status n1k_get_stats(const n1k_handle *h, n1k_stats *out);
  * Parallel -> IntermediateGroup fan-in, execution/exchange.go:161-251).
  * Evaluates the Filter on a device-resident batch and scatters every surviving
  * row's referenced columns into `nparts` regions by hash(group key) % nparts.
- * Row record = 16 bytes per referenced column pair is NOT used; instead each
- * column keeps its own layout so the receiving rank can push the received
- * buffers straight into n1k_push_device_batch of a handle created with
- * n1k_create_partitioned().
+ * Each column keeps its own layout, so the receiving rank can hand the received
+ * buffers straight to n1k_push_device_batch of a handle built from the same plan
+ * without its Filter.
  *
  * out_cols[c] are device buffers with room for `capacity_rows` rows per part
  * (part p starts at row p*capacity_rows); out_counts (device, nparts x u64)

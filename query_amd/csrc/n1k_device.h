@@ -1,0 +1,220 @@
+// n1k_device.h — device-side value semantics of the N1QL hot path (gfx950).
+//
+// Tagged scalars (tag + 64-bit payload) with the reference's collation,
+// equality, truth and 4-valued logic rules.  Each helper cites the Go source
+// it reproduces (paths relative to the reference tree).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "n1k_types.h"
+
+namespace n1k {
+
+#define N1K_DEV __device__ __forceinline__
+
+// type-order class of a tag (value/value.go:69-79):
+// MISSING 0, NULL 1, BOOLEAN 2, NUMBER 3, STRING 4, ARRAY 5, OBJECT 6
+N1K_DEV uint32_t cls_of(uint32_t tag) { return (uint32_t)((0x654332210ull >> (tag * 4u)) & 0xFu); }
+
+N1K_DEV double as_f64(uint64_t bits) { return __longlong_as_double((long long)bits); }
+N1K_DEV uint64_t f64_bits(double d) { return (uint64_t)__double_as_longlong(d); }
+
+// Go float64 -> int64 on amd64 (cvttsd2si): out of range / NaN -> MinInt64
+N1K_DEV int64_t go_f2i(double f) {
+    if (!(f >= -9223372036854775808.0 && f < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t)f;
+}
+// value.IsInt (value/integer.go:354-356)
+N1K_DEV bool is_int_f64(double x) { return x == (double)go_f2i(x); }
+
+// monotone u64 image of a double; NaN -> 0 ("NaN sorts first", value/float.go:123-172)
+N1K_DEV uint64_t f64_sortable(double d) {
+    if (d != d) return 0ull;
+    uint64_t b = f64_bits(d);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+N1K_DEV double f64_unsortable(uint64_t s) {
+    if (s == 0ull) return __longlong_as_double(0x7FF8000000000000ll);
+    uint64_t b = (s & 0x8000000000000000ull) ? (s & 0x7FFFFFFFFFFFFFFFull) : ~s;
+    return as_f64(b);
+}
+
+// collateFloat (value/float.go:123-172)
+N1K_DEV int collate_f64(double t, double o) {
+    if (t != t) return (o != o) ? 0 : -1;
+    if (o != o) return 1;
+    return t < o ? -1 : (t > o ? 1 : 0);
+}
+
+N1K_DEV double num_actual(uint32_t tag, uint64_t p) { return tag == T_INT ? (double)(int64_t)p : as_f64(p); }
+
+// result of X.Compare(Y): -1/0/1, or these two
+constexpr int CMP_NULL = 2, CMP_MISSING = 3;
+
+// X.Collate(Y) for two non-MISSING/NULL values of any type
+// (value/integer.go:100-118, float.go:106-121, string.go:116-130, boolean.go:99-113)
+N1K_DEV int collate(uint32_t ta, uint64_t pa, uint32_t tb, uint64_t pb, const uint32_t* rank, uint32_t* unsupported) {
+    uint32_t ca = cls_of(ta), cb = cls_of(tb);
+    if (ca != cb) return ca < cb ? -1 : 1;
+    if (ca == 3) {
+        if (ta == T_INT && tb == T_INT) {
+            int64_t x = (int64_t)pa, y = (int64_t)pb;
+            return x < y ? -1 : (x > y ? 1 : 0);
+        }
+        return collate_f64(num_actual(ta, pa), num_actual(tb, pb));
+    }
+    if (ca == 2) return ta < tb ? -1 : (ta > tb ? 1 : 0);
+    if (ca == 4) {
+        if (pa == pb) return 0;
+        uint32_t ra = rank[(uint32_t)pa], rb = rank[(uint32_t)pb];
+        return ra < rb ? -1 : 1;
+    }
+    if (ca >= 5) {
+        if (pa == pb) return 0;
+        *unsupported = 1;  // element-wise ordering of arrays/objects is outside the device subset
+        return 0;
+    }
+    return 0;
+}
+
+// X.Compare(Y): MISSING if either is MISSING, else NULL if either is NULL, else Collate
+N1K_DEV int compare(uint32_t ta, uint64_t pa, uint32_t tb, uint64_t pb, const uint32_t* rank, uint32_t* unsupported) {
+    if (ta == T_MISSING || tb == T_MISSING) return CMP_MISSING;
+    if (ta == T_NULL || tb == T_NULL) return CMP_NULL;
+    return collate(ta, pa, tb, pb, rank, unsupported);
+}
+
+// X.Equals(Y) as a 4-valued logic value
+// (value/integer.go:68-87, float.go:74-93, string.go:82-96, boolean.go:74-88, null.go:72-80, missing.go:88-90)
+N1K_DEV uint32_t equals_l(uint32_t ta, uint64_t pa, uint32_t tb, uint64_t pb, uint32_t* unsupported) {
+    if (ta == T_MISSING || tb == T_MISSING) return L_MISSING;
+    if (ta == T_NULL || tb == T_NULL) return L_NULL;
+    uint32_t ca = cls_of(ta), cb = cls_of(tb);
+    if (ca != cb) return L_FALSE;
+    if (ca == 3) {
+        if (ta == T_INT && tb == T_INT) return pa == pb ? L_TRUE : L_FALSE;
+        return num_actual(ta, pa) == num_actual(tb, pb) ? L_TRUE : L_FALSE;
+    }
+    if (ca == 2) return ta == tb ? L_TRUE : L_FALSE;
+    if (ca == 4) return pa == pb ? L_TRUE : L_FALSE;
+    if (pa == pb) return L_TRUE;
+    *unsupported = 1;
+    return L_FALSE;
+}
+
+// type + Truth() of a value used as a condition
+// (value/integer.go:136-138, float.go:190-192, string.go:148, boolean.go:125, null.go:106, missing.go:113)
+N1K_DEV uint32_t truth_l(uint32_t tag, uint64_t p, uint32_t empty_str, uint32_t empty_arr, uint32_t empty_obj) {
+    switch (tag) {
+        case T_MISSING: return L_MISSING;
+        case T_NULL: return L_NULL;
+        case T_FALSE: return L_FALSE;
+        case T_TRUE: return L_TRUE;
+        case T_INT: return p != 0 ? L_TRUE : L_FALSE;
+        case T_FLOAT: {
+            double d = as_f64(p);
+            return (d == d && d != 0.0) ? L_TRUE : L_FALSE;
+        }
+        case T_STRING: return (uint32_t)p != empty_str ? L_TRUE : L_FALSE;
+        case T_ARRAY: return (uint32_t)p != empty_arr ? L_TRUE : L_FALSE;
+        default: return (uint32_t)p != empty_obj ? L_TRUE : L_FALSE;
+    }
+}
+
+// And.Apply over `n` stacked logic values (expression/logic_and.go:64-89)
+N1K_DEV uint32_t logic_and(uint64_t& st, uint32_t n) {
+    bool any_false = false, any_missing = false, any_null = false;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t v = (uint32_t)(st & 3ull);
+        st >>= 2;
+        any_false |= (v == L_FALSE);
+        any_missing |= (v == L_MISSING);
+        any_null |= (v == L_NULL);
+    }
+    return any_false ? L_FALSE : (any_missing ? L_MISSING : (any_null ? L_NULL : L_TRUE));
+}
+// Or.Apply (expression/logic_or.go:98-123)
+N1K_DEV uint32_t logic_or(uint64_t& st, uint32_t n) {
+    bool any_true = false, any_missing = false, any_null = false;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t v = (uint32_t)(st & 3ull);
+        st >>= 2;
+        any_true |= (v == L_TRUE);
+        any_missing |= (v == L_MISSING);
+        any_null |= (v == L_NULL);
+    }
+    return any_true ? L_TRUE : (any_null ? L_NULL : (any_missing ? L_MISSING : L_FALSE));
+}
+// Not.Apply (expression/logic_not.go:57-69)
+N1K_DEV uint32_t logic_not(uint32_t v) { return v >= L_NULL ? v : (v ^ 1u); }
+
+N1K_DEV uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+N1K_DEV uint64_t zigzag(int64_t x) { return ((uint64_t)x << 1) ^ (uint64_t)(x >> 63); }
+N1K_DEV int64_t unzigzag(uint64_t z) { return (int64_t)(z >> 1) ^ -(int64_t)(z & 1); }
+
+// One group-key value -> its bit field (see KeySpec).  Equal fields <=> equal canonical JSON of the
+// key (execution/group_util.go:18-35): MISSING and NULL are distinct, FALSE/TRUE, numbers by value
+// (integral floats fold to the int they equal: value/float.go:31-48 prints 5.0 as "5"), strings /
+// arrays / objects by dictionary code of their (canonical) text.
+N1K_DEV bool pack_key_field(const KeySpec& k, uint32_t tag, uint64_t p, uint64_t& field) {
+    if (k.mode == KEYM_DICT) {
+        // DICT32 columns / pure string keys: 0 MISSING, 1 NULL, code+2
+        if (tag == T_MISSING) field = 0;
+        else if (tag == T_NULL) field = 1;
+        else if (tag == T_STRING) field = p + 2;
+        else return false;
+        return k.bits >= 64 || field < (1ull << k.bits);
+    }
+    uint64_t cls, sub = 0;
+    switch (tag) {
+        case T_MISSING: cls = 0; break;
+        case T_NULL: cls = 1; break;
+        case T_FALSE: cls = 2; break;
+        case T_TRUE: cls = 3; break;
+        case T_INT: cls = 4; sub = zigzag((int64_t)p); break;
+        case T_FLOAT: {
+            double d = as_f64(p);
+            if (!is_int_f64(d)) return false;  // non-integral float keys need the wide-key path
+            cls = 4;
+            sub = zigzag(go_f2i(d));
+            break;
+        }
+        case T_STRING: cls = 5; sub = p; break;
+        case T_ARRAY: cls = 6; sub = p; break;
+        default: cls = 7; sub = p; break;
+    }
+    uint32_t sb = k.bits - 3;
+    if (sb < 64 && sub >= (1ull << sb)) return false;
+    field = (sub << 3) | cls;
+    return true;
+}
+
+N1K_DEV void unpack_key_field(uint32_t mode, uint64_t field, uint32_t& tag, uint64_t& p) {
+    if (mode == KEYM_DICT) {
+        if (field == 0) { tag = T_MISSING; p = 0; }
+        else if (field == 1) { tag = T_NULL; p = 0; }
+        else { tag = T_STRING; p = field - 2; }
+        return;
+    }
+    uint64_t cls = field & 7ull, sub = field >> 3;
+    p = 0;
+    switch (cls) {
+        case 0: tag = T_MISSING; break;
+        case 1: tag = T_NULL; break;
+        case 2: tag = T_FALSE; break;
+        case 3: tag = T_TRUE; break;
+        case 4: tag = T_INT; p = (uint64_t)unzigzag(sub); break;
+        case 5: tag = T_STRING; p = sub; break;
+        case 6: tag = T_ARRAY; p = sub; break;
+        default: tag = T_OBJECT; p = sub; break;
+    }
+}
+
+}  // namespace n1k

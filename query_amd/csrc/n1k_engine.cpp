@@ -1,0 +1,920 @@
+// n1k_engine.cpp — host engine behind the C ABI (include/n1k.h).
+//
+// Host-side mirror of the reference operators for this path: one Handle plays the role of one
+// Parallel copy of Sequence[Filter, InitialGroup] plus the serial IntermediateGroup / FinalGroup
+// (execution/parallel.go:52-83, filter.go, group_initial.go, group_intermediate.go, group_final.go),
+// with the consumer life cycle of execution/base.go:492-545:
+//     create = beforeItems, push_batch = processItem*, finish = afterItems, reset = reopen,
+//     stop = SendStop, destroy = Done.
+// There is no CPU fallback: without a HIP device every compute call fails with N1K_DEVICE_ERROR.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/n1k.h"
+#include "n1k_kernels.h"
+#include "n1k_plan.h"
+
+using namespace n1k;
+
+static_assert(sizeof(n1k_value) == 16, "n1k_value layout");
+static_assert(sizeof(OutValue) == sizeof(n1k_value), "OutValue must alias n1k_value");
+static_assert(sizeof(Program) + sizeof(ScanArgs) + sizeof(GlobalTable) + 64 <= 4096, "kernel arguments exceed 4 KiB");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        size_t want = std::max(count, (size_t)16);
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+uint64_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+uint32_t ceil_log2(uint64_t x) {
+    uint32_t b = 0;
+    while ((1ull << b) < x) b++;
+    return b;
+}
+
+}  // namespace
+
+struct n1k_handle {
+    ParsedPlan plan;
+    std::string last_error;
+    std::atomic<int> stop_flag{0};
+
+    // options
+    int64_t opt_agg_mode = N1K_MODE_AUTO;
+    uint64_t opt_max_groups = 1ull << 22;
+    uint32_t opt_grid_blocks = 0;
+    uint32_t opt_compact = 1, opt_wave_reduce = 1, opt_rep_row = 0;
+    uint32_t opt_lds_bytes = 80 * 1024;
+    int device = -1;
+    bool device_ready = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+
+    // dictionary (all STRING/ARRAY/OBJECT payloads are codes into it)
+    std::vector<std::string> dict;
+    std::unordered_map<std::string, uint32_t> dict_index;
+    bool need_rank = false;
+    size_t rank_built_for = (size_t)-1;
+    DevBuf<uint32_t> d_rank;
+
+    // compiled program (column pointers are patched per batch)
+    Program prog{};
+    bool layout_fixed = false;
+    uint32_t col_kinds[kMaxCols]{};
+    std::vector<std::string> agg_names;
+    bool has_distinct = false;
+
+    // device state
+    GlobalTable table{};
+    DevBuf<uint64_t> d_keys, d_acc, d_rep;
+    DevBuf<uint32_t> d_err;
+    DevBuf<unsigned long long> d_counters;  // [0] rows_selected [1] ngroups [2] out_count [3] filter total
+    uint64_t row_base = 0;
+
+    // staging for host batches
+    std::vector<DevBuf<uint8_t>> st_tags;
+    std::vector<DevBuf<uint64_t>> st_payload;
+    std::vector<DevBuf<uint32_t>> st_codes;
+
+    // filter-only path
+    DevBuf<uint64_t> d_mask, d_tile_off, d_sel;
+    DevBuf<uint32_t> d_tile_cnt;
+    std::vector<uint64_t> selected;
+
+    // results
+    std::vector<n1k_value> r_keys, r_aggs;
+    std::vector<n1k_partial> r_parts;
+    std::vector<uint64_t> r_rep;
+    DevBuf<OutValue> d_okeys, d_oaggs;
+    DevBuf<OutPartial> d_oparts;
+    DevBuf<uint64_t> d_orep;
+    std::vector<char> export_blob;
+
+    // stats
+    n1k_stats stats{};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+n1k_status fail(n1k_handle* h, n1k_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    h->last_error = buf;
+    return st;
+}
+
+#define HIP_TRY(h, expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(h, _e == hipErrorOutOfMemory ? N1K_OOM : N1K_DEVICE_ERROR, "%s failed: %s", #expr, \
+                        hipGetErrorString(_e));                                                           \
+    } while (0)
+
+uint32_t intern(n1k_handle* h, const std::string& s) {
+    auto it = h->dict_index.find(s);
+    if (it != h->dict_index.end()) return it->second;
+    uint32_t code = (uint32_t)h->dict.size();
+    h->dict.push_back(s);
+    h->dict_index.emplace(s, code);
+    return code;
+}
+
+uint32_t lookup_code(const n1k_handle* h, const char* s) {
+    auto it = h->dict_index.find(s);
+    return it == h->dict_index.end() ? 0xFFFFFFFFu : it->second;
+}
+
+bool to_operand(n1k_handle* h, const Expr* e, Operand& o, PlanError& err) {
+    memset(&o, 0, sizeof o);
+    if (e->kind == EK::Path) {
+        for (size_t i = 0; i < h->plan.paths.size(); i++)
+            if (h->plan.paths[i] == e->text) {
+                o.is_const = 0;
+                o.col = (uint32_t)i;
+                return true;
+            }
+        err.msg = "unbound path " + e->text;
+        return false;
+    }
+    if (e->kind == EK::Const) {
+        o.is_const = 1;
+        o.ctag = e->ctag;
+        o.cpayload = e->ctag == T_STRING ? intern(h, e->cstr) : e->cpayload;
+        return true;
+    }
+    err.unsupported = true;
+    err.msg = "computed operands (arithmetic / nested predicates) are not on the device path yet";
+    return false;
+}
+
+// condition tree -> postfix over predicate terms
+bool compile_cond(n1k_handle* h, const Expr* e, PlanError& err) {
+    Program& P = h->prog;
+    auto push_term = [&](uint32_t op, const Expr* a, const Expr* b, const Expr* c) -> bool {
+        if (P.nterms >= (uint32_t)kMaxTerms || P.nlogic >= (uint32_t)kMaxLogic) {
+            err.unsupported = true;
+            err.msg = "condition too large for the device program";
+            return false;
+        }
+        Term& t = P.terms[P.nterms];
+        memset(&t, 0, sizeof t);
+        t.op = op;
+        if (a && !to_operand(h, a, t.a, err)) return false;
+        if (b && !to_operand(h, b, t.b, err)) return false;
+        if (c && !to_operand(h, c, t.c, err)) return false;
+        P.logic[P.nlogic++] = LogicOp{LOGIC_PUSH, (uint8_t)P.nterms};
+        P.nterms++;
+        return true;
+    };
+    auto push_logic = [&](uint8_t op, uint8_t arg) -> bool {
+        if (P.nlogic >= (uint32_t)kMaxLogic) {
+            err.unsupported = true;
+            err.msg = "condition too large for the device program";
+            return false;
+        }
+        P.logic[P.nlogic++] = LogicOp{op, arg};
+        return true;
+    };
+    switch (e->kind) {
+        case EK::And:
+        case EK::Or:
+            if (e->ch.size() > 16) { err.unsupported = true; err.msg = "AND/OR arity > 16"; return false; }
+            for (auto& c : e->ch)
+                if (!compile_cond(h, c.get(), err)) return false;
+            return push_logic(e->kind == EK::And ? LOGIC_AND : LOGIC_OR, (uint8_t)e->ch.size());
+        case EK::Not:
+            if (!compile_cond(h, e->ch[0].get(), err)) return false;
+            return push_logic(LOGIC_NOT, 0);
+        case EK::Eq: h->need_rank = true; return push_term(TERM_EQ, e->ch[0].get(), e->ch[1].get(), nullptr);
+        case EK::LT: h->need_rank = true; return push_term(TERM_LT, e->ch[0].get(), e->ch[1].get(), nullptr);
+        case EK::LE: h->need_rank = true; return push_term(TERM_LE, e->ch[0].get(), e->ch[1].get(), nullptr);
+        case EK::Between:
+            h->need_rank = true;
+            return push_term(TERM_BETWEEN, e->ch[0].get(), e->ch[1].get(), e->ch[2].get());
+        case EK::IsNull: return push_term(TERM_IS_NULL, e->ch[0].get(), nullptr, nullptr);
+        case EK::IsNotNull: return push_term(TERM_IS_NOT_NULL, e->ch[0].get(), nullptr, nullptr);
+        case EK::IsMissing: return push_term(TERM_IS_MISSING, e->ch[0].get(), nullptr, nullptr);
+        case EK::IsNotMissing: return push_term(TERM_IS_NOT_MISSING, e->ch[0].get(), nullptr, nullptr);
+        case EK::IsValued: return push_term(TERM_IS_VALUED, e->ch[0].get(), nullptr, nullptr);
+        case EK::IsNotValued: return push_term(TERM_IS_NOT_VALUED, e->ch[0].get(), nullptr, nullptr);
+        case EK::Path:
+        case EK::Const: return push_term(TERM_TRUTH, e, nullptr, nullptr);
+        default:
+            err.unsupported = true;
+            err.msg = "arithmetic inside a condition is not on the device path yet";
+            return false;
+    }
+}
+
+bool compile_plan(n1k_handle* h, PlanError& err) {
+    Program& P = h->prog;
+    memset(&P, 0, sizeof P);
+    const ParsedPlan& pl = h->plan;
+    if (pl.paths.size() > (size_t)kMaxCols) { err.unsupported = true; err.msg = "more than 16 leaf paths"; return false; }
+    if (pl.keys.size() > (size_t)kMaxKeys) { err.unsupported = true; err.msg = "more than 4 group keys"; return false; }
+    if (pl.aggs.size() > (size_t)kMaxAggs) { err.unsupported = true; err.msg = "more than 8 aggregates"; return false; }
+    P.ncols = (uint32_t)pl.paths.size();
+    if (pl.condition && !compile_cond(h, pl.condition.get(), err)) return false;
+    P.nkeys = (uint32_t)pl.keys.size();
+    for (uint32_t k = 0; k < P.nkeys; k++)
+        if (!to_operand(h, pl.keys[k].get(), P.keys[k].src, err)) return false;
+    P.naggs = (uint32_t)pl.aggs.size();
+    uint32_t lds_w = 1, glob_w = 0;
+    if (h->opt_rep_row) {
+        P.want_rep_row = 1;
+        P.rep_lds_word = lds_w++;
+    }
+    for (uint32_t a = 0; a < P.naggs; a++) {
+        const AggDef& d = pl.aggs[a];
+        AggSpec& s = P.aggs[a];
+        memset(&s, 0, sizeof s);
+        s.kind = d.kind;
+        s.distinct = d.distinct ? 1 : 0;
+        s.has_operand = d.operand ? 1 : 0;
+        if (d.operand && !to_operand(h, d.operand.get(), s.src, err)) return false;
+        h->agg_names.push_back(d.text);
+        s.lds_off = lds_w;
+        s.glob_off = glob_w;
+        if (d.distinct) {
+            h->has_distinct = true;
+            glob_w += 1;
+        } else if (d.kind == AGG_COUNT || d.kind == AGG_COUNTN) {
+            lds_w += 1;
+            glob_w += 1;
+        } else if (d.kind == AGG_SUM || d.kind == AGG_AVG) {
+            lds_w += kLdsWordsSum;
+            glob_w += kGlobWordsSum;
+        } else {
+            h->need_rank = true;
+            lds_w += kWordsMinMax;
+            glob_w += kWordsMinMax;
+        }
+    }
+    if (h->has_distinct) {
+        err.unsupported = true;
+        err.msg = "DISTINCT aggregates are not on the device path yet";
+        return false;
+    }
+    P.lds_words = lds_w;
+    P.glob_words = glob_w ? glob_w : 1;
+    return true;
+}
+
+n1k_status ensure_device(n1k_handle* h) {
+    if (h->device_ready) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        return N1K_OK;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(h, N1K_DEVICE_ERROR, "no HIP device available (this library has no CPU fallback)");
+    if (h->device < 0) {
+        int cur = 0;
+        HIP_TRY(h, hipGetDevice(&cur));
+        h->device = cur;
+    }
+    if (h->device >= n) return fail(h, N1K_DEVICE_ERROR, "device %d out of range (%d visible)", h->device, n);
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (!h->stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    HIP_TRY(h, h->d_err.ensure(4));
+    HIP_TRY(h, h->d_counters.ensure(8));
+    HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4 * sizeof(uint32_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 8 * sizeof(unsigned long long), h->stream));
+    h->device_ready = true;
+    return N1K_OK;
+}
+
+// bytewise rank of every dictionary string (value/string.go:116-130 compares Go strings bytewise)
+n1k_status ensure_rank(n1k_handle* h) {
+    if (!h->need_rank || h->rank_built_for == h->dict.size()) {
+        h->prog.str_rank = h->d_rank.p;
+        return N1K_OK;
+    }
+    size_t n = h->dict.size();
+    std::vector<uint32_t> order(n), rank(std::max(n, (size_t)1));
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h->dict[a] < h->dict[b]; });
+    for (size_t i = 0; i < n; i++) rank[order[i]] = (uint32_t)i;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // earlier launches may still read the old table
+    HIP_TRY(h, h->d_rank.ensure(std::max(n, (size_t)1)));
+    if (n) HIP_TRY(h, hipMemcpy(h->d_rank.p, rank.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->rank_built_for = n;
+    h->prog.str_rank = h->d_rank.p;
+    return N1K_OK;
+}
+
+// Decide the key bit fields once the column kinds are known (first batch).
+n1k_status fix_layout(n1k_handle* h, const n1k_batch* b) {
+    Program& P = h->prog;
+    for (uint32_t c = 0; c < P.ncols; c++) h->col_kinds[c] = b->cols[c].kind;
+    uint32_t n_dict = 0, n_tag = 0;
+    for (uint32_t k = 0; k < P.nkeys; k++) {
+        KeySpec& ks = P.keys[k];
+        bool dict = !ks.src.is_const && h->col_kinds[ks.src.col] == N1K_COL_DICT32;
+        ks.mode = dict ? KEYM_DICT : KEYM_TAGGED;
+        if (dict) n_dict++; else n_tag++;
+    }
+    uint32_t dbits = 0, tbits = 0;
+    if (n_tag == 0 && n_dict) dbits = std::min(32u, 63u / n_dict);
+    else if (n_tag) {
+        dbits = n_dict ? 24u : 0u;
+        if (n_dict * dbits + n_tag * 8 > 63) dbits = (63 - n_tag * 8) / std::max(n_dict, 1u);
+        tbits = (63 - n_dict * dbits) / n_tag;
+    }
+    uint32_t shift = 0;
+    for (uint32_t k = 0; k < P.nkeys; k++) {
+        KeySpec& ks = P.keys[k];
+        ks.bits = ks.mode == KEYM_DICT ? dbits : tbits;
+        ks.shift = shift;
+        shift += ks.bits;
+        if (ks.bits < 4) return fail(h, N1K_UNSUPPORTED, "group key layout does not fit 63 bits");
+    }
+    h->layout_fixed = true;
+    return N1K_OK;
+}
+
+}  // namespace
+
+// ---- table management -------------------------------------------------------------------------
+
+namespace {
+
+n1k_status alloc_table(n1k_handle* h, uint64_t capacity, GlobalTable& t, DevBuf<uint64_t>& keys, DevBuf<uint64_t>& acc,
+                       DevBuf<uint64_t>& rep) {
+    HIP_TRY(h, keys.ensure(capacity));
+    HIP_TRY(h, acc.ensure(capacity * h->prog.glob_words));
+    if (h->prog.want_rep_row) HIP_TRY(h, rep.ensure(capacity));
+    t.keys = keys.p;
+    t.acc = acc.p;
+    t.rep_row = h->prog.want_rep_row ? rep.p : nullptr;
+    t.capacity = capacity;
+    HIP_TRY(h, launch_init_table(h->prog, t, 0, capacity, h->stream));
+    return N1K_OK;
+}
+
+// Make sure the global table can take `incoming_rows` more rows worth of new groups (bounded by max_groups).
+n1k_status ensure_table(n1k_handle* h, uint64_t incoming_rows) {
+    // groups <= rows pushed so far: an upper bound that needs no device round trip
+    uint64_t want_groups = std::min<uint64_t>(h->opt_max_groups, h->row_base + incoming_rows);
+    if (h->prog.nkeys == 0) want_groups = 1;
+    uint64_t cap = next_pow2(std::max<uint64_t>(want_groups * 2, 1024));
+    if (cap <= h->table.capacity) return N1K_OK;
+    if (!h->table.capacity) return alloc_table(h, cap, h->table, h->d_keys, h->d_acc, h->d_rep);
+    // grow: rehash every occupied slot into a bigger table (keys keep their packed form)
+    GlobalTable nt{};
+    DevBuf<uint64_t> nk, na, nr;
+    n1k_status st = alloc_table(h, cap, nt, nk, na, nr);
+    if (st != N1K_OK) return st;
+    HIP_TRY(h, launch_rehash(h->prog, h->table, nt, h->d_err.p, h->d_counters.p + 4, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->d_keys.release();
+    h->d_acc.release();
+    h->d_rep.release();
+    h->d_keys = nk;
+    h->d_acc = na;
+    h->d_rep = nr;
+    h->table = nt;
+    return N1K_OK;
+}
+
+hipEvent_t get_event(n1k_handle* h) {
+    if (!h->event_pool.empty()) {
+        hipEvent_t e = h->event_pool.back();
+        h->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void drain_events(n1k_handle* h) {
+    for (auto& pr : h->events) {
+        float ms = 0.f;
+        if (pr.first && pr.second && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) h->stats.device_ms += ms;
+        if (pr.first) h->event_pool.push_back(pr.first);
+        if (pr.second) h->event_pool.push_back(pr.second);
+    }
+    h->events.clear();
+}
+
+n1k_status validate_batch(n1k_handle* h, const n1k_batch* b) {
+    if (!b) return fail(h, N1K_INVALID, "null batch");
+    if (b->ncols != h->prog.ncols) return fail(h, N1K_INVALID, "batch has %u columns, plan needs %u", b->ncols, h->prog.ncols);
+    for (uint32_t c = 0; c < b->ncols; c++) {
+        const n1k_col& col = b->cols[c];
+        if (col.kind == N1K_COL_DICT32) {
+            if (b->nrows && !col.codes) return fail(h, N1K_INVALID, "column %u: null codes", c);
+        } else if (col.kind == N1K_COL_TAGGED64) {
+            if (b->nrows && (!col.tags || !col.payload)) return fail(h, N1K_INVALID, "column %u: null tags/payload", c);
+        } else
+            return fail(h, N1K_INVALID, "column %u: unknown kind %u", c, col.kind);
+        if (h->layout_fixed && col.kind != h->col_kinds[c])
+            return fail(h, N1K_INVALID, "column %u changed kind between batches", c);
+    }
+    return N1K_OK;
+}
+
+uint64_t batch_bytes_per_row(const n1k_handle* h) {
+    uint64_t b = 0;
+    for (uint32_t c = 0; c < h->prog.ncols; c++) b += h->col_kinds[c] == N1K_COL_DICT32 ? 4 : 9;
+    return b;
+}
+
+n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
+    Program& P = h->prog;
+    n1k_status st = ensure_table(h, b->nrows);
+    if (st != N1K_OK) return st;
+    ScanArgs A{};
+    A.nrows = b->nrows;
+    A.row_base = h->row_base;
+    uint32_t slots = h->opt_lds_bytes / (P.lds_words * 8);
+    slots = (uint32_t)std::min<uint64_t>(slots, 1u << 15);
+    if (P.nkeys == 0) slots = 2;
+    if (slots < 2) return fail(h, N1K_UNSUPPORTED, "accumulator row too wide for LDS");
+    A.lds_slots = slots;
+    A.lds_max_fill = std::max(1u, (uint32_t)((uint64_t)slots * 5 / 8));
+    A.err_flags = h->d_err.p;
+    A.rows_selected = h->d_counters.p + 0;
+    A.wave_reduce = h->opt_wave_reduce;
+    A.compact = h->opt_compact;
+    uint64_t tile_rows = 256 * 4;
+    uint64_t ntiles = (b->nrows + tile_rows - 1) / tile_rows;
+    uint32_t grid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * 2);
+    grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, ntiles));
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    if (e0) (void)hipEventRecord(e0, h->stream);
+    HIP_TRY(h, launch_scan_group(P, A, h->table, h->d_counters.p + 1, grid, h->stream));
+    if (e1) (void)hipEventRecord(e1, h->stream);
+    h->events.emplace_back(e0, e1);
+    h->stats.agg_mode = N1K_MODE_LDS_HASH;
+    return N1K_OK;
+}
+
+n1k_status run_filter_batch(n1k_handle* h, const n1k_batch* b) {
+    Program& P = h->prog;
+    uint64_t ntiles = (b->nrows + kFilterTile - 1) / kFilterTile;
+    if (ntiles == 0) return N1K_OK;
+    HIP_TRY(h, h->d_mask.ensure(ntiles * (kFilterTile / 64)));
+    HIP_TRY(h, h->d_tile_cnt.ensure(ntiles));
+    HIP_TRY(h, h->d_tile_off.ensure(ntiles));
+    uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)h->num_cus * 8);
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    if (e0) (void)hipEventRecord(e0, h->stream);
+    HIP_TRY(h, launch_filter_mask(P, b->nrows, h->d_mask.p, h->d_tile_cnt.p, h->d_err.p, grid, h->stream));
+    HIP_TRY(h, launch_tile_scan(h->d_tile_cnt.p, h->d_tile_off.p, ntiles, h->d_counters.p + 3, h->stream));
+    unsigned long long total = 0;
+    HIP_TRY(h, hipMemcpyAsync(&total, h->d_counters.p + 3, sizeof total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (total) {
+        HIP_TRY(h, h->d_sel.ensure(total));
+        HIP_TRY(h, launch_filter_compact(h->d_mask.p, h->d_tile_off.p, b->nrows, h->row_base, h->d_sel.p, grid, h->stream));
+        size_t old = h->selected.size();
+        h->selected.resize(old + total);
+        HIP_TRY(h, hipMemcpyAsync(h->selected.data() + old, h->d_sel.p, total * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (e1) (void)hipEventRecord(e1, h->stream);
+    h->events.emplace_back(e0, e1);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stats.rows_selected += total;
+    return N1K_OK;
+}
+
+n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
+    if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    st = validate_batch(h, b);
+    if (st != N1K_OK) return st;
+    if (!h->layout_fixed) {
+        st = fix_layout(h, b);
+        if (st != N1K_OK) return st;
+    }
+    Program& P = h->prog;
+    for (uint32_t c = 0; c < P.ncols; c++) {
+        P.cols[c].kind = b->cols[c].kind == N1K_COL_DICT32 ? COLK_DICT32 : COLK_TAGGED64;
+        P.cols[c].tags = b->cols[c].tags;
+        P.cols[c].payload = b->cols[c].payload;
+        P.cols[c].codes = b->cols[c].codes;
+    }
+    P.dict_size = (uint32_t)h->dict.size();
+    P.empty_str_code = lookup_code(h, "");
+    P.empty_arr_code = lookup_code(h, "[]");
+    P.empty_obj_code = lookup_code(h, "{}");
+    st = ensure_rank(h);
+    if (st != N1K_OK) return st;
+    if (b->nrows) {
+        st = h->plan.has_group ? run_group_batch(h, b) : run_filter_batch(h, b);
+        if (st != N1K_OK) return st;
+    }
+    h->row_base += b->nrows;
+    h->stats.rows_in += b->nrows;
+    h->stats.batches += 1;
+    h->stats.bytes_scanned += b->nrows * batch_bytes_per_row(h);
+    return N1K_OK;
+}
+
+void default_value(const AggDef& d, n1k_value& v, n1k_partial& p) {
+    memset(&v, 0, sizeof v);
+    memset(&p, 0, sizeof p);
+    p.extreme.tag = N1K_T_NULL;
+    // Default(): COUNT/COUNTN (also DISTINCT) 0, everything else NULL
+    if (d.kind == AGG_COUNT || d.kind == AGG_COUNTN) {
+        v.tag = N1K_T_INT;
+        v.v.i = 0;
+    } else
+        v.tag = N1K_T_NULL;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+
+extern "C" {
+
+int n1k_abi_version(void) { return N1K_ABI_VERSION; }
+
+int n1k_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* n1k_create_error(void) { return g_create_error.c_str(); }
+
+n1k_status n1k_create(const char* plan_json, size_t len, n1k_handle** out) {
+    if (out) *out = nullptr;
+    if (!plan_json || !out) {
+        g_create_error = "null argument";
+        return N1K_INVALID;
+    }
+    auto* h = new n1k_handle();
+    PlanError err;
+    if (!parse_plan_json(plan_json, len, h->plan, err) || !compile_plan(h, err)) {
+        g_create_error = err.msg;
+        n1k_status st = err.unsupported ? N1K_UNSUPPORTED : N1K_INVALID;
+        delete h;
+        return st;
+    }
+    g_create_error.clear();
+    *out = h;
+    return N1K_OK;
+}
+
+void n1k_destroy(n1k_handle* h) {
+    if (!h) return;
+    if (h->device_ready) {
+        (void)hipSetDevice(h->device);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        drain_events(h);
+        for (auto e : h->event_pool) (void)hipEventDestroy(e);
+        h->d_rank.release();
+        h->d_keys.release();
+        h->d_acc.release();
+        h->d_rep.release();
+        h->d_err.release();
+        h->d_counters.release();
+        for (auto& b : h->st_tags) b.release();
+        for (auto& b : h->st_payload) b.release();
+        for (auto& b : h->st_codes) b.release();
+        h->d_mask.release();
+        h->d_tile_off.release();
+        h->d_sel.release();
+        h->d_tile_cnt.release();
+        h->d_okeys.release();
+        h->d_oaggs.release();
+        h->d_oparts.release();
+        h->d_orep.release();
+        if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+n1k_status n1k_reset(n1k_handle* h) {
+    if (!h) return N1K_INVALID;
+    h->stop_flag.store(0);
+    h->row_base = 0;
+    h->selected.clear();
+    h->r_keys.clear();
+    h->r_aggs.clear();
+    h->r_parts.clear();
+    h->r_rep.clear();
+    memset(&h->stats, 0, sizeof h->stats);
+    if (h->device_ready) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        drain_events(h);
+        h->stats.device_ms = 0;
+        HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4 * sizeof(uint32_t), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 8 * sizeof(unsigned long long), h->stream));
+        if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->stream));
+    }
+    return N1K_OK;
+}
+
+void n1k_stop(n1k_handle* h) {
+    if (h) h->stop_flag.store(1);
+}
+
+const char* n1k_last_error(const n1k_handle* h) { return h ? h->last_error.c_str() : "null handle"; }
+
+uint32_t n1k_num_columns(const n1k_handle* h) { return h ? (uint32_t)h->plan.paths.size() : 0; }
+const char* n1k_column_path(const n1k_handle* h, uint32_t i) {
+    return (h && i < h->plan.paths.size()) ? h->plan.paths[i].c_str() : nullptr;
+}
+uint32_t n1k_num_keys(const n1k_handle* h) { return h ? (uint32_t)h->plan.keys.size() : 0; }
+uint32_t n1k_num_aggregates(const n1k_handle* h) { return h ? (uint32_t)h->plan.aggs.size() : 0; }
+const char* n1k_aggregate_name(const n1k_handle* h, uint32_t i) {
+    return (h && i < h->agg_names.size()) ? h->agg_names[i].c_str() : nullptr;
+}
+
+n1k_status n1k_dict_intern(n1k_handle* h, uint32_t n, const uint64_t* offsets, const char* bytes, uint32_t* out_codes) {
+    if (!h || (n && (!offsets || !bytes || !out_codes))) return N1K_INVALID;
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(h, N1K_INVALID, "dictionary offsets are not monotone");
+        out_codes[i] = intern(h, std::string(bytes + offsets[i], (size_t)(offsets[i + 1] - offsets[i])));
+    }
+    if (h->dict.size() >= 0xFFFFFFF0ull) return fail(h, N1K_OOM, "dictionary too large");
+    return N1K_OK;
+}
+
+uint32_t n1k_dict_size(const n1k_handle* h) { return h ? (uint32_t)h->dict.size() : 0; }
+
+n1k_status n1k_dict_get(const n1k_handle* h, uint32_t code, const char** ptr, size_t* len) {
+    if (!h || !ptr || !len || code >= h->dict.size()) return N1K_INVALID;
+    *ptr = h->dict[code].data();
+    *len = h->dict[code].size();
+    return N1K_OK;
+}
+
+n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return N1K_INVALID;
+    std::string n = name;
+    if (n == "agg_mode") h->opt_agg_mode = value;
+    else if (n == "max_groups") h->opt_max_groups = value > 0 ? (uint64_t)value : 1;
+    else if (n == "grid_blocks") h->opt_grid_blocks = (uint32_t)std::max<int64_t>(0, value);
+    else if (n == "compact") h->opt_compact = value ? 1 : 0;
+    else if (n == "wave_reduce") h->opt_wave_reduce = value ? 1 : 0;
+    else if (n == "lds_bytes") h->opt_lds_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 160 * 1024);
+    else if (n == "device") {
+        if (h->device_ready) return fail(h, N1K_INVALID, "device must be chosen before the first push");
+        h->device = (int)value;
+    } else if (n == "stream") {
+        if (h->device_ready) return fail(h, N1K_INVALID, "stream must be chosen before the first push");
+        h->stream = (hipStream_t)(uintptr_t)value;
+        h->own_stream = false;
+    } else if (n == "rep_row") {
+        if (h->layout_fixed) return fail(h, N1K_INVALID, "rep_row must be chosen before the first push");
+        h->opt_rep_row = value ? 1 : 0;
+        PlanError err;
+        h->agg_names.clear();
+        h->has_distinct = false;
+        if (!compile_plan(h, err)) return fail(h, N1K_INVALID, "%s", err.msg.c_str());
+    } else
+        return fail(h, N1K_INVALID, "unknown option %s", name);
+    return N1K_OK;
+}
+
+n1k_status n1k_push_device_batch(n1k_handle* h, const n1k_batch* batch) {
+    if (!h) return N1K_INVALID;
+    return push_device(h, batch);
+}
+
+n1k_status n1k_push_batch(n1k_handle* h, const n1k_batch* batch) {
+    if (!h) return N1K_INVALID;
+    if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    st = validate_batch(h, batch);
+    if (st != N1K_OK) return st;
+    uint32_t nc = batch->ncols;
+    h->st_tags.resize(std::max<size_t>(h->st_tags.size(), nc));
+    h->st_payload.resize(std::max<size_t>(h->st_payload.size(), nc));
+    h->st_codes.resize(std::max<size_t>(h->st_codes.size(), nc));
+    // the previous batch's kernels may still read the staging buffers
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<n1k_col> dcols(nc);
+    uint64_t n = batch->nrows;
+    for (uint32_t c = 0; c < nc; c++) {
+        const n1k_col& col = batch->cols[c];
+        dcols[c] = col;
+        if (col.kind == N1K_COL_DICT32) {
+            HIP_TRY(h, h->st_codes[c].ensure(n));
+            if (n) HIP_TRY(h, hipMemcpyAsync(h->st_codes[c].p, col.codes, n * 4, hipMemcpyHostToDevice, h->stream));
+            dcols[c].codes = h->st_codes[c].p;
+        } else {
+            HIP_TRY(h, h->st_tags[c].ensure(n));
+            HIP_TRY(h, h->st_payload[c].ensure(n));
+            if (n) {
+                HIP_TRY(h, hipMemcpyAsync(h->st_tags[c].p, col.tags, n, hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(h->st_payload[c].p, col.payload, n * 8, hipMemcpyHostToDevice, h->stream));
+            }
+            dcols[c].tags = h->st_tags[c].p;
+            dcols[c].payload = h->st_payload[c].p;
+        }
+    }
+    // cgo rule: caller memory is not retained after return
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    n1k_batch db = *batch;
+    db.cols = dcols.data();
+    return push_device(h, &db);
+}
+
+n1k_status n1k_sync(n1k_handle* h) {
+    if (!h) return N1K_INVALID;
+    if (!h->device_ready) return N1K_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    drain_events(h);
+    return N1K_OK;
+}
+
+n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
+    if (!h || !out) return N1K_INVALID;
+    memset(out, 0, sizeof *out);
+    if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
+    const ParsedPlan& pl = h->plan;
+    uint32_t nk = (uint32_t)pl.keys.size(), na = (uint32_t)pl.aggs.size();
+    out->nkeys = nk;
+    out->naggs = na;
+    uint32_t err_flags = 0;
+    unsigned long long counters[8] = {0};
+    if (h->device_ready) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        drain_events(h);
+    } else if (h->stats.rows_in == 0) {
+        // no batch was ever pushed: nothing ran on the device; only the empty-input row can be produced
+        n1k_status st = ensure_device(h);
+        if (st != N1K_OK) return st;
+    }
+    if (!pl.has_group) {
+        if (err_flags & ERR_UNSUPPORTED_VALUE)
+            return fail(h, N1K_UNSUPPORTED_DATA, "a value outside the device subset was met (ordering of arrays/objects)");
+        out->nselected = h->selected.size();
+        out->selected = h->selected.data();
+        h->stats.groups_out = 0;
+        return N1K_OK;
+    }
+    h->stats.rows_selected = counters[0];
+    uint64_t ng = counters[1];
+    h->r_keys.clear();
+    h->r_aggs.clear();
+    h->r_parts.clear();
+    h->r_rep.clear();
+    if (ng > 0) {
+        HIP_TRY(h, h->d_okeys.ensure(ng * std::max(nk, 1u)));
+        HIP_TRY(h, h->d_oaggs.ensure(ng * std::max(na, 1u)));
+        HIP_TRY(h, h->d_oparts.ensure(ng * std::max(na, 1u)));
+        HIP_TRY(h, h->d_orep.ensure(ng));
+        HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, launch_finalize(h->prog, h->table, h->d_okeys.p, h->d_oaggs.p, h->d_oparts.p, h->d_orep.p,
+                                   h->d_counters.p + 2, ng, h->d_err.p, h->stream));
+        h->r_keys.resize(ng * nk);
+        h->r_aggs.resize(ng * na);
+        h->r_rep.resize(ng);
+        std::vector<OutPartial> parts(ng * na);
+        if (nk) HIP_TRY(h, hipMemcpyAsync(h->r_keys.data(), h->d_okeys.p, ng * nk * sizeof(n1k_value), hipMemcpyDeviceToHost, h->stream));
+        if (na) {
+            HIP_TRY(h, hipMemcpyAsync(h->r_aggs.data(), h->d_oaggs.p, ng * na * sizeof(n1k_value), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(parts.data(), h->d_oparts.p, ng * na * sizeof(OutPartial), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->r_rep.data(), h->d_orep.p, ng * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->r_parts.resize(ng * na);
+        for (size_t i = 0; i < parts.size(); i++) {
+            n1k_partial& p = h->r_parts[i];
+            memset(&p, 0, sizeof p);
+            p.count = parts[i].count;
+            p.isum = parts[i].isum;
+            p.fsum = parts[i].fsum;
+            p.int_exact = parts[i].flags & 1u;
+            p.has_float = (parts[i].flags >> 1) & 1u;
+            p.extreme.tag = (uint8_t)parts[i].ext_tag;
+            p.extreme.v.code = parts[i].ext_payload;
+            p.distinct = parts[i].distinct;
+        }
+    }
+    if (err_flags & ERR_TABLE_FULL)
+        return fail(h, N1K_OOM, "group table capacity exceeded: raise the max_groups option (now %llu)",
+                    (unsigned long long)h->opt_max_groups);
+    if (err_flags & ERR_UNPACKABLE_KEY)
+        return fail(h, N1K_UNSUPPORTED_DATA,
+                    "a group key value does not fit the packed key (non-integral float or very wide integer key)");
+    if (err_flags & ERR_UNSUPPORTED_VALUE)
+        return fail(h, N1K_UNSUPPORTED_DATA, "a value outside the device subset was met (ordering of arrays/objects)");
+    if (ng == 0 && nk == 0) {
+        // FinalGroup.afterItems: no keys and no input -> one row of Default() values (execution/group_final.go:108-117)
+        h->r_aggs.resize(na);
+        h->r_parts.resize(na);
+        h->r_rep.assign(1, ~0ull);
+        for (uint32_t a = 0; a < na; a++) default_value(pl.aggs[a], h->r_aggs[a], h->r_parts[a]);
+        ng = 1;
+    }
+    out->ngroups = ng;
+    out->keys = h->r_keys.data();
+    out->aggs = h->r_aggs.data();
+    out->partials = h->r_parts.data();
+    out->rep_row = h->r_rep.data();
+    h->stats.groups_out = ng;
+    return N1K_OK;
+}
+
+n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
+    if (!h || !out) return N1K_INVALID;
+    *out = h->stats;
+    return N1K_OK;
+}
+
+n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uint32_t nparts, uint64_t capacity_rows,
+                                      const n1k_col* out_cols, uint64_t* out_counts) {
+    if (!h) return N1K_INVALID;
+    (void)batch; (void)nparts; (void)capacity_rows; (void)out_cols; (void)out_counts;
+    return fail(h, N1K_UNSUPPORTED, "partition kernel not built yet");
+}
+
+n1k_status n1k_export_groups(n1k_handle* h, const void** blob, size_t* len) {
+    if (!h) return N1K_INVALID;
+    (void)blob; (void)len;
+    return fail(h, N1K_UNSUPPORTED, "export not built yet");
+}
+
+n1k_status n1k_merge_groups(n1k_handle* h, const void* blob, size_t len) {
+    if (!h) return N1K_INVALID;
+    (void)blob; (void)len;
+    return fail(h, N1K_UNSUPPORTED, "merge not built yet");
+}
+
+n1k_status n1k_synth_columns(int device, void* stream, const n1k_synth_spec* spec, uint32_t* cat_codes, uint8_t* price_tags,
+                             uint64_t* price_payload, uint8_t* user_tags, uint64_t* user_payload, uint8_t* region_tags,
+                             uint64_t* region_payload) {
+    if (!spec) return N1K_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return N1K_DEVICE_ERROR;
+    SynthArgs a{};
+    a.seed = spec->seed;
+    a.first_row = spec->first_row;
+    a.nrows = spec->nrows;
+    a.total_rows = spec->total_rows;
+    a.k_cat = spec->k_cat;
+    a.cat_cdf = spec->zipf ? spec->cat_cdf : nullptr;
+    a.cat_codes = cat_codes;
+    a.price_tags = price_tags;
+    a.price_payload = price_payload;
+    a.user_tags = user_tags;
+    a.user_payload = user_payload;
+    a.region_tags = region_tags;
+    a.region_payload = region_payload;
+    if (launch_synth(a, (hipStream_t)stream) != hipSuccess) return N1K_DEVICE_ERROR;
+    return N1K_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// n1k_kernels.h — launch interface between the host engine and n1k_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "n1k_types.h"
+
+namespace n1k {
+
+constexpr int kFilterTile = 256;  // rows per tile of the Filter-only path
+
+struct OutValue {  // same 16-byte layout as n1k_value
+    uint64_t tag;  // low byte = tag (little endian), rest zero
+    uint64_t payload;
+};
+
+struct OutPartial {
+    int64_t count;
+    int64_t isum;
+    double fsum;
+    uint32_t flags;  // bit0 int_exact, bit1 has_float
+    uint32_t ext_tag;
+    uint64_t ext_payload;
+    int64_t distinct;
+};
+
+struct SynthArgs {
+    uint64_t seed, first_row, nrows, total_rows;
+    uint32_t k_cat, pad;
+    const double* cat_cdf;
+    uint32_t* cat_codes;
+    uint8_t* price_tags;
+    uint64_t* price_payload;
+    uint8_t* user_tags;
+    uint64_t* user_payload;
+    uint8_t* region_tags;
+    uint64_t* region_payload;
+};
+
+hipError_t launch_init_table(const Program& P, const GlobalTable& G, uint64_t first, uint64_t count, hipStream_t st);
+hipError_t launch_rehash(const Program& P, const GlobalTable& oldt, const GlobalTable& newt, uint32_t* err_flags,
+                         unsigned long long* ngroups_scratch, hipStream_t st);
+hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTable& G, unsigned long long* ngroups,
+                             uint32_t grid, hipStream_t st);
+hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,
+                           OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count, uint64_t max_out,
+                           uint32_t* err_flags, hipStream_t st);
+hipError_t launch_filter_mask(const Program& P, uint64_t nrows, uint64_t* mask_words, uint32_t* tile_counts,
+                              uint32_t* err_flags, uint32_t grid, hipStream_t st);
+hipError_t launch_tile_scan(const uint32_t* counts, uint64_t* offsets, uint64_t ntiles, unsigned long long* total,
+                            hipStream_t st);
+hipError_t launch_filter_compact(const uint64_t* mask_words, const uint64_t* tile_offsets, uint64_t nrows,
+                                 uint64_t row_base, uint64_t* out_rows, uint32_t grid, hipStream_t st);
+hipError_t launch_synth(const SynthArgs& a, hipStream_t st);
+
+}  // namespace n1k

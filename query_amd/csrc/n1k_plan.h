@@ -1,0 +1,62 @@
+// n1k_plan.h — host side: the reference's plan JSON and expression.Stringer text -> compiled plan.
+//
+// Mirrors, for the hot path only, what plan.(*Filter).UnmarshalJSON (plan/filter.go:55-71) and
+// plan.(*InitialGroup).UnmarshalJSON (plan/group.go:72-103) do with expression/parser: parse the
+// stringified expressions back into trees.  Anything outside the device subset is reported as
+// "unsupported" so that the caller keeps the reference operators (N1K_UNSUPPORTED).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include "n1k_types.h"
+
+namespace n1k {
+
+struct PlanError {
+    bool unsupported = false;  // valid but outside the device subset
+    std::string msg;
+};
+
+// expression tree (subset of expression/*.go)
+enum class EK {
+    Const, Path, Add, Sub, Mult, Div, Mod, Neg, IDiv, IMod, Eq, LT, LE, Between, And, Or, Not,
+    IsNull, IsNotNull, IsMissing, IsNotMissing, IsValued, IsNotValued
+};
+
+struct Expr {
+    EK kind;
+    std::vector<std::unique_ptr<Expr>> ch;
+    // Const
+    uint32_t ctag = T_NULL;
+    uint64_t cpayload = 0;   // INT: int64, FLOAT: bits; STRING: filled with the dictionary code at bind time
+    std::string cstr;        // STRING constant bytes
+    // Path
+    std::string text;        // exact stringer text, e.g. (`default`.`price`)
+};
+
+struct AggDef {
+    uint32_t kind;  // AGG_*
+    bool distinct = false;
+    std::unique_ptr<Expr> operand;  // null for count(*)
+    std::string text;               // agg.String(): key of the reference's "aggregates" attachment map
+};
+
+struct ParsedPlan {
+    bool has_filter = false;
+    bool has_group = false;
+    std::unique_ptr<Expr> condition;
+    std::vector<std::unique_ptr<Expr>> keys;
+    std::vector<AggDef> aggs;
+    std::vector<std::string> paths;  // distinct leaf paths in column order
+    int max_parallelism = 0;
+};
+
+// Parse plan JSON (Sequence / Parallel / Filter / InitialGroup nodes).  Returns false and fills err on failure.
+bool parse_plan_json(const char* json, size_t len, ParsedPlan& out, PlanError& err);
+
+// Parse one stringified expression / aggregate.
+std::unique_ptr<Expr> parse_expression(const std::string& s, PlanError& err);
+bool parse_aggregate(const std::string& s, AggDef& out, PlanError& err);
+
+}  // namespace n1k

@@ -1,0 +1,149 @@
+// n1k_types.h — structures shared by the host engine and the HIP kernels.
+//
+// The host compiles the reference's plan JSON (plan/filter.go:46-53,
+// plan/group.go:54-70) into a small, wave-uniform "program"; the kernels
+// interpret it with scalar control flow (every lane runs the same op on its
+// own rows), so the interpretive overhead stays on the scalar unit.
+#pragma once
+#include <stdint.h>
+
+namespace n1k {
+
+constexpr int kMaxCols = 16;
+constexpr int kMaxTerms = 12;
+constexpr int kMaxLogic = 32;
+constexpr int kMaxKeys = 4;
+constexpr int kMaxAggs = 8;
+constexpr int kMaxLdsWords = 40;   // 1 key word + accumulators
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+
+// value tags == n1k_tag (include/n1k.h)
+enum : uint32_t { T_MISSING = 0, T_NULL, T_FALSE, T_TRUE, T_INT, T_FLOAT, T_STRING, T_ARRAY, T_OBJECT };
+
+// 4-valued logic of N1QL (expression/logic_and.go:64-89, logic_or.go:98-123)
+enum : uint32_t { L_FALSE = 0, L_TRUE = 1, L_NULL = 2, L_MISSING = 3 };
+
+enum : uint32_t { COLK_TAGGED64 = 0, COLK_DICT32 = 1 };
+
+struct DevCol {
+    const uint8_t* tags;
+    const uint64_t* payload;
+    const uint32_t* codes;
+    uint32_t kind;
+    uint32_t pad;
+};
+
+struct Operand {
+    uint32_t is_const;  // 0: column, 1: constant
+    uint32_t col;
+    uint32_t ctag;
+    uint32_t pad;
+    uint64_t cpayload;
+};
+
+// predicate terms (leaves of the 4-valued logic tree)
+enum : uint32_t {
+    TERM_EQ = 0,       // expression/comp_eq.go:76-78
+    TERM_LT,           // expression/comp_lt.go:57-65
+    TERM_LE,           // expression/comp_le.go:57-65
+    TERM_BETWEEN,      // expression/comp_between.go:58-78
+    TERM_IS_NULL,      // expression/comp_null.go:58-67
+    TERM_IS_NOT_NULL,  // comp_null.go:116-125
+    TERM_IS_MISSING,   // comp_missing.go:62-69
+    TERM_IS_NOT_MISSING,
+    TERM_IS_VALUED,    // comp_valued.go:61-68
+    TERM_IS_NOT_VALUED,
+    TERM_TRUTH         // a bare value used as a condition: type + Truth()
+};
+
+struct Term {
+    uint32_t op;
+    uint32_t pad;
+    Operand a, b, c;
+};
+
+enum : uint8_t { LOGIC_PUSH = 0, LOGIC_AND, LOGIC_OR, LOGIC_NOT };
+struct LogicOp {
+    uint8_t op;
+    uint8_t arg;  // PUSH: term index; AND/OR: arity
+};
+
+// group key packing: every key becomes a bit field of one 63-bit word
+enum : uint32_t { KEYM_DICT = 0, KEYM_TAGGED = 1 };
+struct KeySpec {
+    Operand src;
+    uint32_t mode;
+    uint32_t bits;
+    uint32_t shift;
+    uint32_t pad;
+};
+
+enum : uint32_t { AGG_SUM = 0, AGG_COUNT, AGG_COUNTN, AGG_AVG, AGG_MIN, AGG_MAX };
+struct AggSpec {
+    uint32_t kind;
+    uint32_t distinct;
+    uint32_t has_operand;
+    uint32_t lds_off;   // first accumulator word inside an LDS slot
+    uint32_t glob_off;  // first accumulator word inside a global-table row
+    uint32_t pad;
+    Operand src;
+};
+
+// LDS accumulator words per aggregate
+//   COUNT/COUNTN : [cnt]
+//   SUM/AVG      : [isum i64][fsum f64][n_neg<<32 | n_nonneg][n_float]
+//   MIN/MAX      : [flags][ival i64][fval sortable u64][sval rank<<32|code]
+//   * DISTINCT   : (none; pairs go to the distinct log)
+// global accumulator words per aggregate
+//   COUNT/COUNTN : [cnt]
+//   SUM/AVG      : [isum_lo][isum_hi][fsum][n_nonneg][n_neg][n_float]
+//   MIN/MAX      : [flags][ival][fval][sval]
+//   * DISTINCT   : [distinct count]  (filled at finish)
+constexpr uint32_t kLdsWordsSum = 4, kGlobWordsSum = 6, kWordsMinMax = 4;
+
+// MIN/MAX flag bits
+enum : uint64_t { MM_FALSE = 1, MM_TRUE = 2, MM_INT = 4, MM_FLOAT = 8, MM_STRING = 16, MM_OTHER = 32 };
+
+// run-time problem bits reported by the kernels
+enum : uint32_t {
+    ERR_UNPACKABLE_KEY = 1,   // a group key value does not fit its bit field (wide ints, non-integral floats)
+    ERR_TABLE_FULL = 2,       // global group table capacity exceeded
+    ERR_UNSUPPORTED_VALUE = 4 // e.g. ordering two arrays/objects
+};
+
+struct Program {
+    uint32_t ncols, nterms, nlogic, nkeys, naggs, pad0;
+    uint32_t lds_words;     // words per LDS slot (key + accumulators)
+    uint32_t glob_words;    // words per global row (accumulators only)
+    uint32_t want_rep_row;  // keep min row ordinal per group
+    uint32_t rep_lds_word;  // LDS word of the rep row (when wanted)
+    uint32_t dict_size;
+    uint32_t empty_str_code, empty_arr_code, empty_obj_code;  // codes of "", "[]", "{}" or 0xFFFFFFFF
+    const uint32_t* str_rank;  // rank[code]: bytewise order of the dictionary strings (value/string.go:116-130)
+    DevCol cols[kMaxCols];
+    Term terms[kMaxTerms];
+    LogicOp logic[kMaxLogic];
+    KeySpec keys[kMaxKeys];
+    AggSpec aggs[kMaxAggs];
+};
+
+struct GlobalTable {
+    uint64_t* keys;     // capacity entries, kEmptyKey when free
+    uint64_t* acc;      // capacity * glob_words
+    uint64_t* rep_row;  // capacity entries (or null)
+    uint64_t capacity;  // power of two
+};
+
+struct ScanArgs {
+    uint64_t nrows;
+    uint64_t row_base;        // ordinal of row 0 of this batch
+    uint32_t lds_slots;       // power of two
+    uint32_t lds_max_fill;    // stop inserting new keys beyond this many occupied slots
+    uint32_t* err_flags;      // device word, OR of ERR_*
+    unsigned long long* rows_selected;  // device counter
+    uint32_t wave_reduce;
+    uint32_t compact;
+};
+
+}  // namespace n1k

@@ -1,0 +1,92 @@
+"""Helpers shared by the parity tests: run the same plan through the device path (C ABI) and the oracle."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+
+import query_amd
+from query_amd import _ffi, plan as qplan
+from oracle import n1o
+
+REL_TOL = 1e-9  # north_star: float SUM/AVG within 1e-9 relative; everything else bit-exact
+
+
+def run_gpu(table: n1o.Table, condition: Optional[str], keys: Sequence[str], aggs: Sequence[str], *,
+            filter_only: bool = False, batches: int = 1, device_resident: bool = False, **options):
+    """Run through libn1k.so.  The table's columns are matched to the plan's leaf paths by name."""
+    pj = qplan.filter_group_plan(condition, keys, aggs, filter_only=filter_only)
+    op = query_amd.GpuFilterGroup(pj, **options)
+    try:
+        by_name = {c.name: c for c in table.columns}
+        cols = [by_name[p] for p in op.column_paths]
+        n = table.nrows
+        if not cols:  # count(*) over no referenced path: the engine still needs the row count
+            raise AssertionError("plan references no column")
+        step = max(1, (n + batches - 1) // batches)
+        lo = 0
+        first = True
+        keep = []
+        while first or lo < n:
+            hi = min(n, lo + step)
+            part = [_slice(c, lo, hi) for c in cols]
+            if device_resident:
+                import torch
+                op.intern(list(table.dictionary))
+                dev = []
+                for c in part:
+                    if c.kind == n1o.COL_DICT32:
+                        t = torch.from_numpy(np.ascontiguousarray(c.codes).view(np.int32)).cuda()
+                        keep.append(t)
+                        dev.append((_ffi.COL_DICT32, None, None, t.data_ptr()))
+                    else:
+                        t = torch.from_numpy(np.ascontiguousarray(c.tags)).cuda()
+                        p = torch.from_numpy(np.ascontiguousarray(c.payload).view(np.int64)).cuda()
+                        keep += [t, p]
+                        dev.append((_ffi.COL_TAGGED64, t.data_ptr(), p.data_ptr(), None))
+                torch.cuda.synchronize()
+                op.process_device_items(hi - lo, dev)
+            else:
+                op.process_items(part, table.dictionary)
+            lo = hi
+            first = False
+        rows = op.after_items()
+        stats = op.stats()
+        return rows, stats
+    finally:
+        op.done()
+
+
+def _slice(c, lo, hi):
+    if c.kind == n1o.COL_DICT32:
+        return n1o.Column(c.name, c.kind, codes=c.codes[lo:hi])
+    return n1o.Column(c.name, c.kind, tags=c.tags[lo:hi], payload=c.payload[lo:hi])
+
+
+def values_match(g, o, rel=REL_TOL) -> bool:
+    """(tag, value) from the device vs the oracle: tags must agree; ints/strings/bools exact; floats within rel."""
+    if g[0] != o[0]:
+        return False
+    if g[0] == n1o.T_FLOAT:
+        a, b = g[1], o[1]
+        if math.isnan(a) or math.isnan(b):
+            return math.isnan(a) and math.isnan(b)
+        if a == b:
+            return True
+        return abs(a - b) <= rel * max(abs(a), abs(b))
+    return g[1] == o[1]
+
+
+def assert_same_groups(gpu, ora, rel=REL_TOL):
+    assert gpu.nkeys == ora.nkeys and gpu.naggs == ora.naggs
+    gmap = {tuple(k): a for k, a in zip(gpu.keys, gpu.aggs)}
+    omap = {tuple(k): a for k, a in zip(ora.keys, ora.aggs)}
+    assert len(gmap) == len(gpu.keys), "device emitted a duplicate group (NewDuplicateFinalGroupError)"
+    missing = set(omap) - set(gmap)
+    extra = set(gmap) - set(omap)
+    assert not missing and not extra, ("group sets differ", list(missing)[:5], list(extra)[:5])
+    for k, oa in omap.items():
+        ga = gmap[k]
+        for i, (g, o) in enumerate(zip(ga, oa)):
+            assert values_match(g, o, rel), ("aggregate %d of group %r: device %r oracle %r" % (i, k, g, o))

@@ -1,0 +1,74 @@
+"""CPU-side checks of the product: the C-ABI library loads, exports every declared symbol, parses the
+reference's plan JSON and refuses what is outside the device subset.  No compute call needs a GPU here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import query_amd
+from query_amd import _ffi, plan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "n1k.h")).read()
+    declared = set(re.findall(r"\b(n1k_[a-z_]+)\s*\(", hdr))
+    declared -= {"n1k_status", "n1k_handle"}
+    assert declared == set(_ffi.SYMBOLS), (declared ^ set(_ffi.SYMBOLS))
+    L = C.CDLL(_ffi.LIB_PATH)
+    for s in sorted(declared):
+        assert hasattr(L, s), "libn1k.so does not export " + s
+    assert _ffi.lib().n1k_abi_version() == 1
+
+
+def test_plan_json_binding_and_names():
+    pj = plan.filter_group_plan("(50 < (`default`.`price`))", ["(`default`.`cat`)"],
+                                ["count(*)", "sum((`default`.`price`))"])
+    op = query_amd.GpuFilterGroup(pj)
+    assert op.column_paths == ["(`default`.`price`)", "(`default`.`cat`)"]
+    assert op.aggregate_names == ["count(*)", "sum((`default`.`price`))"]  # keys of the "aggregates" attachment
+    assert op.num_keys == 1
+    op.done()
+
+
+def test_golden_explain_plan_shape_is_accepted():
+    """The EXPLAIN golden of the reference (case_by_id.json:369-456) nests InitialGroup in Parallel{Sequence}."""
+    pj = ('{"#operator":"Parallel","~child":{"#operator":"Sequence","~children":[{"#operator":"InitialGroup",'
+          '"aggregates":["count(*)","min((`game`.`score`))"],"group_keys":[]}]}}')
+    op = query_amd.GpuFilterGroup(pj)
+    assert op.aggregate_names == ["count(*)", "min((`game`.`score`))"] and op.num_keys == 0
+    op.done()
+
+
+@pytest.mark.parametrize("pj,status", [
+    ('{"#operator":"Filter","condition":"(length((`a`.`b`)) < 3)"}', _ffi.UNSUPPORTED),
+    ('{"#operator":"Fetch","keyspace":"x"}', _ffi.UNSUPPORTED),
+    ('{"#operator":"InitialGroup","group_keys":[],"aggregates":["array_agg((`a`.`b`))"]}', _ffi.UNSUPPORTED),
+    ('{"#operator":"Filter","condition":"(any x in (`a`.`b`) satisfies x end)"}', _ffi.UNSUPPORTED),
+    ('{"#operator":"Filter","condition":"((`a`.`b`) <"}', _ffi.INVALID),
+    ('not json', _ffi.INVALID),
+])
+def test_unsupported_plans_are_refused(pj, status):
+    with pytest.raises(query_amd.N1kError) as ei:
+        query_amd.GpuFilterGroup(pj)
+    assert ei.value.status == status
+
+
+def test_no_cpu_fallback_without_device():
+    if query_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(None, [], ["count(*)"]))
+    with pytest.raises(query_amd.N1kError) as ei:
+        op.after_items()
+    assert ei.value.status == _ffi.DEVICE_ERROR
+    op.done()
+
+
+def test_dictionary_interning_is_stable():
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan('((`d`.`s`) = "x")', [], ["count(*)"]))
+    a = op.intern([b"x", b"y", b"", b"x"])
+    assert a[0] == a[3] and len({int(a[0]), int(a[1]), int(a[2])}) == 3
+    assert op.dict_get(int(a[1])) == b"y" and op.dict_get(int(a[2])) == b""
+    op.done()

