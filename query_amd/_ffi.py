@@ -82,6 +82,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; two HIP runtimes in one process cannot both own the GPU.  Importing
+    # torch first makes libn1k.so's NEEDED libamdhip64.so.7 bind to the copy torch already loaded (same SONAME).
+    # A C/Go consumer of the ABI simply uses the system ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing, not a requirement of the library
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "query_amd/libn1k.so is missing: run `python -m query_amd.build` (hipcc, gfx950). "

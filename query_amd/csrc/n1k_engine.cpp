@@ -403,6 +403,16 @@ n1k_status ensure_table(n1k_handle* h, uint64_t incoming_rows) {
     // groups <= rows pushed so far: an upper bound that needs no device round trip
     uint64_t want_groups = std::min<uint64_t>(h->opt_max_groups, h->row_base + incoming_rows);
     if (h->prog.nkeys == 0) want_groups = 1;
+    else {
+        // all keys dictionary coded: the key domain bounds the number of groups (|dict| + MISSING + NULL per key)
+        bool all_dict = true;
+        long double dom = 1;
+        for (uint32_t k = 0; k < h->prog.nkeys; k++) {
+            all_dict &= h->prog.keys[k].mode == KEYM_DICT;
+            dom *= (long double)h->dict.size() + 2;
+        }
+        if (all_dict && dom < (long double)want_groups) want_groups = (uint64_t)dom;
+    }
     uint64_t cap = next_pow2(std::max<uint64_t>(want_groups * 2, 1024));
     if (cap <= h->table.capacity) return N1K_OK;
     if (!h->table.capacity) return alloc_table(h, cap, h->table, h->d_keys, h->d_acc, h->d_rep);

@@ -47,7 +47,7 @@ def test_config2_filter_group_sum(k_cat, zipf, device_resident):
     cond, keys, aggs = CONFIG2
     ora = n1o.run(t, cond, keys, aggs, threads=2)
     gpu, stats = pu.run_gpu(t, cond, keys, aggs, device_resident=device_resident)
-    pu.assert_same_groups(gpu, ora)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
     assert stats["rows_in"] == t.nrows
     assert stats["rows_selected"] == ora.rows_passed  # bit-exact COUNT of the filter
 
@@ -66,7 +66,7 @@ def test_all_aggregates_many_filters(cond):
     t = n1o.synth_table(120_000, k_cat=40)
     ora = n1o.run(t, cond, [D("cat")], ALL_AGGS)
     gpu, _ = pu.run_gpu(t, cond, [D("cat")], ALL_AGGS)
-    pu.assert_same_groups(gpu, ora)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
 
 
 @pytest.mark.parametrize("keys", [[], [D("region_id")], [D("cat"), D("region_id")], [D("price")], [D("user_id")]])
@@ -82,7 +82,7 @@ def test_key_shapes(keys):
     aggs = sorted(["count(*)", "sum(%s)" % D("price"), "max(%s)" % D("user_id")])
     ora = n1o.run(t, "(%s is not missing)" % D("price"), keys, aggs)
     gpu, _ = pu.run_gpu(t, "(%s is not missing)" % D("price"), keys, aggs, batches=3)
-    pu.assert_same_groups(gpu, ora)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
 
 
 def test_empty_input_default_row():
@@ -92,7 +92,7 @@ def test_empty_input_default_row():
     ora = n1o.run(t, cond, [], aggs)
     gpu, _ = pu.run_gpu(t, cond, [], aggs)
     assert len(ora.keys) == 1  # FinalGroup's default row (execution/group_final.go:108-117)
-    pu.assert_same_groups(gpu, ora)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
     ora = n1o.run(t, cond, [D("cat")], aggs)
     gpu, _ = pu.run_gpu(t, cond, [D("cat")], aggs)
     assert len(ora.keys) == 0 and len(gpu.keys) == 0
@@ -123,7 +123,7 @@ def test_int64_exact_sum_and_sign_rule():
     aggs = sorted(["sum(%s)" % D("v"), "avg(%s)" % D("v"), "min(%s)" % D("v"), "max(%s)" % D("v")])
     ora = n1o.run(t, None, [D("g")], aggs)
     gpu, _ = pu.run_gpu(t, None, [D("g")], aggs)
-    pu.assert_same_groups(gpu, ora)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
     kinds = {k[0][1]: a[aggs.index("sum(%s)" % D("v"))][0] for k, a in zip(gpu.keys, gpu.aggs)}
     assert kinds[0] == n1o.T_INT and kinds[1] == n1o.T_INT and kinds[2] == n1o.T_FLOAT and kinds[3] == n1o.T_FLOAT
 
