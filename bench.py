@@ -99,7 +99,7 @@ def cpu_baseline(wl: dict, k_cat: int, zipf: bool, total_rows: int, sample_rows:
     """Time the CPU oracle (port of the reference algorithm: Parallel copies with private maps + serial merge,
     execution/parallel.go:52-75) on the first `sample_rows` rows of the same data set, all host cores."""
     from oracle import n1o
-    threads = os.cpu_count() or 1
+    threads = min(16, len(os.sched_getaffinity(0)))  # the box's CPU share for one GPU
     t = n1o.synth_table(sample_rows, k_cat=k_cat, zipf=zipf, seed=SEED, first_row=0, total_rows=total_rows)
     res = n1o.run(t, wl["cond"], wl["keys"], wl["aggs"], threads=threads)
     return {"value": sample_rows / res.seconds, "unit": "rows/s", "cores": threads, "kind": "port",
@@ -151,7 +151,7 @@ def main():
     def step():
         op.reopen()
         op.process_device_items(args.rows, batch)
-        return op.after_items()
+        return op.after_items_raw()
 
     for _ in range(args.warmup):
         rows = step()
@@ -168,7 +168,7 @@ def main():
     st = op.stats()
     # reopen() zeroes the stats each step: the last step's numbers are one launch of the scan kernel
     scan_ms = st["device_ms"]
-    ngroups = len(rows.keys)
+    ngroups = int(rows["ngroups"])
     alg_bytes = wl["bytes_per_row"] * args.rows
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 

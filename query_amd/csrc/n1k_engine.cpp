@@ -77,7 +77,8 @@ struct n1k_handle {
     uint64_t opt_max_groups = 1ull << 22;
     uint32_t opt_grid_blocks = 0;
     uint32_t opt_compact = 1, opt_wave_reduce = 1, opt_rep_row = 0;
-    uint32_t opt_lds_bytes = 80 * 1024;
+    uint32_t opt_lds_bytes = 64 * 1024;
+    uint32_t opt_block = 1024, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1;
     int device = -1;
     bool device_ready = false;
     hipStream_t stream = nullptr;
@@ -225,9 +226,24 @@ bool compile_cond(n1k_handle* h, const Expr* e, PlanError& err) {
         case EK::Not:
             if (!compile_cond(h, e->ch[0].get(), err)) return false;
             return push_logic(LOGIC_NOT, 0);
-        case EK::Eq: h->need_rank = true; return push_term(TERM_EQ, e->ch[0].get(), e->ch[1].get(), nullptr);
-        case EK::LT: h->need_rank = true; return push_term(TERM_LT, e->ch[0].get(), e->ch[1].get(), nullptr);
-        case EK::LE: h->need_rank = true; return push_term(TERM_LE, e->ch[0].get(), e->ch[1].get(), nullptr);
+        case EK::Eq:
+        case EK::LT:
+        case EK::LE: {
+            const Expr* a = e->ch[0].get();
+            const Expr* b = e->ch[1].get();
+            auto is_num = [](const Expr* x) { return x->kind == EK::Const && (x->ctag == T_INT || x->ctag == T_FLOAT); };
+            // x <op> NUMBER constant (either side): the cheap term form, same semantics
+            if (is_num(b) && !is_num(a)) {
+                uint32_t op = e->kind == EK::Eq ? TERM_NUM_EQ : (e->kind == EK::LT ? TERM_NUM_LT : TERM_NUM_LE);
+                return push_term(op, a, b, nullptr);
+            }
+            if (is_num(a) && !is_num(b)) {  // (c < x) == (x > c)
+                uint32_t op = e->kind == EK::Eq ? TERM_NUM_EQ : (e->kind == EK::LT ? TERM_NUM_GT : TERM_NUM_GE);
+                return push_term(op, b, a, nullptr);
+            }
+            h->need_rank = true;
+            return push_term(e->kind == EK::Eq ? TERM_EQ : (e->kind == EK::LT ? TERM_LT : TERM_LE), a, b, nullptr);
+        }
         case EK::Between:
             h->need_rank = true;
             return push_term(TERM_BETWEEN, e->ch[0].get(), e->ch[1].get(), e->ch[2].get());
@@ -281,9 +297,12 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
         } else if (d.kind == AGG_COUNT || d.kind == AGG_COUNTN) {
             lds_w += 1;
             glob_w += 1;
-        } else if (d.kind == AGG_SUM || d.kind == AGG_AVG) {
+        } else if (d.kind == AGG_SUM) {
             lds_w += kLdsWordsSum;
             glob_w += kGlobWordsSum;
+        } else if (d.kind == AGG_AVG) {
+            lds_w += kLdsWordsAvg;
+            glob_w += kGlobWordsAvg;
         } else {
             h->need_rank = true;
             lds_w += kWordsMinMax;
@@ -477,6 +496,89 @@ uint64_t batch_bytes_per_row(const n1k_handle* h) {
     return b;
 }
 
+// Can this plan run on the fast kernel (bounded shape, every descriptor static)?  Fills F when it can.
+bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F) {
+    const Program& P = h->prog;
+    memset(&F, 0, sizeof F);
+    if (h->opt_fast == 0 || P.want_rep_row || P.ncols == 0 || P.ncols > (uint32_t)kFastCols) return false;
+    if (P.nkeys > (uint32_t)kFastKeys || P.naggs > (uint32_t)kFastAggs || P.naggs == 0) return false;
+    // predicate: none, one term, or AND of two terms
+    uint32_t term_ix[2] = {0, 0};
+    if (P.nlogic == 0) F.nterms = 0;
+    else if (P.nlogic == 1 && P.logic[0].op == LOGIC_PUSH) { F.nterms = 1; term_ix[0] = P.logic[0].arg; }
+    else if (P.nlogic == 3 && P.logic[0].op == LOGIC_PUSH && P.logic[1].op == LOGIC_PUSH && P.logic[2].op == LOGIC_AND &&
+             P.logic[2].arg == 2) { F.nterms = 2; term_ix[0] = P.logic[0].arg; term_ix[1] = P.logic[1].arg; }
+    else return false;
+    for (uint32_t i = 0; i < F.nterms; i++) {
+        const Term& t = P.terms[term_ix[i]];
+        FastTerm& ft = F.terms[i];
+        if (t.op >= TERM_NUM_LT && t.op <= TERM_NUM_EQ) {
+            if (t.a.is_const) return false;
+            ft.op = t.op; ft.col = t.a.col; ft.ctag = t.b.ctag; ft.cpayload = t.b.cpayload;
+        } else if (t.op >= TERM_IS_NULL && t.op <= TERM_IS_NOT_VALUED) {
+            if (t.a.is_const) return false;
+            ft.op = t.op; ft.col = t.a.col;
+        } else if (t.op == TERM_EQ) {  // column = "string constant" (either side)
+            const Operand *c = nullptr, *k = nullptr;
+            if (!t.a.is_const && t.b.is_const && t.b.ctag == T_STRING) { c = &t.a; k = &t.b; }
+            else if (!t.b.is_const && t.a.is_const && t.a.ctag == T_STRING) { c = &t.b; k = &t.a; }
+            else return false;
+            ft.op = TERM_STR_EQ; ft.col = c->col; ft.ctag = T_STRING; ft.cpayload = k->cpayload;
+        } else return false;
+    }
+    // keys: dictionary columns with a domain that fits the LDS table
+    uint64_t domain = 1;
+    F.nkeys = P.nkeys;
+    for (uint32_t k = 0; k < P.nkeys; k++) {
+        const KeySpec& ks = P.keys[k];
+        if (ks.mode != KEYM_DICT || ks.src.is_const) return false;
+        uint64_t radix = (uint64_t)h->dict.size() + 2;
+        if (ks.bits < 64 && radix > (1ull << ks.bits)) return false;
+        F.keys[k].col = ks.src.col;
+        F.keys[k].stride = (uint32_t)domain;
+        F.keys[k].radix = (uint32_t)radix;
+        F.keys[k].shift = ks.shift;
+        domain *= radix;
+        if (domain > max_slots) return false;
+    }
+    F.lds_slots = (uint32_t)std::max<uint64_t>(domain, 2);
+    F.naggs = P.naggs;
+    for (uint32_t a = 0; a < P.naggs; a++) {
+        const AggSpec& ag = P.aggs[a];
+        if (ag.distinct) return false;
+        if (ag.has_operand) {
+            if (ag.src.is_const) return false;
+            F.agg_col[a] = ag.src.col;
+        }
+    }
+    F.ncols = P.ncols;
+    for (uint32_t c = 0; c < P.ncols; c++) F.cols[c] = P.cols[c];
+    return true;
+}
+
+// exact-shape lookup among the ahead-of-time instantiated plan shapes (n1k_spec.h)
+const SpecEntry* find_spec(const n1k_handle* h, const FastArgs& F) {
+    const Program& P = h->prog;
+    SpecSig g{};
+    g.ncols = (int)F.ncols; g.nterms = (int)F.nterms; g.nkeys = (int)F.nkeys; g.naggs = (int)F.naggs;
+    for (uint32_t c = 0; c < F.ncols; c++) g.col_kind[c] = F.cols[c].kind;
+    for (uint32_t t = 0; t < F.nterms; t++) {
+        g.terms[t].op = F.terms[t].op;
+        g.terms[t].col = F.terms[t].col;
+        bool num = F.terms[t].op >= TERM_NUM_LT && F.terms[t].op <= TERM_NUM_EQ;
+        g.terms[t].const_int = num && F.terms[t].ctag == T_INT ? 1u : 0u;
+    }
+    for (uint32_t k = 0; k < F.nkeys; k++) g.key_col[k] = F.keys[k].col;
+    for (uint32_t a = 0; a < F.naggs; a++) {
+        g.aggs[a].kind = P.aggs[a].kind;
+        g.aggs[a].has_operand = P.aggs[a].has_operand;
+        g.aggs[a].col = P.aggs[a].has_operand ? F.agg_col[a] : 0u;
+    }
+    for (const SpecEntry& e : spec_registry())
+        if (memcmp(&e.sig, &g, sizeof g) == 0) return &e;
+    return nullptr;
+}
+
 n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     Program& P = h->prog;
     n1k_status st = ensure_table(h, b->nrows);
@@ -484,26 +586,100 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     ScanArgs A{};
     A.nrows = b->nrows;
     A.row_base = h->row_base;
-    uint32_t slots = h->opt_lds_bytes / (P.lds_words * 8);
-    slots = (uint32_t)std::min<uint64_t>(slots, 1u << 15);
+    uint32_t block = h->opt_block;
+    uint32_t rpl = block == 1024 ? h->opt_rows_per_lane : 4;
+    uint32_t max_slots = h->opt_lds_bytes / (P.lds_words * 8);
+    max_slots = (uint32_t)std::min<uint64_t>(max_slots, 1u << 15);
+    if (max_slots < 2) return fail(h, N1K_UNSUPPORTED, "accumulator row too wide for LDS");
+    FastArgs F;
+    if (h->opt_agg_mode != N1K_MODE_LDS_HASH && build_fast_args(h, max_slots, F)) {
+        uint32_t fblock = block == 256 ? 512 : block;
+        uint32_t frpl = h->opt_rows_per_lane;
+        uint32_t per_cu = fblock == 1024 ? (frpl == 2 ? 2 : 1) : (frpl == 2 ? 3 : 2);
+        uint32_t fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
+        F.err_flags = h->d_err.p;
+        F.rows_selected = h->d_counters.p + 0;
+        hipEvent_t e0 = get_event(h), e1 = get_event(h);
+        if (e0) (void)hipEventRecord(e0, h->stream);
+        // a prebuilt plan-specialised kernel of exactly this shape?
+        const SpecEntry* spec = h->opt_spec ? find_spec(h, F) : nullptr;
+        h->stats.reserved = spec ? 1u : 0u;
+        const uint64_t chunk = 1ull << 31;  // 32-bit row indices inside one launch
+        for (uint64_t off = 0; off < b->nrows; off += chunk) {
+            uint64_t n = std::min<uint64_t>(chunk, b->nrows - off);
+            F.row_base = h->row_base + off;
+            bool aligned = true;
+            for (uint32_t c = 0; c < P.ncols; c++) {
+                F.cols[c] = P.cols[c];
+                if (F.cols[c].tags) F.cols[c].tags += off;
+                if (F.cols[c].payload) F.cols[c].payload += off;
+                if (F.cols[c].codes) F.cols[c].codes += off;
+                aligned &= ((uintptr_t)F.cols[c].tags % 2 == 0) && ((uintptr_t)F.cols[c].payload % 16 == 0) &&
+                           ((uintptr_t)F.cols[c].codes % 8 == 0);
+            }
+            if (spec) {
+                // WIDE launch over the even prefix (2 adjacent rows per lane and load), scalar launch for an odd last row
+                bool wide = aligned && h->opt_wide && n >= 2;
+                uint64_t n_main = wide ? (n & ~1ull) : n;
+                F.nrows = (uint32_t)n_main;
+                uint64_t items = wide ? n_main / 2 : n_main;
+                uint32_t rpl = wide ? 2 : 4;
+                uint64_t tiles = (items + (uint64_t)fblock * rpl - 1) / ((uint64_t)fblock * rpl);
+                uint32_t sgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * (fblock == 1024 ? 2 : 4));
+                uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(sgrid, tiles));
+                HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, h->stream));
+                if (n_main < n) {
+                    for (uint32_t c = 0; c < P.ncols; c++) {
+                        if (F.cols[c].tags) F.cols[c].tags += n_main;
+                        if (F.cols[c].payload) F.cols[c].payload += n_main;
+                        if (F.cols[c].codes) F.cols[c].codes += n_main;
+                    }
+                    F.nrows = (uint32_t)(n - n_main);
+                    F.row_base += n_main;
+                    HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, 1, fblock, false, h->stream));
+                }
+                continue;
+            }
+            F.nrows = (uint32_t)n;
+            uint64_t tiles = (n + (uint64_t)fblock * frpl - 1) / ((uint64_t)fblock * frpl);
+            uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(fgrid, tiles));
+            HIP_TRY(h, launch_scan_fast(P, F, h->table, h->d_counters.p + 1, g, fblock, frpl, h->stream));
+        }
+        if (e1) (void)hipEventRecord(e1, h->stream);
+        h->events.emplace_back(e0, e1);
+        h->stats.agg_mode = N1K_MODE_LDS_DIRECT;
+        return N1K_OK;
+    }
+    // DIRECT: every key is dictionary coded and the whole key domain fits the LDS table -> perfect hash
+    bool direct = h->opt_agg_mode != N1K_MODE_LDS_HASH;
+    uint64_t domain = 1;
+    for (uint32_t k = 0; k < P.nkeys && direct; k++) {
+        if (P.keys[k].mode != KEYM_DICT) direct = false;
+        uint64_t radix = (uint64_t)h->dict.size() + 2;
+        A.direct_stride[k] = (uint32_t)domain;
+        A.direct_radix[k] = (uint32_t)std::min<uint64_t>(radix, 0xFFFFFFFFull);
+        domain *= radix;
+        if (domain > max_slots) direct = false;
+    }
+    uint32_t slots = direct ? (uint32_t)std::max<uint64_t>(domain, 2) : max_slots;
     if (P.nkeys == 0) slots = 2;
-    if (slots < 2) return fail(h, N1K_UNSUPPORTED, "accumulator row too wide for LDS");
     A.lds_slots = slots;
     A.lds_max_fill = std::max(1u, (uint32_t)((uint64_t)slots * 5 / 8));
     A.err_flags = h->d_err.p;
     A.rows_selected = h->d_counters.p + 0;
     A.wave_reduce = h->opt_wave_reduce;
     A.compact = h->opt_compact;
-    uint64_t tile_rows = 256 * 4;
+    uint64_t tile_rows = (uint64_t)block * rpl;
     uint64_t ntiles = (b->nrows + tile_rows - 1) / tile_rows;
-    uint32_t grid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * 2);
+    uint32_t per_cu = block == 1024 ? 1 : (block == 512 ? 2 : 4);
+    uint32_t grid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
     grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, ntiles));
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
     if (e0) (void)hipEventRecord(e0, h->stream);
-    HIP_TRY(h, launch_scan_group(P, A, h->table, h->d_counters.p + 1, grid, h->stream));
+    HIP_TRY(h, launch_scan_group(P, A, h->table, h->d_counters.p + 1, grid, block, rpl, direct, h->stream));
     if (e1) (void)hipEventRecord(e1, h->stream);
     h->events.emplace_back(e0, e1);
-    h->stats.agg_mode = N1K_MODE_LDS_HASH;
+    h->stats.agg_mode = direct ? N1K_MODE_LDS_DIRECT : N1K_MODE_LDS_HASH;
     return N1K_OK;
 }
 
@@ -711,7 +887,16 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "grid_blocks") h->opt_grid_blocks = (uint32_t)std::max<int64_t>(0, value);
     else if (n == "compact") h->opt_compact = value ? 1 : 0;
     else if (n == "wave_reduce") h->opt_wave_reduce = value ? 1 : 0;
-    else if (n == "lds_bytes") h->opt_lds_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 160 * 1024);
+    else if (n == "fast") h->opt_fast = value ? 1 : 0;
+    else if (n == "spec") h->opt_spec = value ? 1 : 0;
+    else if (n == "wide") h->opt_wide = value ? 1 : 0;
+    else if (n == "block") {
+        if (value != 256 && value != 512 && value != 1024) return fail(h, N1K_INVALID, "block must be 256, 512 or 1024");
+        h->opt_block = (uint32_t)value;
+    } else if (n == "rows_per_lane") {
+        if (value != 2 && value != 4) return fail(h, N1K_INVALID, "rows_per_lane must be 2 or 4");
+        h->opt_rows_per_lane = (uint32_t)value;
+    } else if (n == "lds_bytes") h->opt_lds_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 160 * 1024);
     else if (n == "device") {
         if (h->device_ready) return fail(h, N1K_INVALID, "device must be chosen before the first push");
         h->device = (int)value;

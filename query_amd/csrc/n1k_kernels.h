@@ -1,6 +1,7 @@
 // n1k_kernels.h — launch interface between the host engine and n1k_kernels.hip
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include "n1k_types.h"
 
 namespace n1k {
@@ -39,7 +40,16 @@ hipError_t launch_init_table(const Program& P, const GlobalTable& G, uint64_t fi
 hipError_t launch_rehash(const Program& P, const GlobalTable& oldt, const GlobalTable& newt, uint32_t* err_flags,
                          unsigned long long* ngroups_scratch, hipStream_t st);
 hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTable& G, unsigned long long* ngroups,
-                             uint32_t grid, hipStream_t st);
+                             uint32_t grid, uint32_t block, uint32_t rows_per_lane, bool direct, hipStream_t st);
+hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
+                            uint32_t grid, uint32_t block, uint32_t rows_per_lane, hipStream_t st);
+struct SpecEntry {
+    const char* name;
+    SpecSig sig;
+    hipError_t (*launch)(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
+                         uint32_t grid, uint32_t block, bool wide, hipStream_t st);
+};
+const std::vector<SpecEntry>& spec_registry();
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,
                            OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count, uint64_t max_out,
                            uint32_t* err_flags, hipStream_t st);

@@ -14,8 +14,26 @@
 #include <hip/hip_runtime.h>
 #include "n1k_device.h"
 #include "n1k_kernels.h"
+#include <vector>
 
 namespace n1k {
+
+// LDS is addressed through explicit address-space-3 pointers and workgroup-scope atomics so that every access
+// is a ds_* instruction (generic pointers make hipcc fall back to flat_* loads for volatile reads).
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) long long lds_i64;
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+
+N1K_DEV lds_u64* lds_word(uint64_t* lds, uint32_t index) { return (lds_u64*)lds + index; }
+N1K_DEV unsigned long long lds_peek(lds_u64* p) { return *(volatile lds_u64*)p; }
+N1K_DEV void lds_add_u64(lds_u64* p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+N1K_DEV void lds_add_f64(lds_u64* p, double v) { (void)__hip_atomic_fetch_add((lds_f64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+N1K_DEV void lds_or_u64(lds_u64* p, unsigned long long v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+N1K_DEV void lds_min_u64(lds_u64* p, unsigned long long v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+N1K_DEV void lds_max_u64(lds_u64* p, unsigned long long v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+N1K_DEV void lds_min_i64(lds_u64* p, long long v) { (void)__hip_atomic_fetch_min((lds_i64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+N1K_DEV void lds_max_i64(lds_u64* p, long long v) { (void)__hip_atomic_fetch_max((lds_i64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // ------------------------------------------------------------------ operand / term evaluation
 
@@ -117,10 +135,32 @@ N1K_DEV void eval_term(const Program& P, const Term& t, const uint64_t (&row)[R]
 #pragma unroll
             for (int j = 0; j < R; j++) out[j] = ta[j] <= T_NULL ? L_TRUE : L_FALSE;
             break;
-        default:  // TERM_TRUTH
+        case TERM_TRUTH:
 #pragma unroll
             for (int j = 0; j < R; j++) out[j] = truth_l(ta[j], pa[j], P.empty_str_code, P.empty_arr_code, P.empty_obj_code);
             break;
+        default: {  // TERM_NUM_*: a <op> NUMBER constant; same result as LT/LE/Eq.Apply with the operands in this order
+            const uint32_t ct = t.b.ctag;
+            const uint64_t cp = t.b.cpayload;
+            const double cf = num_actual(ct, cp);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                uint32_t tg = ta[j];
+                int c;  // collation of a against the constant
+                if (tg == T_INT && ct == T_INT) {
+                    int64_t x = (int64_t)pa[j], y = (int64_t)cp;
+                    c = x < y ? -1 : (x > y ? 1 : 0);
+                } else if (tg == T_INT || tg == T_FLOAT) {
+                    c = collate_f64(num_actual(tg, pa[j]), cf);
+                } else {
+                    c = tg < T_INT ? -1 : 1;  // BOOLEAN sorts below NUMBER, STRING/ARRAY/OBJECT above
+                }
+                bool r = t.op == TERM_NUM_LT ? c < 0 : t.op == TERM_NUM_LE ? c <= 0 : t.op == TERM_NUM_GT ? c > 0
+                         : t.op == TERM_NUM_GE ? c >= 0 : (c == 0 && (tg == T_INT || tg == T_FLOAT));
+                out[j] = tg == T_MISSING ? L_MISSING : (tg == T_NULL ? L_NULL : (r ? L_TRUE : L_FALSE));
+            }
+            break;
+        }
     }
 }
 
@@ -161,21 +201,33 @@ N1K_DEV void eval_predicate(const Program& P, const uint64_t (&row)[R], const bo
 
 // ------------------------------------------------------------------ hash tables
 
-// open-addressed LDS table: slot s occupies words [s*W, (s+1)*W); word 0 is the packed key
-N1K_DEV int lds_find_or_insert(uint64_t* lds, uint32_t S, uint32_t W, uint64_t key, uint32_t* fill, uint32_t max_fill) {
-    uint32_t h = (uint32_t)(((mix64(key) >> 32) * (uint64_t)S) >> 32);  // S need not be a power of two
+// The workgroup's LDS table is word-major: word w of slot s lives at lds[w * S + s] (consecutive slots fall
+// into consecutive banks).  Word 0 is the packed key (HASH mode) or a "touched" marker (DIRECT mode).
+N1K_DEV uint32_t lds_hash(uint64_t key, uint32_t S) {
+    uint32_t x = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u);
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 15;
+    x *= 0xC2B2AE35u;
+    return __umulhi(x, S);  // S need not be a power of two
+}
+
+N1K_DEV int lds_find_or_insert(uint64_t* lds, uint32_t S, uint64_t key, uint32_t* fill, uint32_t max_fill) {
+    uint32_t h = lds_hash(key, S);
+    lds_u32* fillp = (lds_u32*)fill;
     for (int probe = 0; probe < 32; probe++) {
-        volatile uint64_t* p = &lds[(size_t)h * W];
-        uint64_t cur = *p;
+        lds_u64* p = lds_word(lds, h);
+        unsigned long long cur = lds_peek(p);
         if (cur == key) return (int)h;
         if (cur == kEmptyKey) {
-            if (*(volatile uint32_t*)fill >= max_fill) return -1;  // table is kept sparse: new keys bypass LDS
-            unsigned long long old = atomicCAS((unsigned long long*)p, (unsigned long long)kEmptyKey, (unsigned long long)key);
-            if (old == kEmptyKey) {
-                atomicAdd(fill, 1u);
+            if (*(volatile lds_u32*)fillp >= max_fill) return -1;  // table is kept sparse: new keys bypass LDS
+            unsigned long long expected = kEmptyKey;
+            bool won = __hip_atomic_compare_exchange_strong(p, &expected, (unsigned long long)key, __ATOMIC_RELAXED,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (won) {
+                (void)__hip_atomic_fetch_add(fillp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return (int)h;
             }
-            if (old == key) return (int)h;
+            if (expected == key) return (int)h;
         }
         h = h + 1 == S ? 0 : h + 1;
     }
@@ -206,20 +258,21 @@ N1K_DEV long long global_find_or_insert(const GlobalTable& G, uint64_t key, uint
 
 // ------------------------------------------------------------------ accumulators
 
-N1K_DEV void lds_slot_init(const Program& P, uint64_t* s) {
-    s[0] = kEmptyKey;
-    if (P.want_rep_row) s[P.rep_lds_word] = ~0ull;
+template <int BLOCK>
+N1K_DEV void lds_table_init(const Program& P, uint64_t* lds, uint32_t S, uint32_t tid) {
+    for (uint32_t s = tid; s < S; s += BLOCK) lds[s] = kEmptyKey;
+    if (P.want_rep_row)
+        for (uint32_t s = tid; s < S; s += BLOCK) lds[(size_t)P.rep_lds_word * S + s] = ~0ull;
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
         if (ag.distinct) continue;
-        uint64_t* w = s + ag.lds_off;
-        switch (ag.kind) {
-            case AGG_COUNT:
-            case AGG_COUNTN: w[0] = 0; break;
-            case AGG_SUM:
-            case AGG_AVG: w[0] = 0; w[1] = 0; w[2] = 0; w[3] = 0; break;
-            case AGG_MIN: w[0] = 0; w[1] = (uint64_t)INT64_MAX; w[2] = ~0ull; w[3] = ~0ull; break;
-            default: w[0] = 0; w[1] = (uint64_t)INT64_MIN; w[2] = 0; w[3] = 0; break;
+        uint64_t* w = lds + (size_t)ag.lds_off * S;
+        uint32_t nw = (ag.kind == AGG_COUNT || ag.kind == AGG_COUNTN) ? 1u : (ag.kind == AGG_SUM ? kLdsWordsSum : (ag.kind == AGG_AVG ? kLdsWordsAvg : kWordsMinMax));
+        for (uint32_t i = 0; i < nw; i++) {
+            uint64_t ident = 0;
+            if (ag.kind == AGG_MIN) ident = i == 1 ? (uint64_t)INT64_MAX : (i >= 2 ? ~0ull : 0ull);
+            if (ag.kind == AGG_MAX) ident = i == 1 ? (uint64_t)INT64_MIN : 0ull;
+            for (uint32_t s = tid; s < S; s += BLOCK) w[(size_t)i * S + s] = ident;
         }
     }
 }
@@ -232,8 +285,8 @@ __device__ __forceinline__ void glob_row_init(const Program& P, uint64_t* g) {
         switch (ag.kind) {
             case AGG_COUNT:
             case AGG_COUNTN: w[0] = 0; break;
-            case AGG_SUM:
-            case AGG_AVG: for (int i = 0; i < 6; i++) w[i] = 0; break;
+            case AGG_SUM: for (int i = 0; i < (int)kGlobWordsSum; i++) w[i] = 0; break;
+            case AGG_AVG: for (int i = 0; i < (int)kGlobWordsAvg; i++) w[i] = 0; break;
             case AGG_MIN: w[0] = 0; w[1] = (uint64_t)INT64_MAX; w[2] = ~0ull; w[3] = ~0ull; break;
             default: w[0] = 0; w[1] = (uint64_t)INT64_MIN; w[2] = 0; w[3] = 0; break;
         }
@@ -258,10 +311,12 @@ N1K_DEV void acc_global(const Program& P, const AggSpec& ag, uint64_t* g, uint32
                 int64_t x = (int64_t)p;
                 atomicAdd(&w[0], (unsigned long long)(uint32_t)x);
                 atomicAdd(&w[1], (unsigned long long)(x >> 32));
-                atomicAdd(&w[x < 0 ? 4 : 3], 1ull);
+                atomicOr(&w[3], x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
+                if (ag.kind == AGG_AVG) atomicAdd(&w[4], 1ull);
             } else if (tag == T_FLOAT) {
                 atomicAdd((double*)&w[2], as_f64(p));
-                atomicAdd(&w[5], 1ull);
+                atomicOr(&w[3], (unsigned long long)SF_FLOAT);
+                if (ag.kind == AGG_AVG) atomicAdd(&w[4], 1ull);
             }
             break;
         case AGG_MIN:
@@ -289,50 +344,56 @@ N1K_DEV void acc_global(const Program& P, const AggSpec& ag, uint64_t* g, uint32
     }
 }
 
+// set a read-mostly flag bit in LDS: after the first row of a kind the atomic is skipped
+N1K_DEV void lds_set_flag(lds_u64* w, unsigned long long bit) {
+    if (!(lds_peek(w) & bit)) lds_or_u64(w, bit);
+}
+
 // CumulateInitial into the workgroup's LDS slot.  Returns false when the value must take the global path
 // (|int| >= 2^40: the 64-bit LDS sum of a workgroup's share could overflow).
-N1K_DEV bool acc_lds(const Program& P, const AggSpec& ag, uint64_t* s, uint32_t tag, uint64_t p) {
-    unsigned long long* w = (unsigned long long*)(s + ag.lds_off);
+N1K_DEV bool acc_lds(const Program& P, const AggSpec& ag, uint64_t* lds, uint32_t S, uint32_t slot, uint32_t tag, uint64_t p) {
+    lds_u64* w = lds_word(lds, ag.lds_off * S + slot);  // word i at w[i * S]
     switch (ag.kind) {
         case AGG_COUNT:
-            if (!ag.has_operand || tag > T_NULL) atomicAdd(&w[0], 1ull);
+            if (!ag.has_operand || tag > T_NULL) lds_add_u64(w, 1ull);
             return true;
         case AGG_COUNTN:
-            if (tag == T_INT || tag == T_FLOAT) atomicAdd(&w[0], 1ull);
+            if (tag == T_INT || tag == T_FLOAT) lds_add_u64(w, 1ull);
             return true;
         case AGG_SUM:
         case AGG_AVG:
             if (tag == T_INT) {
                 int64_t x = (int64_t)p;
                 if (x >= (1ll << 40) || x <= -(1ll << 40)) return false;
-                atomicAdd(&w[0], (unsigned long long)x);
-                atomicAdd(&w[2], x < 0 ? (1ull << 32) : 1ull);
+                lds_add_u64(w, (unsigned long long)x);
+                lds_set_flag(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
+                if (ag.kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
             } else if (tag == T_FLOAT) {
-                atomicAdd((double*)&w[1], as_f64(p));
-                atomicAdd(&w[3], 1ull);
+                lds_add_f64(w + S, as_f64(p));
+                lds_set_flag(w + 2 * S, (unsigned long long)SF_FLOAT);
+                if (ag.kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
             }
             return true;
         default: {  // MIN / MAX
             if (tag <= T_NULL) return true;
             bool mn = ag.kind == AGG_MIN;
-            volatile unsigned long long* vw = w;
             if (tag == T_FALSE || tag == T_TRUE) {
-                unsigned long long bit = tag == T_TRUE ? (unsigned long long)MM_TRUE : (unsigned long long)MM_FALSE;
-                if (!(vw[0] & bit)) atomicOr(&w[0], bit);
+                lds_set_flag(w, tag == T_TRUE ? (unsigned long long)MM_TRUE : (unsigned long long)MM_FALSE);
             } else if (tag == T_INT) {
-                if (!(vw[0] & MM_INT)) atomicOr(&w[0], (unsigned long long)MM_INT);
-                long long x = (long long)p, cur = (long long)vw[1];
-                if (mn ? x < cur : x > cur) { if (mn) atomicMin((long long*)&w[1], x); else atomicMax((long long*)&w[1], x); }
+                lds_set_flag(w, (unsigned long long)MM_INT);
+                long long x = (long long)p, cur = (long long)lds_peek(w + S);
+                if (mn ? x < cur : x > cur) { if (mn) lds_min_i64(w + S, x); else lds_max_i64(w + S, x); }
             } else if (tag == T_FLOAT) {
-                if (!(vw[0] & MM_FLOAT)) atomicOr(&w[0], (unsigned long long)MM_FLOAT);
-                unsigned long long x = f64_sortable(as_f64(p)), cur = vw[2];
-                if (mn ? x < cur : x > cur) { if (mn) atomicMin(&w[2], x); else atomicMax(&w[2], x); }
+                lds_set_flag(w, (unsigned long long)MM_FLOAT);
+                unsigned long long x = f64_sortable(as_f64(p)), cur = lds_peek(w + 2 * S);
+                if (mn ? x < cur : x > cur) { if (mn) lds_min_u64(w + 2 * S, x); else lds_max_u64(w + 2 * S, x); }
             } else if (tag == T_STRING) {
-                if (!(vw[0] & MM_STRING)) atomicOr(&w[0], (unsigned long long)MM_STRING);
-                unsigned long long x = ((unsigned long long)P.str_rank[(uint32_t)p] << 32) | (uint32_t)p, cur = vw[3];
-                if (mn ? x < cur : x > cur) { if (mn) atomicMin(&w[3], x); else atomicMax(&w[3], x); }
+                lds_set_flag(w, (unsigned long long)MM_STRING);
+                unsigned long long x = ((unsigned long long)P.str_rank[(uint32_t)p] << 32) | (uint32_t)p;
+                unsigned long long cur = lds_peek(w + 3 * S);
+                if (mn ? x < cur : x > cur) { if (mn) lds_min_u64(w + 3 * S, x); else lds_max_u64(w + 3 * S, x); }
             } else {
-                if (!(vw[0] & MM_OTHER)) atomicOr(&w[0], (unsigned long long)MM_OTHER);
+                lds_set_flag(w, (unsigned long long)MM_OTHER);
             }
             return true;
         }
@@ -340,11 +401,11 @@ N1K_DEV bool acc_lds(const Program& P, const AggSpec& ag, uint64_t* s, uint32_t 
 }
 
 // CumulateIntermediate: fold one LDS slot into its global row (algebra/agg_*.go CumulateIntermediate)
-N1K_DEV void merge_slot(const Program& P, const uint64_t* s, uint64_t* g) {
+N1K_DEV void merge_slot(const Program& P, const uint64_t* lds, uint32_t S, uint32_t slot, uint64_t* g) {
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
         if (ag.distinct) continue;
-        const uint64_t* l = s + ag.lds_off;
+        const uint64_t* l = lds + (size_t)ag.lds_off * S + slot;  // word i at l[i * S]
         unsigned long long* w = (unsigned long long*)(g + ag.glob_off);
         switch (ag.kind) {
             case AGG_COUNT:
@@ -353,27 +414,26 @@ N1K_DEV void merge_slot(const Program& P, const uint64_t* s, uint64_t* g) {
                 break;
             case AGG_SUM:
             case AGG_AVG: {
-                if (l[2]) {
+                uint64_t fl = l[2 * (size_t)S];
+                if (!fl) break;
+                if (fl & (SF_NONNEG_INT | SF_NEG_INT)) {
                     int64_t x = (int64_t)l[0];
                     atomicAdd(&w[0], (unsigned long long)(uint32_t)x);
                     atomicAdd(&w[1], (unsigned long long)(x >> 32));
-                    uint64_t nn = l[2] & 0xFFFFFFFFull, ng = l[2] >> 32;
-                    if (nn) atomicAdd(&w[3], (unsigned long long)nn);
-                    if (ng) atomicAdd(&w[4], (unsigned long long)ng);
                 }
-                if (l[3]) {
-                    atomicAdd((double*)&w[2], as_f64(l[1]));
-                    atomicAdd(&w[5], (unsigned long long)l[3]);
-                }
+                if (fl & SF_FLOAT) atomicAdd((double*)&w[2], as_f64(l[(size_t)S]));
+                atomicOr(&w[3], (unsigned long long)fl);
+                if (ag.kind == AGG_AVG) atomicAdd(&w[4], (unsigned long long)l[3 * (size_t)S]);
                 break;
             }
             default: {
-                if (!l[0]) break;
+                uint64_t fl = l[0];
+                if (!fl) break;
                 bool mn = ag.kind == AGG_MIN;
-                atomicOr(&w[0], (unsigned long long)l[0]);
-                if (l[0] & MM_INT) { if (mn) atomicMin((long long*)&w[1], (long long)l[1]); else atomicMax((long long*)&w[1], (long long)l[1]); }
-                if (l[0] & MM_FLOAT) { if (mn) atomicMin(&w[2], (unsigned long long)l[2]); else atomicMax(&w[2], (unsigned long long)l[2]); }
-                if (l[0] & MM_STRING) { if (mn) atomicMin(&w[3], (unsigned long long)l[3]); else atomicMax(&w[3], (unsigned long long)l[3]); }
+                atomicOr(&w[0], (unsigned long long)fl);
+                if (fl & MM_INT) { if (mn) atomicMin((long long*)&w[1], (long long)l[(size_t)S]); else atomicMax((long long*)&w[1], (long long)l[(size_t)S]); }
+                if (fl & MM_FLOAT) { if (mn) atomicMin(&w[2], (unsigned long long)l[2 * (size_t)S]); else atomicMax(&w[2], (unsigned long long)l[2 * (size_t)S]); }
+                if (fl & MM_STRING) { if (mn) atomicMin(&w[3], (unsigned long long)l[3 * (size_t)S]); else atomicMax(&w[3], (unsigned long long)l[3 * (size_t)S]); }
                 break;
             }
         }
@@ -381,16 +441,21 @@ N1K_DEV void merge_slot(const Program& P, const uint64_t* s, uint64_t* g) {
 }
 
 // ------------------------------------------------------------------ K1+K2+K3(+K4): scan -> filter -> group
+//
+// One persistent workgroup per CU slice walks tiles of BLOCK*R rows.  DIRECT = the group-key domain is small
+// and dictionary coded, so the LDS slot is a perfect hash of the key fields (no probing, no key compare);
+// otherwise the LDS table is open addressed on the packed key.  Either way the workgroup's partial groups are
+// merged into the global open-addressed table at the end (K4).
 
-template <int R, int BLOCK>
+template <int R, int BLOCK, bool DIRECT>
 __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, const ScanArgs A, const GlobalTable G,
                                                           unsigned long long* ngroups) {
     extern __shared__ uint64_t lds[];
     __shared__ uint32_t lds_fill;
-    const uint32_t S = A.lds_slots, W = P.lds_words;
+    const uint32_t S = A.lds_slots;
     const uint32_t tid = threadIdx.x;
 
-    for (uint32_t s = tid; s < S; s += BLOCK) lds_slot_init(P, &lds[(size_t)s * W]);
+    lds_table_init<BLOCK>(P, lds, S, tid);
     if (tid == 0) lds_fill = 0;
     __syncthreads();
 
@@ -409,10 +474,11 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
         }
         eval_predicate<R>(P, row, valid, pass, unsupported);
 
-        // group key -> one packed word per row (execution/group_util.go:18-35)
+        // group key -> packed word (execution/group_util.go:18-35) and, in DIRECT mode, the LDS slot itself
         uint64_t key[R];
+        uint32_t dslot[R];
 #pragma unroll
-        for (int j = 0; j < R; j++) key[j] = 0;
+        for (int j = 0; j < R; j++) { key[j] = 0; dslot[j] = 0; }
         for (uint32_t k = 0; k < P.nkeys; k++) {
             const KeySpec& ks = P.keys[k];
             uint32_t kt[R];
@@ -421,11 +487,15 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 uint64_t f = 0;
-                if (pass[j] && !pack_key_field(ks, kt[j], kp[j], f)) {
+                bool ok = !pass[j] || pack_key_field(ks, kt[j], kp[j], f);
+                if (DIRECT) ok = ok && f < (uint64_t)A.direct_radix[k];
+                if (!ok) {
                     unpackable = 1;
                     pass[j] = false;
+                    f = 0;
                 }
                 key[j] |= f << ks.shift;
+                if (DIRECT) dslot[j] += (uint32_t)f * A.direct_stride[k];
             }
         }
 
@@ -438,14 +508,19 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
             grow[j] = -1;
             if (pass[j]) {
                 selected++;
-                slot[j] = lds_find_or_insert(lds, S, W, key[j], &lds_fill, A.lds_max_fill);
-                if (slot[j] < 0) {
-                    grow[j] = global_find_or_insert(G, key[j], A.err_flags, ngroups);
-                    if (grow[j] < 0) pass[j] = false;
+                if (DIRECT) {
+                    slot[j] = (int)dslot[j];
+                    if (lds_peek(lds_word(lds, dslot[j])) == kEmptyKey) *(volatile lds_u64*)lds_word(lds, dslot[j]) = key[j];
+                } else {
+                    slot[j] = lds_find_or_insert(lds, S, key[j], &lds_fill, A.lds_max_fill);
+                    if (slot[j] < 0) {
+                        grow[j] = global_find_or_insert(G, key[j], A.err_flags, ngroups);
+                        if (grow[j] < 0) pass[j] = false;
+                    }
                 }
                 if (P.want_rep_row && pass[j]) {
                     unsigned long long ord = A.row_base + row[j];
-                    if (slot[j] >= 0) atomicMin((unsigned long long*)&lds[(size_t)slot[j] * W + P.rep_lds_word], ord);
+                    if (slot[j] >= 0) lds_min_u64(lds_word(lds, P.rep_lds_word * S + (uint32_t)slot[j]), ord);
                     else atomicMin((unsigned long long*)&G.rep_row[grow[j]], ord);
                 }
             }
@@ -464,7 +539,7 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
                 uint32_t t = ag.has_operand ? vt[j] : (uint32_t)T_NULL;
                 uint64_t p = ag.has_operand ? vp[j] : 0ull;
                 if (slot[j] >= 0) {
-                    if (!acc_lds(P, ag, &lds[(size_t)slot[j] * W], t, p)) {
+                    if (!acc_lds(P, ag, lds, S, (uint32_t)slot[j], t, p)) {
                         if (grow[j] < 0) grow[j] = global_find_or_insert(G, key[j], A.err_flags, ngroups);
                         if (grow[j] >= 0) acc_global(P, ag, &G.acc[(size_t)grow[j] * P.glob_words], t, p);
                     }
@@ -482,16 +557,285 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
     if ((tid & 63) == 0 && selected) atomicAdd(A.rows_selected, selected);
 
     __syncthreads();
-    // K4: merge this workgroup's partial groups into the global table
+    // K4: merge this workgroup's partial groups into the global table (≙ IntermediateGroup)
     for (uint32_t s = tid; s < S; s += BLOCK) {
-        const uint64_t* sp = &lds[(size_t)s * W];
-        if (sp[0] == kEmptyKey) continue;
-        long long g = global_find_or_insert(G, sp[0], A.err_flags, ngroups);
+        uint64_t key = lds[s];
+        if (key == kEmptyKey) continue;
+        long long g = global_find_or_insert(G, key, A.err_flags, ngroups);
         if (g < 0) continue;
-        merge_slot(P, sp, &G.acc[(size_t)g * P.glob_words]);
-        if (P.want_rep_row && sp[P.rep_lds_word] != ~0ull)
-            atomicMin((unsigned long long*)&G.rep_row[g], (unsigned long long)sp[P.rep_lds_word]);
+        merge_slot(P, lds, S, s, &G.acc[(size_t)g * P.glob_words]);
+        if (P.want_rep_row) {
+            uint64_t rep = lds[(size_t)P.rep_lds_word * S + s];
+            if (rep != ~0ull) atomicMin((unsigned long long*)&G.rep_row[g], (unsigned long long)rep);
+        }
     }
+}
+
+// ------------------------------------------------------------------ fast scan kernel (bounded plan shapes)
+//
+// Same algorithm and the same LDS/global tables as scan_group_kernel<.., DIRECT = true>, but every plan
+// descriptor sits at a compile-time index (loops are fully unrolled to the kFast* maxima and guarded by
+// wave-uniform counts), so the compiler hoists all kernarg reads out of the tile loop and nothing is
+// interpreted per row.  Each column is loaded exactly once per row.
+
+// one cheap predicate term on a register-resident column value -> "is TRUE" (the only thing Filter needs)
+N1K_DEV bool fast_term_true(const FastTerm& t, uint32_t tg, uint64_t p) {
+    switch (t.op) {
+        case TERM_IS_NULL: return tg == T_NULL;
+        case TERM_IS_NOT_NULL: return tg > T_NULL;
+        case TERM_IS_MISSING: return tg == T_MISSING;
+        case TERM_IS_NOT_MISSING: return tg != T_MISSING;
+        case TERM_IS_VALUED: return tg > T_NULL;
+        case TERM_IS_NOT_VALUED: return tg <= T_NULL;
+        case TERM_STR_EQ: return tg == T_STRING && p == t.cpayload;
+        default: {
+            if (tg <= T_NULL) return false;  // MISSING / NULL are never TRUE
+            int c;
+            if (tg == T_INT && t.ctag == T_INT) {
+                int64_t x = (int64_t)p, y = (int64_t)t.cpayload;
+                c = x < y ? -1 : (x > y ? 1 : 0);
+            } else if (tg == T_INT || tg == T_FLOAT) {
+                c = collate_f64(num_actual(tg, p), num_actual(t.ctag, t.cpayload));
+            } else {
+                c = tg < T_INT ? -1 : 1;
+            }
+            return t.op == TERM_NUM_LT ? c < 0 : t.op == TERM_NUM_LE ? c <= 0 : t.op == TERM_NUM_GT ? c > 0
+                   : t.op == TERM_NUM_GE ? c >= 0 : (c == 0 && (tg == T_INT || tg == T_FLOAT));
+        }
+    }
+}
+
+// pick one of the register-resident columns by a wave-uniform index
+template <int R>
+N1K_DEV void pick_col(uint32_t c, const uint32_t (&ctag)[kFastCols][R], const uint64_t (&cpay)[kFastCols][R],
+                      uint32_t (&t)[R], uint64_t (&p)[R]) {
+#pragma unroll
+    for (int j = 0; j < R; j++) { t[j] = ctag[0][j]; p[j] = cpay[0][j]; }
+#pragma unroll
+    for (int k = 1; k < kFastCols; k++) {
+        if (c == (uint32_t)k) {
+#pragma unroll
+            for (int j = 0; j < R; j++) { t[j] = ctag[k][j]; p[j] = cpay[k][j]; }
+        }
+    }
+}
+
+// perfect-hash slot -> packed group key (inverse of slot = sum(field_k * stride_k))
+N1K_DEV uint64_t fast_slot_key(const FastArgs& F, uint32_t slot) {
+    uint64_t key = 0;
+#pragma unroll
+    for (int k = kFastKeys - 1; k >= 0; k--) {
+        if (k < (int)F.nkeys) {
+            uint32_t f = slot / F.keys[k].stride;
+            slot -= f * F.keys[k].stride;
+            key |= (uint64_t)f << F.keys[k].shift;
+        }
+    }
+    return key;
+}
+
+template <int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void scan_fast_kernel(const Program P, const FastArgs F, const GlobalTable G,
+                                                         unsigned long long* ngroups) {
+    extern __shared__ uint64_t lds[];
+    const uint32_t S = F.lds_slots;
+    const uint32_t tid = threadIdx.x;
+    lds_table_init<BLOCK>(P, lds, S, tid);
+    __syncthreads();
+
+    uint32_t unpackable = 0;
+    uint32_t selected = 0;
+    const uint32_t tile_rows = BLOCK * R;
+    const uint32_t n = F.nrows;
+
+    for (uint32_t base = blockIdx.x * tile_rows; base < n; base += gridDim.x * tile_rows) {
+        uint32_t idx[R];
+        bool pass[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            idx[j] = base + (uint32_t)j * BLOCK + tid;
+            pass[j] = idx[j] < n;
+        }
+        // every referenced column, once
+        uint32_t ctag[kFastCols][R];
+        uint64_t cpay[kFastCols][R];
+#pragma unroll
+        for (int c = 0; c < kFastCols; c++) {
+            if (c < (int)F.ncols) {
+                if (F.cols[c].kind == COLK_DICT32) {
+                    const uint32_t* __restrict__ codes = F.cols[c].codes;
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        uint32_t code = pass[j] ? codes[idx[j]] : 0xFFFFFFFFu;
+                        ctag[c][j] = code == 0xFFFFFFFFu ? (uint32_t)T_MISSING : (code == 0xFFFFFFFEu ? (uint32_t)T_NULL : (uint32_t)T_STRING);
+                        cpay[c][j] = code;
+                    }
+                } else {
+                    const uint8_t* __restrict__ tags = F.cols[c].tags;
+                    const uint64_t* __restrict__ payload = F.cols[c].payload;
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        ctag[c][j] = pass[j] ? (uint32_t)tags[idx[j]] : (uint32_t)T_MISSING;
+                        cpay[c][j] = pass[j] ? payload[idx[j]] : 0ull;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; j++) { ctag[c][j] = T_MISSING; cpay[c][j] = 0; }
+            }
+        }
+        // Filter: a conjunction passes iff every term is TRUE (expression/logic_and.go:64-89)
+#pragma unroll
+        for (int t = 0; t < kFastTerms; t++) {
+            if (t < (int)F.nterms) {
+                uint32_t vt[R];
+                uint64_t vp[R];
+                pick_col<R>(F.terms[t].col, ctag, cpay, vt, vp);
+#pragma unroll
+                for (int j = 0; j < R; j++) pass[j] = pass[j] && fast_term_true(F.terms[t], vt[j], vp[j]);
+            }
+        }
+        // group key: perfect-hash slot (execution/group_util.go:18-35); the packed key is rebuilt from the slot
+        // index when the workgroup's table is merged
+        uint32_t slot[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) slot[j] = 0;
+#pragma unroll
+        for (int k = 0; k < kFastKeys; k++) {
+            if (k < (int)F.nkeys) {
+                uint32_t vt[R];
+                uint64_t vp[R];
+                pick_col<R>(F.keys[k].col, ctag, cpay, vt, vp);
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    uint32_t tg = vt[j];
+                    uint32_t f = tg == T_MISSING ? 0u : (tg == T_NULL ? 1u : (uint32_t)vp[j] + 2u);
+                    if (pass[j] && ((tg > T_NULL && tg != T_STRING) || f >= F.keys[k].radix)) {
+                        unpackable = 1;
+                        pass[j] = false;
+                    }
+                    slot[j] += (pass[j] ? f : 0u) * F.keys[k].stride;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (pass[j]) {
+                selected++;
+                if (lds_peek(lds_word(lds, slot[j])) == kEmptyKey) *(volatile lds_u64*)lds_word(lds, slot[j]) = 1ull;
+            }
+        }
+        // CumulateInitial of every aggregate (execution/group_initial.go:89-97)
+#pragma unroll
+        for (int a = 0; a < kFastAggs; a++) {
+            if (a < (int)F.naggs) {
+                const AggSpec& ag = P.aggs[a];
+                if (!ag.has_operand) {
+#pragma unroll
+                    for (int j = 0; j < R; j++)
+                        if (pass[j]) acc_lds(P, ag, lds, S, slot[j], T_NULL, 0ull);
+                } else {
+                    uint32_t vt[R];
+                    uint64_t vp[R];
+                    pick_col<R>(F.agg_col[a], ctag, cpay, vt, vp);
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        if (pass[j] && !acc_lds(P, ag, lds, S, slot[j], vt[j], vp[j])) {
+                            long long g = global_find_or_insert(G, fast_slot_key(F, slot[j]), F.err_flags, ngroups);
+                            if (g >= 0) acc_global(P, ag, &G.acc[(size_t)g * P.glob_words], vt[j], vp[j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+    for (int off = 32; off > 0; off >>= 1) selected += __shfl_down(selected, off, 64);
+    if ((tid & 63) == 0 && selected) atomicAdd(F.rows_selected, (unsigned long long)selected);
+
+    __syncthreads();
+    // K4: merge this workgroup's partial groups into the global table (≙ IntermediateGroup)
+    for (uint32_t s = tid; s < S; s += BLOCK) {
+        if (lds[s] == kEmptyKey) continue;
+        long long g = global_find_or_insert(G, fast_slot_key(F, s), F.err_flags, ngroups);
+        if (g < 0) continue;
+        merge_slot(P, lds, S, s, &G.acc[(size_t)g * P.glob_words]);
+    }
+}
+
+}  // namespace n1k
+#include "n1k_spec.h"
+namespace n1k {
+
+// ---- ahead-of-time instantiated plan shapes ------------------------------------------------------------------
+// (column order = order of first use in the plan: condition, keys, aggregates; aggregates sorted by text as the
+//  planner emits them, planner/build_select_sub.go:551-558)
+#define T64 COLK_TAGGED64
+#define D32 COLK_DICT32
+#define ST(op, col, ci) SpecTerm{op, col, ci}
+#define SA(kind, has, col) SpecAgg{kind, has, col}
+#define NOTERM ST(0, 0, 0)
+#define NOAGG SA(0, 0, 0)
+// SELECT k, SUM(x) WHERE x <cmp> int GROUP BY k          (BASELINE config 2)
+N1K_DEFINE_SPEC(Spec_gt_sum, 2, T64, D32, 0, 1, ST(TERM_NUM_GT, 0, 1), NOTERM, 1, 1, 0, 1, SA(AGG_SUM, 1, 0), NOAGG, NOAGG, NOAGG, NOAGG);
+N1K_DEFINE_SPEC(Spec_lt_sum, 2, T64, D32, 0, 1, ST(TERM_NUM_LT, 0, 1), NOTERM, 1, 1, 0, 1, SA(AGG_SUM, 1, 0), NOAGG, NOAGG, NOAGG, NOAGG);
+N1K_DEFINE_SPEC(Spec_gtf_sum, 2, T64, D32, 0, 1, ST(TERM_NUM_GT, 0, 0), NOTERM, 1, 1, 0, 1, SA(AGG_SUM, 1, 0), NOAGG, NOAGG, NOAGG, NOAGG);
+// ... with AVG, COUNT(*), MAX, MIN, SUM of the filtered column
+N1K_DEFINE_SPEC(Spec_gt_all, 2, T64, D32, 0, 1, ST(TERM_NUM_GT, 0, 1), NOTERM, 1, 1, 0, 5, SA(AGG_AVG, 1, 0), SA(AGG_COUNT, 0, 0),
+                SA(AGG_MAX, 1, 0), SA(AGG_MIN, 1, 0), SA(AGG_SUM, 1, 0));
+// SELECT k, COUNT(*) WHERE x > int GROUP BY k
+N1K_DEFINE_SPEC(Spec_gt_count, 2, T64, D32, 0, 1, ST(TERM_NUM_GT, 0, 1), NOTERM, 1, 1, 0, 1, SA(AGG_COUNT, 0, 0), NOAGG, NOAGG, NOAGG, NOAGG);
+// SELECT k, SUM(x) GROUP BY k ; SELECT k, AVG(x) GROUP BY k ; SELECT k, COUNT(*) GROUP BY k
+N1K_DEFINE_SPEC(Spec_sum, 2, D32, T64, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_SUM, 1, 1), NOAGG, NOAGG, NOAGG, NOAGG);
+N1K_DEFINE_SPEC(Spec_avg, 2, D32, T64, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_AVG, 1, 1), NOAGG, NOAGG, NOAGG, NOAGG);
+N1K_DEFINE_SPEC(Spec_count, 1, D32, 0, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_COUNT, 0, 0), NOAGG, NOAGG, NOAGG, NOAGG);
+// SELECT COUNT(*) / SUM(x) WHERE x > int
+N1K_DEFINE_SPEC(Spec_gt_nokey_count, 1, T64, 0, 0, 1, ST(TERM_NUM_GT, 0, 1), NOTERM, 0, 0, 0, 1, SA(AGG_COUNT, 0, 0), NOAGG, NOAGG, NOAGG, NOAGG);
+// SELECT k1, k2, SUM(x) GROUP BY k1, k2 (two dictionary keys)
+N1K_DEFINE_SPEC(Spec_2k_sum, 3, D32, D32, T64, 0, NOTERM, NOTERM, 2, 0, 1, 1, SA(AGG_SUM, 1, 2), NOAGG, NOAGG, NOAGG, NOAGG);
+#undef T64
+#undef D32
+#undef ST
+#undef SA
+#undef NOTERM
+#undef NOAGG
+
+template <class Spec>
+static SpecSig make_sig() {
+    SpecSig g{};
+    g.ncols = Spec::ncols; g.nterms = Spec::nterms; g.nkeys = Spec::nkeys; g.naggs = Spec::naggs;
+    for (int c = 0; c < kFastCols; c++) g.col_kind[c] = c < Spec::ncols ? Spec::col_kind[c] : 0;
+    for (int t = 0; t < kFastTerms; t++) if (t < Spec::nterms) g.terms[t] = Spec::terms[t];
+    for (int k = 0; k < kFastKeys; k++) g.key_col[k] = k < Spec::nkeys ? Spec::key_col[k] : 0;
+    for (int a = 0; a < kFastAggs; a++) if (a < Spec::naggs) g.aggs[a] = Spec::aggs[a];
+    return g;
+}
+
+template <class Spec>
+static hipError_t launch_spec(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
+                              uint32_t grid, uint32_t block, bool wide, hipStream_t st) {
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8;
+#define N1K_LAUNCH(R, B, W)                                                                                       \
+    do {                                                                                                          \
+        auto k = scan_spec_kernel<Spec, R, B, W>;                                                                 \
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(B), shmem, st, P, F, G, ngroups);                                  \
+    } while (0)
+    if (block == 512) { if (wide) N1K_LAUNCH(2, 512, true); else N1K_LAUNCH(4, 512, false); }
+    else { if (wide) N1K_LAUNCH(2, 1024, true); else N1K_LAUNCH(4, 1024, false); }
+#undef N1K_LAUNCH
+    return hipGetLastError();
+}
+
+const std::vector<SpecEntry>& spec_registry() {
+    static const std::vector<SpecEntry> reg = {
+#define N1K_REG(S) SpecEntry{#S, make_sig<S>(), &launch_spec<S>}
+        N1K_REG(Spec_gt_sum), N1K_REG(Spec_lt_sum), N1K_REG(Spec_gtf_sum), N1K_REG(Spec_gt_all), N1K_REG(Spec_gt_count),
+        N1K_REG(Spec_sum), N1K_REG(Spec_avg), N1K_REG(Spec_count), N1K_REG(Spec_gt_nokey_count), N1K_REG(Spec_2k_sum),
+#undef N1K_REG
+    };
+    return reg;
 }
 
 __global__ void init_table_kernel(const Program P, const GlobalTable G, uint64_t first, uint64_t count) {
@@ -544,28 +888,29 @@ N1K_DEV void finalize_agg(const Program& P, const AggSpec& ag, const uint64_t* g
             break;
         case AGG_SUM:
         case AGG_AVG: {
-            uint64_t nn = w[3], ng = w[4], nf = w[5];
-            uint64_t n = nn + ng + nf;
+            uint64_t fl = w[3];
+            bool has_nn = fl & SF_NONNEG_INT, has_ng = fl & SF_NEG_INT, has_f = fl & SF_FLOAT;
             // exact 128-bit integer total = hi * 2^32 + lo
             __int128 tot = ((__int128)(int64_t)w[1] << 32) + (__int128)(unsigned __int128)w[0];
             bool fits = tot >= (__int128)INT64_MIN && tot <= (__int128)INT64_MAX;
             // intValue.Add keeps an int only for same-sign operands without overflow (value/integer.go:266-277)
-            bool int_exact = nf == 0 && !(nn > 0 && ng > 0) && fits;
+            bool int_exact = !has_f && !(has_nn && has_ng) && fits;
             double itot = (double)(int64_t)w[1] * 4294967296.0 + (double)w[0];
             if (fits) itot = (double)(int64_t)tot;
             double fsum = as_f64(w[2]);
+            uint64_t n = ag.kind == AGG_AVG ? w[4] : 0;
             pt.count = (int64_t)n;
             pt.isum = int_exact ? (int64_t)tot : 0;
             pt.fsum = int_exact ? fsum : fsum + itot;
-            pt.flags = (int_exact ? 1u : 0u) | (nf ? 2u : 0u);
-            if (n == 0) {
+            pt.flags = (int_exact ? 1u : 0u) | (has_f ? 2u : 0u);
+            if (fl == 0) {
                 put_value(fin, T_NULL, 0);  // Default(): NULL (agg_sum.go:77, agg_avg.go:77)
             } else if (ag.kind == AGG_SUM) {
                 if (int_exact) put_value(fin, T_INT, (uint64_t)(int64_t)tot);
                 else put_value(fin, T_FLOAT, f64_bits(fsum + itot));
             } else {
-                double s = int_exact ? (double)(int64_t)tot : fsum + itot;
-                double avg = s / (double)n;  // agg_avg.go:124-125 -> value.NewValue folds integral results
+                double sm = int_exact ? (double)(int64_t)tot : fsum + itot;
+                double avg = sm / (double)n;  // agg_avg.go:124-125 -> value.NewValue folds integral results
                 if (is_int_f64(avg)) put_value(fin, T_INT, (uint64_t)go_f2i(avg));
                 else put_value(fin, T_FLOAT, f64_bits(avg));
             }
@@ -792,12 +1137,48 @@ hipError_t launch_rehash(const Program& P, const GlobalTable& oldt, const Global
     return hipGetLastError();
 }
 
-hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTable& G, unsigned long long* ngroups,
-                             uint32_t grid, hipStream_t st) {
-    constexpr int R = 4, BLOCK = 256;
-    size_t shmem = (size_t)A.lds_slots * P.lds_words * 8;
-    hipLaunchKernelGGL((scan_group_kernel<R, BLOCK>), dim3(grid), dim3(BLOCK), shmem, st, P, A, G, ngroups);
+template <int R, int BLOCK>
+static hipError_t launch_scan_variant(const Program& P, const ScanArgs& A, const GlobalTable& G, unsigned long long* ngroups,
+                                      uint32_t grid, bool direct, size_t shmem, hipStream_t st) {
+    if (direct) {
+        auto k = scan_group_kernel<R, BLOCK, true>;
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), shmem, st, P, A, G, ngroups);
+    } else {
+        auto k = scan_group_kernel<R, BLOCK, false>;
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), shmem, st, P, A, G, ngroups);
+    }
     return hipGetLastError();
+}
+
+hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTable& G, unsigned long long* ngroups,
+                             uint32_t grid, uint32_t block, uint32_t rows_per_lane, bool direct, hipStream_t st) {
+    size_t shmem = (size_t)A.lds_slots * P.lds_words * 8;
+    if (block == 256) return launch_scan_variant<4, 256>(P, A, G, ngroups, grid, direct, shmem, st);
+    if (block == 512) return launch_scan_variant<4, 512>(P, A, G, ngroups, grid, direct, shmem, st);
+    if (rows_per_lane == 2) return launch_scan_variant<2, 1024>(P, A, G, ngroups, grid, direct, shmem, st);
+    return launch_scan_variant<4, 1024>(P, A, G, ngroups, grid, direct, shmem, st);
+}
+
+template <int R, int BLOCK>
+static hipError_t launch_fast_variant(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
+                                      uint32_t grid, size_t shmem, hipStream_t st) {
+    auto k = scan_fast_kernel<R, BLOCK>;
+    if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), shmem, st, P, F, G, ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
+                            uint32_t grid, uint32_t block, uint32_t rows_per_lane, hipStream_t st) {
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8;
+    if (block == 512) {
+        if (rows_per_lane == 2) return launch_fast_variant<2, 512>(P, F, G, ngroups, grid, shmem, st);
+        return launch_fast_variant<4, 512>(P, F, G, ngroups, grid, shmem, st);
+    }
+    if (rows_per_lane == 2) return launch_fast_variant<2, 1024>(P, F, G, ngroups, grid, shmem, st);
+    return launch_fast_variant<4, 1024>(P, F, G, ngroups, grid, shmem, st);
 }
 
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,

@@ -54,7 +54,11 @@ enum : uint32_t {
     TERM_IS_NOT_MISSING,
     TERM_IS_VALUED,    // comp_valued.go:61-68
     TERM_IS_NOT_VALUED,
-    TERM_TRUTH         // a bare value used as a condition: type + Truth()
+    TERM_TRUTH,        // a bare value used as a condition: type + Truth()
+    // fast forms of LT/LE/EQ when operand b is a NUMBER constant (same semantics, fewer instructions):
+    // a <op> const with op in {<, <=, >, >=, =}   ("(50 < x)" is stored as x GT 50)
+    TERM_NUM_LT, TERM_NUM_LE, TERM_NUM_GT, TERM_NUM_GE, TERM_NUM_EQ,
+    TERM_STR_EQ        // a = STRING constant (dictionary code compare)
 };
 
 struct Term {
@@ -90,17 +94,23 @@ struct AggSpec {
     Operand src;
 };
 
-// LDS accumulator words per aggregate
+// LDS accumulator words per aggregate (the LDS table is word-major: word w of slot s lives at lds[w * S + s])
 //   COUNT/COUNTN : [cnt]
-//   SUM/AVG      : [isum i64][fsum f64][n_neg<<32 | n_nonneg][n_float]
+//   SUM          : [isum i64][fsum f64][flags]          one atomic per row; flags are read-mostly
+//   AVG          : [isum i64][fsum f64][flags][n]
 //   MIN/MAX      : [flags][ival i64][fval sortable u64][sval rank<<32|code]
 //   * DISTINCT   : (none; pairs go to the distinct log)
 // global accumulator words per aggregate
 //   COUNT/COUNTN : [cnt]
-//   SUM/AVG      : [isum_lo][isum_hi][fsum][n_nonneg][n_neg][n_float]
+//   SUM          : [isum_lo][isum_hi][fsum][flags]
+//   AVG          : [isum_lo][isum_hi][fsum][flags][n]
 //   MIN/MAX      : [flags][ival][fval][sval]
 //   * DISTINCT   : [distinct count]  (filled at finish)
-constexpr uint32_t kLdsWordsSum = 4, kGlobWordsSum = 6, kWordsMinMax = 4;
+constexpr uint32_t kLdsWordsSum = 3, kLdsWordsAvg = 4, kGlobWordsSum = 4, kGlobWordsAvg = 5, kWordsMinMax = 4;
+
+// SUM/AVG flag bits: which kinds of NUMBER operands were met.  intValue.Add keeps an int64 only for same-sign
+// operands (value/integer.go:266-277), so the sign mix decides the representation of the result.
+enum : uint64_t { SF_NONNEG_INT = 1, SF_NEG_INT = 2, SF_FLOAT = 4 };
 
 // MIN/MAX flag bits
 enum : uint64_t { MM_FALSE = 1, MM_TRUE = 2, MM_INT = 4, MM_FLOAT = 8, MM_STRING = 16, MM_OTHER = 32 };
@@ -138,12 +148,62 @@ struct GlobalTable {
 struct ScanArgs {
     uint64_t nrows;
     uint64_t row_base;        // ordinal of row 0 of this batch
-    uint32_t lds_slots;       // power of two
-    uint32_t lds_max_fill;    // stop inserting new keys beyond this many occupied slots
+    uint32_t lds_slots;       // S: slots of the LDS table (any value >= 2)
+    uint32_t lds_max_fill;    // HASH mode: stop inserting new keys beyond this many occupied slots
+    uint32_t direct_stride[kMaxKeys];  // DIRECT mode: slot = sum(field_k * stride_k), field_k < radix_k
+    uint32_t direct_radix[kMaxKeys];
     uint32_t* err_flags;      // device word, OR of ERR_*
     unsigned long long* rows_selected;  // device counter
     uint32_t wave_reduce;
     uint32_t compact;
+};
+
+// ---- "fast" scan kernel: bounded plan shapes with every descriptor at a static index ------------------------
+// <= 4 columns (each loaded once per row into registers), <= 2 cheap terms combined by AND, <= 2 dictionary
+// keys addressed by perfect hash (DIRECT), <= 5 non-DISTINCT aggregates over columns.
+constexpr int kFastCols = 3, kFastTerms = 2, kFastKeys = 2, kFastAggs = 5;
+
+struct FastTerm {
+    uint32_t op;    // TERM_NUM_* / TERM_IS_* / TERM_STR_EQ
+    uint32_t col;   // column slot of operand a
+    uint32_t ctag;
+    uint32_t pad;
+    uint64_t cpayload;
+};
+struct FastKey {
+    uint32_t col, stride, radix, shift;
+};
+struct FastArgs {
+    uint32_t ncols, nterms, nkeys, naggs;
+    uint32_t nrows;      // rows of this launch (< 2^32)
+    uint32_t lds_slots;  // S
+    uint64_t row_base;
+    DevCol cols[kFastCols];
+    FastTerm terms[kFastTerms];
+    FastKey keys[kFastKeys];
+    uint32_t agg_col[kFastAggs];  // column slot of each aggregate's operand (unused when has_operand == 0)
+    uint32_t pad;
+    uint32_t* err_flags;
+    unsigned long long* rows_selected;
+};
+
+// compile-time shape of a plan handled by scan_spec_kernel (see n1k_spec.h)
+struct SpecTerm {
+    uint32_t op;         // TERM_NUM_* / TERM_IS_* / TERM_STR_EQ
+    uint32_t col;        // column slot
+    uint32_t const_int;  // TERM_NUM_*: 1 = the constant is an INT, 0 = FLOAT
+};
+struct SpecAgg {
+    uint32_t kind;  // AGG_*
+    uint32_t has_operand;
+    uint32_t col;
+};
+struct SpecSig {
+    int ncols, nterms, nkeys, naggs;
+    uint32_t col_kind[kFastCols];
+    SpecTerm terms[kFastTerms];
+    uint32_t key_col[kFastKeys];
+    SpecAgg aggs[kFastAggs];
 };
 
 }  // namespace n1k

@@ -161,36 +161,77 @@ class GpuFilterGroup:
         self._check(self._lib.n1k_sync(self._h))
 
     # -------------------------------------------------------------------- results
-    def _value(self, v) -> tuple:
-        t = v.tag
-        if t == _ffi.T_INT:
-            return (t, int(v.v.i))
-        if t == _ffi.T_FLOAT:
-            return (t, float(v.v.f))
-        if t in (_ffi.T_STRING, _ffi.T_ARRAY, _ffi.T_OBJECT):
-            return (t, self.dict_get(int(v.v.code)))
-        return (t, None)
+    _VALUE_DT = np.dtype([("tag", "u1"), ("pad", "u1", (7,)), ("v", "<u8")])
+    _PARTIAL_DT = np.dtype([("count", "<i8"), ("isum", "<i8"), ("fsum", "<f8"), ("int_exact", "u1"), ("has_float", "u1"),
+                            ("pad", "u1", (6,)), ("ext_tag", "u1"), ("ext_pad", "u1", (7,)), ("ext_v", "<u8"),
+                            ("distinct", "<i8")])
 
-    def after_items(self) -> GroupRows:
+    def _finish(self):
         res = _ffi.Result()
         self._check(self._lib.n1k_finish(self._h, C.byref(res)))
+        return res
+
+    def after_items_raw(self) -> dict:
+        """FinalGroup output as numpy arrays (copies): keys/aggs are structured (tag, v) arrays of shape
+        [ngroups, nkeys] / [ngroups, naggs]; string values are dictionary codes."""
+        res = self._finish()
         ng, nk, na = int(res.ngroups), int(res.nkeys), int(res.naggs)
-        out = GroupRows(nk, na, [], [], [])
-        if res.nselected or not ng:
-            out.selected = (np.ctypeslib.as_array(res.selected, shape=(int(res.nselected),)).copy()
-                            if res.nselected else np.zeros(0, dtype=np.uint64))
-        for g in range(ng):
-            out.keys.append(tuple(self._value(res.keys[g * nk + k]) for k in range(nk)))
-            out.aggs.append(tuple(self._value(res.aggs[g * na + a]) for a in range(na)))
-            parts = []
-            for a in range(na):
-                p = res.partials[g * na + a]
-                parts.append({"count": int(p.count), "isum": int(p.isum), "fsum": float(p.fsum),
-                              "int_exact": int(p.int_exact), "has_float": int(p.has_float),
-                              "extreme": self._value(p.extreme), "distinct": int(p.distinct)})
-            out.partials.append(tuple(parts))
-        if ng and res.rep_row:
-            out.rep_row = np.ctypeslib.as_array(res.rep_row, shape=(ng,)).copy()
+
+        def arr(ptr, count, dt):
+            if not count or not ptr:
+                return np.zeros(0, dtype=dt)
+            raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * dt.itemsize,))
+            return raw.view(dt).copy()
+
+        out = {"ngroups": ng, "nkeys": nk, "naggs": na,
+               "keys": arr(res.keys, ng * nk, self._VALUE_DT).reshape(ng, nk) if nk else np.zeros((ng, 0), self._VALUE_DT),
+               "aggs": arr(res.aggs, ng * na, self._VALUE_DT).reshape(ng, na) if na else np.zeros((ng, 0), self._VALUE_DT),
+               "partials": arr(res.partials, ng * na, self._PARTIAL_DT).reshape(ng, na) if na else None,
+               "rep_row": arr(res.rep_row, ng, np.dtype("<u8")) if ng else None,
+               "selected": arr(res.selected, int(res.nselected), np.dtype("<u8"))}
+        return out
+
+    def _py_values(self, a: np.ndarray, cache: dict) -> list:
+        """structured (tag, v) array [n, m] -> list of n tuples of (tag, python value)."""
+        tags = a["tag"]
+        v = a["v"]
+        ints = v.view(np.int64)
+        flts = v.view(np.float64)
+        rows = []
+        for r in range(a.shape[0]):
+            row = []
+            for c in range(a.shape[1]):
+                t = int(tags[r, c])
+                if t == _ffi.T_INT:
+                    row.append((t, int(ints[r, c])))
+                elif t == _ffi.T_FLOAT:
+                    row.append((t, float(flts[r, c])))
+                elif t >= _ffi.T_STRING:
+                    code = int(v[r, c])
+                    s = cache.get(code)
+                    if s is None:
+                        s = cache[code] = self.dict_get(code)
+                    row.append((t, s))
+                else:
+                    row.append((t, None))
+            rows.append(tuple(row))
+        return rows
+
+    def after_items(self) -> GroupRows:
+        raw = self.after_items_raw()
+        ng, nk, na = raw["ngroups"], raw["nkeys"], raw["naggs"]
+        cache: dict = {}
+        out = GroupRows(nk, na, self._py_values(raw["keys"], cache) if ng else [],
+                        self._py_values(raw["aggs"], cache) if ng else [], [])
+        out.selected = raw["selected"]
+        if ng and na:
+            p = raw["partials"]
+            for g in range(ng):
+                out.partials.append(tuple(
+                    {"count": int(p[g, a]["count"]), "isum": int(p[g, a]["isum"]), "fsum": float(p[g, a]["fsum"]),
+                     "int_exact": int(p[g, a]["int_exact"]), "has_float": int(p[g, a]["has_float"]),
+                     "distinct": int(p[g, a]["distinct"])} for a in range(na)))
+        out.rep_row = raw["rep_row"]
         return out
 
     def stats(self) -> dict:
