@@ -1072,9 +1072,60 @@ n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
 
 n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uint32_t nparts, uint64_t capacity_rows,
                                       const n1k_col* out_cols, uint64_t* out_counts) {
-    if (!h) return N1K_INVALID;
-    (void)batch; (void)nparts; (void)capacity_rows; (void)out_cols; (void)out_counts;
-    return fail(h, N1K_UNSUPPORTED, "partition kernel not built yet");
+    if (!h || !batch || !out_cols || !out_counts || nparts == 0) return N1K_INVALID;
+    if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
+    if (!h->plan.has_group) return fail(h, N1K_INVALID, "partitioning needs group keys");
+    if (sizeof(Program) + sizeof(PartArgs) + 64 > 4096) return fail(h, N1K_UNSUPPORTED, "kernel arguments exceed 4 KiB");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    st = validate_batch(h, batch);
+    if (st != N1K_OK) return st;
+    if (!h->layout_fixed) {
+        st = fix_layout(h, batch);
+        if (st != N1K_OK) return st;
+    }
+    Program& P = h->prog;
+    PartArgs A{};
+    for (uint32_t c = 0; c < P.ncols; c++) {
+        P.cols[c].kind = batch->cols[c].kind == N1K_COL_DICT32 ? COLK_DICT32 : COLK_TAGGED64;
+        P.cols[c].tags = batch->cols[c].tags;
+        P.cols[c].payload = batch->cols[c].payload;
+        P.cols[c].codes = batch->cols[c].codes;
+        if (out_cols[c].kind != batch->cols[c].kind) return fail(h, N1K_INVALID, "output column %u has another kind", c);
+        A.out_tags[c] = (uint8_t*)out_cols[c].tags;
+        A.out_payload[c] = (uint64_t*)out_cols[c].payload;
+        A.out_codes[c] = (uint32_t*)out_cols[c].codes;
+    }
+    P.dict_size = (uint32_t)h->dict.size();
+    P.empty_str_code = lookup_code(h, "");
+    P.empty_arr_code = lookup_code(h, "[]");
+    P.empty_obj_code = lookup_code(h, "{}");
+    st = ensure_rank(h);
+    if (st != N1K_OK) return st;
+    A.nrows = batch->nrows;
+    A.capacity = capacity_rows;
+    A.nparts = nparts;
+    A.counts = (unsigned long long*)out_counts;
+    A.err_flags = h->d_err.p;
+    HIP_TRY(h, hipMemsetAsync(out_counts, 0, nparts * sizeof(uint64_t), h->stream));
+    if (batch->nrows) {
+        uint64_t ntiles = (batch->nrows + 1023) / 1024;
+        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8, ntiles));
+        hipEvent_t e0 = get_event(h), e1 = get_event(h);
+        if (e0) (void)hipEventRecord(e0, h->stream);
+        HIP_TRY(h, launch_partition(P, A, grid, h->stream));
+        if (e1) (void)hipEventRecord(e1, h->stream);
+        h->events.emplace_back(e0, e1);
+    }
+    uint32_t err_flags = 0;
+    HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (err_flags & ERR_TABLE_FULL) return fail(h, N1K_OOM, "partition region capacity (%llu rows) exceeded", (unsigned long long)capacity_rows);
+    if (err_flags & ERR_UNPACKABLE_KEY) return fail(h, N1K_UNSUPPORTED_DATA, "a group key value does not fit the packed key");
+    if (err_flags & ERR_UNSUPPORTED_VALUE) return fail(h, N1K_UNSUPPORTED_DATA, "a value outside the device subset was met");
+    h->stats.rows_in += batch->nrows;
+    h->stats.batches += 1;
+    return N1K_OK;
 }
 
 n1k_status n1k_export_groups(n1k_handle* h, const void** blob, size_t* len) {

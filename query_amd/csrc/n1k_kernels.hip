@@ -847,6 +847,90 @@ __global__ void init_table_kernel(const Program P, const GlobalTable G, uint64_t
     glob_row_init(P, &G.acc[(size_t)s * P.glob_words]);
 }
 
+// ------------------------------------------------------------------ multi-GPU: hash partition of the filter's survivors
+//
+// No reference analogue (the reference fans in through one in-memory queue, execution/exchange.go:161-251): every
+// surviving row goes to the GPU that owns hash(group key) % nparts, so that each group lives on exactly one GPU
+// and COUNT(DISTINCT) needs no cross-GPU merge.  Region d of every output column receives the rows for rank d;
+// positions come from one wave-aggregated atomic per (wave, destination).
+template <int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const PartArgs A) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    uint32_t unsupported = 0, unpackable = 0;
+    const uint64_t tile_rows = (uint64_t)BLOCK * R;
+    const uint64_t ntiles = (A.nrows + tile_rows - 1) / tile_rows;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t row[R];
+        bool valid[R], pass[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            row[j] = tile * tile_rows + (uint64_t)j * BLOCK + tid;
+            valid[j] = row[j] < A.nrows;
+        }
+        eval_predicate<R>(P, row, valid, pass, unsupported);
+        uint64_t key[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) key[j] = 0;
+        for (uint32_t k = 0; k < P.nkeys; k++) {
+            const KeySpec& ks = P.keys[k];
+            uint32_t kt[R];
+            uint64_t kp[R];
+            load_operand<R>(P, ks.src, row, pass, kt, kp);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                uint64_t f = 0;
+                if (pass[j] && !pack_key_field(ks, kt[j], kp[j], f)) {
+                    unpackable = 1;
+                    pass[j] = false;
+                }
+                key[j] |= f << ks.shift;
+            }
+        }
+        uint64_t pos[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            uint32_t dest = (uint32_t)(((mix64(key[j]) >> 32) * (uint64_t)A.nparts) >> 32);
+            pos[j] = 0;
+            for (uint32_t d = 0; d < A.nparts; d++) {
+                unsigned long long m = __ballot(pass[j] && dest == d);
+                if (m == 0ull) continue;
+                int leader = __ffsll((long long)m) - 1;
+                unsigned long long base = 0;
+                if ((int)lane == leader) base = atomicAdd(&A.counts[d], (unsigned long long)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (pass[j] && dest == d) {
+                    uint64_t r = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (r >= A.capacity) {
+                        atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                        pass[j] = false;
+                    }
+                    pos[j] = (uint64_t)d * A.capacity + r;
+                }
+            }
+        }
+        for (uint32_t c = 0; c < P.ncols; c++) {
+            Operand o{};
+            o.is_const = 0;
+            o.col = c;
+            uint32_t vt[R];
+            uint64_t vp[R];
+            load_operand<R>(P, o, row, pass, vt, vp);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                if (!pass[j]) continue;
+                if (P.cols[c].kind == COLK_DICT32) {
+                    A.out_codes[c][pos[j]] = (uint32_t)vp[j];
+                } else {
+                    A.out_tags[c][pos[j]] = (uint8_t)vt[j];
+                    A.out_payload[c][pos[j]] = vp[j];
+                }
+            }
+        }
+    }
+    if (unsupported) atomicOr(A.err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
+    if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+}
+
 // grow the global table: re-insert every occupied slot (keys keep their packed form)
 __global__ void rehash_kernel(const Program P, const GlobalTable oldt, const GlobalTable newt, uint32_t* err_flags,
                               unsigned long long* scratch) {
@@ -1179,6 +1263,11 @@ hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTab
     }
     if (rows_per_lane == 2) return launch_fast_variant<2, 1024>(P, F, G, ngroups, grid, shmem, st);
     return launch_fast_variant<4, 1024>(P, F, G, ngroups, grid, shmem, st);
+}
+
+hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, hipStream_t st) {
+    hipLaunchKernelGGL((partition_kernel<4, 256>), dim3(grid), dim3(256), 0, st, P, A);
+    return hipGetLastError();
 }
 
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,

@@ -187,6 +187,17 @@ struct FastArgs {
     unsigned long long* rows_selected;
 };
 
+struct PartArgs {
+    uint64_t nrows;
+    uint64_t capacity;  // rows per destination region
+    uint32_t nparts, pad;
+    unsigned long long* counts;  // nparts counters (rows written per destination)
+    uint32_t* err_flags;
+    uint8_t* out_tags[kMaxCols];
+    uint64_t* out_payload[kMaxCols];
+    uint32_t* out_codes[kMaxCols];
+};
+
 // compile-time shape of a plan handled by scan_spec_kernel (see n1k_spec.h)
 struct SpecTerm {
     uint32_t op;         // TERM_NUM_* / TERM_IS_* / TERM_STR_EQ

@@ -1,0 +1,217 @@
+"""Multi-GPU Filter -> Group -> Aggregate: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference has no distributed query path (README.md:61-65); inside one process it fans Parallel copies into
+one serial IntermediateGroup through an in-memory queue (execution/exchange.go:161-251).  Here every rank
+
+  1. filters its own row shard and hash-partitions the survivors on the group key
+     (n1k_partition_device_batch: hash(key) % world, one region per destination rank),
+  2. exchanges the regions with ONE all-to-all per column buffer (RCCL all_to_all_single with split sizes; on an
+     8-GPU node every GPU pair has its own xGMI link, so all 7 links of a GPU carry traffic at once),
+  3. runs InitialGroup/FinalGroup on the rows it received (it owns those groups entirely, so no partial states
+     cross the fabric and COUNT(DISTINCT) needs no set merge),
+  4. gathers the finished groups on rank 0 (the only serial step, G rows).
+
+The exchange code is backend-agnostic (it moves torch tensors with all_to_all_single / all_gather), so the same
+functions run under gloo on CPU tensors in tests/test_distributed_cpu.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def exchange_counts(counts, group=None):
+    """counts[d] rows this rank sends to rank d  ->  tensor recv[s] rows it receives from rank s."""
+    import torch
+    import torch.distributed as dist
+    recv = torch.empty_like(counts)
+    dist.all_to_all_single(recv, counts, group=group)
+    return recv
+
+
+def exchange_rows(send_cols: Sequence, send_counts: Sequence[int], recv_counts: Sequence[int], group=None) -> List:
+    """One all_to_all_single per column buffer.  send_cols[c] is contiguous and ordered by destination rank
+    (send_counts rows each); returns the received column buffers ordered by source rank."""
+    import torch
+    import torch.distributed as dist
+    out = []
+    total = int(sum(recv_counts))
+    for col in send_cols:
+        recv = torch.empty((total,) + tuple(col.shape[1:]), dtype=col.dtype, device=col.device)
+        dist.all_to_all_single(recv, col, output_split_sizes=[int(x) for x in recv_counts],
+                               input_split_sizes=[int(x) for x in send_counts], group=group)
+        out.append(recv)
+    return out
+
+
+def gather_groups(local: np.ndarray, device=None, dst: int = 0, group=None) -> Optional[np.ndarray]:
+    """Gather variable-length arrays of fixed-size records (uint8 [n, record_bytes]) on rank dst."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    width = local.shape[1] if local.ndim == 2 else 1
+    mx = max(max(counts), 1)
+    pad = np.zeros((mx, width), dtype=np.uint8)
+    pad[:local.shape[0]] = local.reshape(local.shape[0], width)
+    mine = torch.from_numpy(pad).to(dev)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)  # G rows: tiny next to the row exchange
+    if rank != dst:
+        return None
+    parts = [bufs[r][:counts[r]].cpu().numpy() for r in range(world)]
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, width), np.uint8)
+
+
+class ShardedFilterGroup:
+    """One rank's share of the distributed operator (device path through libn1k.so)."""
+
+    def __init__(self, condition: Optional[str], keys: Sequence[str], aggs: Sequence[str], dictionary: Sequence[bytes],
+                 rank: int, world: int, device: int, **options):
+        import query_amd
+        from query_amd import plan
+        self.rank, self.world, self.device = rank, world, device
+        # sender: Filter + key evaluation; receiver: the same grouping without the Filter (it was applied already)
+        self.sender = query_amd.GpuFilterGroup(plan.filter_group_plan(condition, keys, aggs), device=device)
+        self.receiver = query_amd.GpuFilterGroup(plan.filter_group_plan(None, keys, aggs), device=device, **options)
+        self.sender.intern(list(dictionary))
+        self.receiver.intern(list(dictionary))
+        self.send_paths = self.sender.column_paths
+        self.recv_paths = self.receiver.column_paths
+        self._bufs = None
+
+    def _alloc(self, capacity: int, kinds: Sequence[int]):
+        import torch
+        from query_amd import _ffi
+        dev = torch.device("cuda", self.device)
+        bufs = []
+        for k in kinds:
+            if k == _ffi.COL_DICT32:
+                bufs.append({"codes": torch.empty(capacity * self.world, dtype=torch.int32, device=dev)})
+            else:
+                bufs.append({"tags": torch.empty(capacity * self.world, dtype=torch.uint8, device=dev),
+                             "payload": torch.empty(capacity * self.world, dtype=torch.int64, device=dev)})
+        counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        return bufs, counts
+
+    def run(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
+        """cols_by_path: path -> (kind, tags_ptr, payload_ptr, codes_ptr) device addresses of this rank's shard.
+        Returns (local final groups as numpy record arrays, timing/volume info)."""
+        import torch
+        import torch.distributed as dist
+        from query_amd import _ffi
+        cols = [cols_by_path[p] for p in self.send_paths]
+        kinds = [c[0] for c in cols]
+        if self._bufs is None or self._bufs[2] < nrows:
+            self._bufs = self._alloc(nrows, kinds) + (nrows,)
+        bufs, counts, cap = self._bufs
+        # 1. filter + hash partition on the group key
+        batch, keep = self.sender._make_batch(nrows, cols)
+        out_arr = (_ffi.Col * len(cols))()
+        for i, (k, b) in enumerate(zip(kinds, bufs)):
+            out_arr[i].kind = k
+            if k == _ffi.COL_DICT32:
+                out_arr[i].codes = b["codes"].data_ptr()
+            else:
+                out_arr[i].tags = b["tags"].data_ptr()
+                out_arr[i].payload = b["payload"].data_ptr()
+        torch.cuda.synchronize()
+        st = self.sender._lib.n1k_partition_device_batch(self.sender._h, C.byref(batch), self.world, cap, out_arr,
+                                                        counts.data_ptr())
+        self.sender._check(st)
+        # 2. all-to-all over xGMI: counts, then one collective per column buffer
+        recv_counts = exchange_counts(counts)
+        sc = counts.cpu().tolist()
+        rc = recv_counts.cpu().tolist()
+        send_cols, layout = [], []
+        for k, b in zip(kinds, bufs):
+            for name in (("codes",) if k == _ffi.COL_DICT32 else ("tags", "payload")):
+                t = b[name]
+                send_cols.append(torch.cat([t[d * cap: d * cap + sc[d]] for d in range(self.world)]))
+                layout.append(name)
+        recv = exchange_rows(send_cols, sc, rc)
+        # 3. local InitialGroup .. FinalGroup on the rows this rank owns
+        received = {}
+        it = iter(recv)
+        for p, k in zip(self.send_paths, kinds):
+            if k == _ffi.COL_DICT32:
+                t = next(it)
+                received[p] = (k, None, None, t.data_ptr(), t)
+            else:
+                tg, pl = next(it), next(it)
+                received[p] = (k, tg.data_ptr(), pl.data_ptr(), None, (tg, pl))
+        nrecv = int(sum(rc))
+        self.receiver.reopen()
+        torch.cuda.synchronize()
+        self.receiver.process_device_items(nrecv, [received[p][:4] for p in self.recv_paths])
+        raw = self.receiver.after_items_raw()
+        info = {"sent_rows": int(sum(sc)), "recv_rows": nrecv}
+        return raw, info
+
+
+def bench_main(args, rank: int, world: int, local_rank: int):
+    """bench.py --gpus N (N > 1): weak scaling, every rank owns `--rows` rows of the global data set."""
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    wl = bench.workloads()[args.workload]
+    total_rows = args.rows * world
+    cols = bench.DeviceColumns(args.rows, args.kcat, bool(args.zipf), rank * args.rows, total_rows, local_rank)
+    op = ShardedFilterGroup(wl["cond"], wl["keys"], wl["aggs"], bench.synth_dictionary(args.kcat), rank, world,
+                            local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    def step():
+        raw, info = op.run(args.rows, cols.by_path)
+        rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
+                              raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1) \
+            if raw["ngroups"] else np.zeros((0, 16 * (raw["nkeys"] + raw["naggs"])), np.uint8)
+        allg = gather_groups(rec, device=dev)
+        return allg, info
+
+    for _ in range(args.warmup):
+        allg, info = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allg, info = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    if rank == 0:
+        out = {
+            "metric": "rows/sec filter+group-by on 100M synthetic JSON docs; achieved HBM GB/s",
+            "value": total_rows * args.steps / elapsed,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64/f64 tagged scalars (u8 tag + 8 B payload), u32 dictionary codes",
+            "data": "synthetic",
+            "config": {"workload": "%s: %s @ %d rows per GPU x %d GPUs, K_cat=%d, rows hash-partitioned on the group "
+                                   "key by RCCL all-to-all, final groups gathered on rank 0" %
+                                   (args.workload, wl["sql"], args.rows, world, args.kcat),
+                       "rows_per_gpu": args.rows, "groups": int(allg.shape[0]) if allg is not None else None,
+                       "exchange_rows_rank0": info},
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()
