@@ -77,8 +77,8 @@ struct n1k_handle {
     uint64_t opt_max_groups = 1ull << 22;
     uint32_t opt_grid_blocks = 0;
     uint32_t opt_compact = 1, opt_wave_reduce = 1, opt_rep_row = 0;
-    uint32_t opt_lds_bytes = 64 * 1024;
-    uint32_t opt_block = 1024, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1;
+    uint32_t opt_lds_bytes = 64 * 1024;   // HASH mode: LDS table bytes per workgroup
+    uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     int device = -1;
     bool device_ready = false;
     hipStream_t stream = nullptr;
@@ -101,7 +101,7 @@ struct n1k_handle {
 
     // device state
     GlobalTable table{};
-    DevBuf<uint64_t> d_keys, d_acc, d_rep;
+    DevBuf<uint64_t> d_keys, d_acc, d_rep, d_slabs;
     DevBuf<uint32_t> d_err;
     DevBuf<unsigned long long> d_counters;  // [0] rows_selected [1] ngroups [2] out_count [3] filter total
     uint64_t row_base = 0;
@@ -586,17 +586,24 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     ScanArgs A{};
     A.nrows = b->nrows;
     A.row_base = h->row_base;
-    uint32_t block = h->opt_block;
+    uint32_t block = h->opt_block ? h->opt_block : 1024;
     uint32_t rpl = block == 1024 ? h->opt_rows_per_lane : 4;
     uint32_t max_slots = h->opt_lds_bytes / (P.lds_words * 8);
     max_slots = (uint32_t)std::min<uint64_t>(max_slots, 1u << 15);
     if (max_slots < 2) return fail(h, N1K_UNSUPPORTED, "accumulator row too wide for LDS");
     FastArgs F;
-    if (h->opt_agg_mode != N1K_MODE_LDS_HASH && build_fast_args(h, max_slots, F)) {
-        uint32_t fblock = block == 256 ? 512 : block;
+    // DIRECT tables may take (almost) the whole 160 KiB LDS of a CU: occupancy is chosen from the table size
+    const uint32_t direct_max_slots = (uint32_t)std::min<uint64_t>((156u * 1024u) / (P.lds_words * 8), 1u << 15);
+    if (h->opt_agg_mode != N1K_MODE_LDS_HASH && build_fast_args(h, direct_max_slots, F)) {
+        const uint32_t table_bytes = F.lds_slots * P.lds_words * 8;
+        // workgroups per CU that fit: 512 threads x 3 (<= 48 KiB each), x 2 (<= 72 KiB), else 1024 threads x 1
+        uint32_t fblock = h->opt_block == 1024 || h->opt_block == 512 ? h->opt_block : (table_bytes <= 72 * 1024 ? 512u : 1024u);
+        uint32_t per_cu = fblock == 512 ? (table_bytes <= 48 * 1024 ? 3u : (table_bytes <= 72 * 1024 ? 2u : 1u))
+                                        : (table_bytes <= 72 * 1024 ? 2u : 1u);
         uint32_t frpl = h->opt_rows_per_lane;
-        uint32_t per_cu = fblock == 1024 ? (frpl == 2 ? 2 : 1) : (frpl == 2 ? 3 : 2);
         uint32_t fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
+        // slabs + merge kernel pay off once the table is more than a few KiB
+        const bool use_slabs = h->opt_slabs == 1 ? table_bytes >= 4096 : h->opt_slabs == 2;
         F.err_flags = h->d_err.p;
         F.rows_selected = h->d_counters.p + 0;
         hipEvent_t e0 = get_event(h), e1 = get_event(h);
@@ -625,9 +632,15 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 uint64_t items = wide ? n_main / 2 : n_main;
                 uint32_t rpl = wide ? 2 : 4;
                 uint64_t tiles = (items + (uint64_t)fblock * rpl - 1) / ((uint64_t)fblock * rpl);
-                uint32_t sgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * (fblock == 1024 ? 2 : 4));
-                uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(sgrid, tiles));
+                uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(fgrid, tiles));
+                F.slabs = nullptr;
+                if (use_slabs && g > 1) {
+                    HIP_TRY(h, h->d_slabs.ensure((size_t)g * P.lds_words * F.lds_slots));
+                    F.slabs = h->d_slabs.p;
+                }
                 HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, h->stream));
+                if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
+                F.slabs = nullptr;
                 if (n_main < n) {
                     for (uint32_t c = 0; c < P.ncols; c++) {
                         if (F.cols[c].tags) F.cols[c].tags += n_main;
@@ -643,7 +656,14 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             F.nrows = (uint32_t)n;
             uint64_t tiles = (n + (uint64_t)fblock * frpl - 1) / ((uint64_t)fblock * frpl);
             uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(fgrid, tiles));
+            F.slabs = nullptr;
+            if (use_slabs && g > 1) {
+                HIP_TRY(h, h->d_slabs.ensure((size_t)g * P.lds_words * F.lds_slots));
+                F.slabs = h->d_slabs.p;
+            }
             HIP_TRY(h, launch_scan_fast(P, F, h->table, h->d_counters.p + 1, g, fblock, frpl, h->stream));
+            if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
+            F.slabs = nullptr;
         }
         if (e1) (void)hipEventRecord(e1, h->stream);
         h->events.emplace_back(e0, e1);
@@ -804,6 +824,7 @@ void n1k_destroy(n1k_handle* h) {
         h->d_keys.release();
         h->d_acc.release();
         h->d_rep.release();
+        h->d_slabs.release();
         h->d_err.release();
         h->d_counters.release();
         for (auto& b : h->st_tags) b.release();
@@ -890,8 +911,9 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fast") h->opt_fast = value ? 1 : 0;
     else if (n == "spec") h->opt_spec = value ? 1 : 0;
     else if (n == "wide") h->opt_wide = value ? 1 : 0;
+    else if (n == "slabs") h->opt_slabs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);  // 0 off, 1 auto, 2 always
     else if (n == "block") {
-        if (value != 256 && value != 512 && value != 1024) return fail(h, N1K_INVALID, "block must be 256, 512 or 1024");
+        if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(h, N1K_INVALID, "block must be 0 (auto), 256, 512 or 1024");
         h->opt_block = (uint32_t)value;
     } else if (n == "rows_per_lane") {
         if (value != 2 && value != 4) return fail(h, N1K_INVALID, "rows_per_lane must be 2 or 4");

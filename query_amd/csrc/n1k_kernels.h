@@ -43,6 +43,8 @@ hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTa
                              uint32_t grid, uint32_t block, uint32_t rows_per_lane, bool direct, hipStream_t st);
 hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                             uint32_t grid, uint32_t block, uint32_t rows_per_lane, hipStream_t st);
+hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalTable& G, uint32_t nblocks,
+                              unsigned long long* ngroups, hipStream_t st);
 hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, hipStream_t st);
 struct SpecEntry {
     const char* name;

@@ -755,6 +755,11 @@ __global__ __launch_bounds__(BLOCK) void scan_fast_kernel(const Program P, const
     if ((tid & 63) == 0 && selected) atomicAdd(F.rows_selected, (unsigned long long)selected);
 
     __syncthreads();
+    if (F.slabs) {
+        uint64_t* slab = F.slabs + (size_t)blockIdx.x * P.lds_words * S;
+        for (uint32_t i = tid; i < P.lds_words * S; i += BLOCK) slab[i] = lds[i];
+        return;
+    }
     // K4: merge this workgroup's partial groups into the global table (≙ IntermediateGroup)
     for (uint32_t s = tid; s < S; s += BLOCK) {
         if (lds[s] == kEmptyKey) continue;
@@ -929,6 +934,93 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
     }
     if (unsupported) atomicOr(A.err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
     if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+}
+
+// ------------------------------------------------------------------ K4: IntermediateGroup over workgroup slabs
+//
+// execution/group_intermediate.go:56-104: the first partial met for a key is kept, later ones are merged with
+// CumulateIntermediate.  Every workgroup of a DIRECT-mode scan left its LDS table (same slot for the same key in
+// every workgroup) in a slab; one thread per slot folds the slabs in workgroup order — no atomics between
+// workgroups, and float sums are reproducible for a given grid.
+__global__ void merge_slabs_kernel(const Program P, const FastArgs F, const GlobalTable G, uint32_t nblocks_total,
+                                   unsigned long long* ngroups) {
+    // thread (x, y): slot x of this 64-slot stripe, workgroup slabs y, y + Y, y + 2Y, ... (Y = blockDim.y chunks
+    // run in parallel and meet in the global row through a handful of atomics)
+    const uint32_t S = F.lds_slots;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const uint32_t Y = blockDim.y * gridDim.y, y = blockIdx.y * blockDim.y + threadIdx.y;
+    const size_t slab_words = (size_t)P.lds_words * S * Y;  // stride between the slabs this thread reads
+    const uint32_t nblocks = y < nblocks_total ? (nblocks_total - y + Y - 1) / Y : 0;
+    const uint64_t* base = F.slabs + (size_t)y * P.lds_words * S + s;
+    bool touched = false;
+    for (uint32_t b = 0; b < nblocks; b++) touched |= base[b * slab_words] != kEmptyKey;
+    if (!touched) return;
+    long long g = global_find_or_insert(G, fast_slot_key(F, s), F.err_flags, ngroups);
+    if (g < 0) return;
+    uint64_t* grow = &G.acc[(size_t)g * P.glob_words];
+    for (uint32_t a = 0; a < P.naggs; a++) {
+        const AggSpec& ag = P.aggs[a];
+        if (ag.distinct) continue;
+        const uint64_t* l = base + (size_t)ag.lds_off * S;  // word i of workgroup b at l[b * slab_words + i * S]
+        unsigned long long* w = (unsigned long long*)(grow + ag.glob_off);
+        switch (ag.kind) {
+            case AGG_COUNT:
+            case AGG_COUNTN: {
+                unsigned long long c = 0;
+                for (uint32_t b = 0; b < nblocks; b++) c += l[b * slab_words];
+                if (c) atomicAdd(&w[0], c);
+                break;
+            }
+            case AGG_SUM:
+            case AGG_AVG: {
+                unsigned long long lo = 0, hi = 0, fl = 0, n = 0;
+                double fs = 0.0;
+                for (uint32_t b = 0; b < nblocks; b++) {
+                    const uint64_t* lb = l + b * slab_words;
+                    uint64_t f = lb[2 * (size_t)S];
+                    if (!f) continue;
+                    fl |= f;
+                    if (f & (SF_NONNEG_INT | SF_NEG_INT)) {
+                        int64_t x = (int64_t)lb[0];
+                        lo += (unsigned long long)(uint32_t)x;
+                        hi += (unsigned long long)(x >> 32);
+                    }
+                    if (f & SF_FLOAT) fs += as_f64(lb[(size_t)S]);
+                    if (ag.kind == AGG_AVG) n += lb[3 * (size_t)S];
+                }
+                if (!fl) break;
+                if (fl & (SF_NONNEG_INT | SF_NEG_INT)) { atomicAdd(&w[0], lo); atomicAdd(&w[1], hi); }
+                if (fl & SF_FLOAT) atomicAdd((double*)&w[2], fs);
+                atomicOr(&w[3], fl);
+                if (ag.kind == AGG_AVG) atomicAdd(&w[4], n);
+                break;
+            }
+            default: {
+                bool mn = ag.kind == AGG_MIN;
+                unsigned long long fl = 0;
+                long long iv = mn ? INT64_MAX : INT64_MIN;
+                unsigned long long fv = mn ? ~0ull : 0ull, sv = mn ? ~0ull : 0ull;
+                for (uint32_t b = 0; b < nblocks; b++) {
+                    const uint64_t* lb = l + b * slab_words;
+                    uint64_t f = lb[0];
+                    if (!f) continue;
+                    fl |= f;
+                    long long x = (long long)lb[(size_t)S];
+                    unsigned long long y = lb[2 * (size_t)S], z = lb[3 * (size_t)S];
+                    if (f & MM_INT) iv = mn ? (x < iv ? x : iv) : (x > iv ? x : iv);
+                    if (f & MM_FLOAT) fv = mn ? (y < fv ? y : fv) : (y > fv ? y : fv);
+                    if (f & MM_STRING) sv = mn ? (z < sv ? z : sv) : (z > sv ? z : sv);
+                }
+                if (!fl) break;
+                atomicOr(&w[0], fl);
+                if (fl & MM_INT) { if (mn) atomicMin((long long*)&w[1], iv); else atomicMax((long long*)&w[1], iv); }
+                if (fl & MM_FLOAT) { if (mn) atomicMin(&w[2], fv); else atomicMax(&w[2], fv); }
+                if (fl & MM_STRING) { if (mn) atomicMin(&w[3], sv); else atomicMax(&w[3], sv); }
+                break;
+            }
+        }
+    }
 }
 
 // grow the global table: re-insert every occupied slot (keys keep their packed form)
@@ -1263,6 +1355,14 @@ hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTab
     }
     if (rows_per_lane == 2) return launch_fast_variant<2, 1024>(P, F, G, ngroups, grid, shmem, st);
     return launch_fast_variant<4, 1024>(P, F, G, ngroups, grid, shmem, st);
+}
+
+hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalTable& G, uint32_t nblocks,
+                              unsigned long long* ngroups, hipStream_t st) {
+    uint32_t blocks = (F.lds_slots + 63) / 64;
+    uint32_t ychunks = nblocks >= 512 ? 4 : (nblocks >= 128 ? 2 : 1);  // 16 * ychunks parallel chunks of workgroups
+    hipLaunchKernelGGL(merge_slabs_kernel, dim3(blocks, ychunks), dim3(64, 16), 0, st, P, F, G, nblocks, ngroups);
+    return hipGetLastError();
 }
 
 hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, hipStream_t st) {

@@ -225,6 +225,12 @@ __global__ __launch_bounds__(BLOCK) void scan_spec_kernel(const Program P, const
     if ((tid & 63) == 0 && selected) atomicAdd(F.rows_selected, (unsigned long long)selected);
 
     __syncthreads();
+    if (F.slabs) {
+        // hand the workgroup's partial groups to merge_slabs_kernel: plain coalesced stores, no atomics
+        uint64_t* slab = F.slabs + (size_t)blockIdx.x * P.lds_words * S;
+        for (uint32_t i = tid; i < P.lds_words * S; i += BLOCK) slab[i] = lds[i];
+        return;
+    }
     // K4: merge this workgroup's partial groups into the global table (≙ IntermediateGroup)
     for (uint32_t s = tid; s < S; s += BLOCK) {
         if (lds[s] == kEmptyKey) continue;

@@ -185,6 +185,7 @@ struct FastArgs {
     uint32_t pad;
     uint32_t* err_flags;
     unsigned long long* rows_selected;
+    uint64_t* slabs;  // when non-null: workgroup b stores its LDS table at slabs[b * lds_words * S ..] instead of merging
 };
 
 struct PartArgs {

@@ -43,21 +43,18 @@ def main():
         c2 = ("(50 < %s)" % D("price"), [D("cat")], ["sum(%s)" % D("price")])
         allaggs = sorted(["count(*)", "sum(%s)" % D("price"), "avg(%s)" % D("price"), "min(%s)" % D("price"), "max(%s)" % D("price")])
         variants = []
-        for block in (1024, 512):
-            for wide in (1, 0):
-                variants.append(("config2 spec b%d wide%d" % (block, wide), c2[0], c2[1], c2[2], {"block": block, "wide": wide}, False))
-        for grid in (256, 512, 768, 1024, 2048):
-            variants.append(("config2 spec b1024 g%d" % grid, c2[0], c2[1], c2[2], {"grid_blocks": grid}, False))
-            variants.append(("config2 spec b512 g%d" % grid, c2[0], c2[1], c2[2], {"block": 512, "grid_blocks": grid}, False))
+        for slabs in (1, 0):
+            for block, grid in ((1024, 256), (1024, 512), (512, 512), (512, 768), (512, 1024)):
+                variants.append(("config2 spec b%d g%d slabs%d" % (block, grid, slabs), c2[0], c2[1], c2[2],
+                                 {"block": block, "grid_blocks": grid, "slabs": slabs}, False))
         variants += [
             ("config2 fast(no spec)", c2[0], c2[1], c2[2], {"spec": 0}, False),
             ("config2 interp direct", c2[0], c2[1], c2[2], {"fast": 0}, False),
-            ("config2 interp hash", c2[0], c2[1], c2[2], {"fast": 0, "agg_mode": 1}, False),
             ("nofilter sum", None, [D("cat")], ["sum(%s)" % D("price")], {}, False),
             ("nofilter count*", None, [D("cat")], ["count(*)"], {}, False),
             ("filter nokey count*", c2[0], [], ["count(*)"], {}, False),
             ("allaggs spec", c2[0], [D("cat")], allaggs, {}, False),
-            ("allaggs fast", c2[0], [D("cat")], allaggs, {"spec": 0}, False),
+            ("allaggs spec noslab", c2[0], [D("cat")], allaggs, {"slabs": 0}, False),
         ]
         for name, cond, keys, aggs, opts, fo in variants:
             ms, wall, ng = run(cols, rows, kcat, cond, keys, aggs, opts, filter_only=fo)
