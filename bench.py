@@ -191,7 +191,8 @@ def main():
                    "agg_mode": st["agg_mode"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "scan_group_kernel", "kernel_ms": scan_ms,
+                     "kernel": ("scan_spec_kernel(+merge_slabs_kernel)" if st.get("spec_kernel") else "scan_fast/scan_group_kernel"),
+                     "kernel_ms": scan_ms,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
     if not args.no_cpu:

@@ -148,7 +148,7 @@ typedef struct n1k_stats {
     double device_ms;       /* hipEvent time of all device work (≙ execTime) */
     uint64_t bytes_scanned; /* algorithmic column bytes read by the scan kernel */
     uint32_t agg_mode;      /* n1k_agg_mode actually used by the last batch */
-    uint32_t reserved;
+    uint32_t spec_kernel;   /* 1: a plan-specialised kernel ran the last batch */
 } n1k_stats;
 
 typedef enum n1k_agg_mode {

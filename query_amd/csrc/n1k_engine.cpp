@@ -610,7 +610,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         if (e0) (void)hipEventRecord(e0, h->stream);
         // a prebuilt plan-specialised kernel of exactly this shape?
         const SpecEntry* spec = h->opt_spec ? find_spec(h, F) : nullptr;
-        h->stats.reserved = spec ? 1u : 0u;
+        h->stats.spec_kernel = spec ? 1u : 0u;
         const uint64_t chunk = 1ull << 31;  // 32-bit row indices inside one launch
         for (uint64_t off = 0; off < b->nrows; off += chunk) {
             uint64_t n = std::min<uint64_t>(chunk, b->nrows - off);

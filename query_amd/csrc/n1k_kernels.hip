@@ -942,77 +942,123 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
 // CumulateIntermediate.  Every workgroup of a DIRECT-mode scan left its LDS table (same slot for the same key in
 // every workgroup) in a slab; one thread per slot folds the slabs in workgroup order — no atomics between
 // workgroups, and float sums are reproducible for a given grid.
-__global__ void merge_slabs_kernel(const Program P, const FastArgs F, const GlobalTable G, uint32_t nblocks_total,
-                                   unsigned long long* ngroups) {
-    // thread (x, y): slot x of this 64-slot stripe, workgroup slabs y, y + Y, y + 2Y, ... (Y = blockDim.y chunks
-    // run in parallel and meet in the global row through a handful of atomics)
+enum { RED_ADD_U64, RED_ADD_F64, RED_OR, RED_MIN_I64, RED_MAX_I64, RED_MIN_U64, RED_MAX_U64 };
+
+// reduce one 64-bit value over threadIdx.y (16 rows) for every threadIdx.x column; all threads of the block call it
+template <int OP>
+N1K_DEV uint64_t reduce_over_y(uint64_t (*red)[64], uint64_t v) {
+    const uint32_t tx = threadIdx.x, ty = threadIdx.y;
+    red[ty][tx] = v;
+    __syncthreads();
+    for (uint32_t off = 8; off > 0; off >>= 1) {
+        if (ty < off) {
+            uint64_t a = red[ty][tx], b = red[ty + off][tx], r;
+            if (OP == RED_ADD_U64) r = a + b;
+            else if (OP == RED_ADD_F64) r = f64_bits(as_f64(a) + as_f64(b));
+            else if (OP == RED_OR) r = a | b;
+            else if (OP == RED_MIN_I64) r = (int64_t)a < (int64_t)b ? a : b;
+            else if (OP == RED_MAX_I64) r = (int64_t)a > (int64_t)b ? a : b;
+            else if (OP == RED_MIN_U64) r = a < b ? a : b;
+            else r = a > b ? a : b;
+            red[ty][tx] = r;
+        }
+        __syncthreads();
+    }
+    uint64_t out = red[0][tx];
+    __syncthreads();
+    return out;
+}
+
+__global__ __launch_bounds__(1024) void merge_slabs_kernel(const Program P, const FastArgs F, const GlobalTable G,
+                                                          uint32_t nblocks_total, unsigned long long* ngroups) {
+    // block = 64 slots (x) x 16 chunks (y); thread (x, y) folds workgroup slabs y', y' + Y, ... (y' = its global chunk,
+    // Y = 16 * gridDim.y chunks) with unconditional, unrolled loads; the 16 chunks of a block meet through an LDS tree
+    // and thread y == 0 applies the result to the global row (a handful of atomics per slot and block row).
+    __shared__ uint64_t red[16][64];
     const uint32_t S = F.lds_slots;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const uint32_t Y = blockDim.y * gridDim.y, y = blockIdx.y * blockDim.y + threadIdx.y;
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = s < S;
+    const uint32_t Y = 16 * gridDim.y, y = blockIdx.y * 16 + threadIdx.y;
     const size_t slab_words = (size_t)P.lds_words * S * Y;  // stride between the slabs this thread reads
-    const uint32_t nblocks = y < nblocks_total ? (nblocks_total - y + Y - 1) / Y : 0;
-    const uint64_t* base = F.slabs + (size_t)y * P.lds_words * S + s;
-    bool touched = false;
-    for (uint32_t b = 0; b < nblocks; b++) touched |= base[b * slab_words] != kEmptyKey;
-    if (!touched) return;
-    long long g = global_find_or_insert(G, fast_slot_key(F, s), F.err_flags, ngroups);
-    if (g < 0) return;
-    uint64_t* grow = &G.acc[(size_t)g * P.glob_words];
+    const uint32_t nblocks = (in_range && y < nblocks_total) ? (nblocks_total - y + Y - 1) / Y : 0;
+    const uint64_t* base = F.slabs + (size_t)y * P.lds_words * S + (in_range ? s : 0);
+    uint64_t touched = 0;
+#pragma unroll 8
+    for (uint32_t b = 0; b < nblocks; b++) touched |= base[b * slab_words] ^ kEmptyKey;
+    touched = reduce_over_y<RED_OR>(red, touched);
+    const bool leader = threadIdx.y == 0 && in_range && touched != 0;
+    long long g = -1;
+    if (leader) g = global_find_or_insert(G, fast_slot_key(F, s), F.err_flags, ngroups);
+    uint64_t* grow = g >= 0 ? &G.acc[(size_t)g * P.glob_words] : nullptr;
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
         if (ag.distinct) continue;
         const uint64_t* l = base + (size_t)ag.lds_off * S;  // word i of workgroup b at l[b * slab_words + i * S]
-        unsigned long long* w = (unsigned long long*)(grow + ag.glob_off);
+        unsigned long long* w = grow ? (unsigned long long*)(grow + ag.glob_off) : nullptr;
         switch (ag.kind) {
             case AGG_COUNT:
             case AGG_COUNTN: {
                 unsigned long long c = 0;
+#pragma unroll 8
                 for (uint32_t b = 0; b < nblocks; b++) c += l[b * slab_words];
-                if (c) atomicAdd(&w[0], c);
+                c = reduce_over_y<RED_ADD_U64>(red, c);
+                if (w && c) atomicAdd(&w[0], c);
                 break;
             }
             case AGG_SUM:
             case AGG_AVG: {
                 unsigned long long lo = 0, hi = 0, fl = 0, n = 0;
                 double fs = 0.0;
+                const bool avg = ag.kind == AGG_AVG;
+#pragma unroll 4
                 for (uint32_t b = 0; b < nblocks; b++) {
                     const uint64_t* lb = l + b * slab_words;
-                    uint64_t f = lb[2 * (size_t)S];
-                    if (!f) continue;
-                    fl |= f;
-                    if (f & (SF_NONNEG_INT | SF_NEG_INT)) {
-                        int64_t x = (int64_t)lb[0];
-                        lo += (unsigned long long)(uint32_t)x;
-                        hi += (unsigned long long)(x >> 32);
-                    }
-                    if (f & SF_FLOAT) fs += as_f64(lb[(size_t)S]);
-                    if (ag.kind == AGG_AVG) n += lb[3 * (size_t)S];
+                    int64_t x = (int64_t)lb[0];        // 0 when no int was added
+                    double f = as_f64(lb[(size_t)S]);  // +0.0 when no float was added
+                    fl |= lb[2 * (size_t)S];
+                    lo += (unsigned long long)(uint32_t)x;
+                    hi += (unsigned long long)(x >> 32);
+                    fs += f;
+                    if (avg) n += lb[3 * (size_t)S];
                 }
-                if (!fl) break;
+                lo = reduce_over_y<RED_ADD_U64>(red, lo);
+                hi = reduce_over_y<RED_ADD_U64>(red, hi);
+                fs = as_f64(reduce_over_y<RED_ADD_F64>(red, f64_bits(fs)));
+                fl = reduce_over_y<RED_OR>(red, fl);
+                if (avg) n = reduce_over_y<RED_ADD_U64>(red, n);
+                if (!w || !fl) break;
                 if (fl & (SF_NONNEG_INT | SF_NEG_INT)) { atomicAdd(&w[0], lo); atomicAdd(&w[1], hi); }
                 if (fl & SF_FLOAT) atomicAdd((double*)&w[2], fs);
                 atomicOr(&w[3], fl);
-                if (ag.kind == AGG_AVG) atomicAdd(&w[4], n);
+                if (avg) atomicAdd(&w[4], n);
                 break;
             }
             default: {
-                bool mn = ag.kind == AGG_MIN;
+                const bool mn = ag.kind == AGG_MIN;
                 unsigned long long fl = 0;
                 long long iv = mn ? INT64_MAX : INT64_MIN;
                 unsigned long long fv = mn ? ~0ull : 0ull, sv = mn ? ~0ull : 0ull;
+#pragma unroll 4
                 for (uint32_t b = 0; b < nblocks; b++) {
                     const uint64_t* lb = l + b * slab_words;
-                    uint64_t f = lb[0];
-                    if (!f) continue;
-                    fl |= f;
-                    long long x = (long long)lb[(size_t)S];
-                    unsigned long long y = lb[2 * (size_t)S], z = lb[3 * (size_t)S];
-                    if (f & MM_INT) iv = mn ? (x < iv ? x : iv) : (x > iv ? x : iv);
-                    if (f & MM_FLOAT) fv = mn ? (y < fv ? y : fv) : (y > fv ? y : fv);
-                    if (f & MM_STRING) sv = mn ? (z < sv ? z : sv) : (z > sv ? z : sv);
+                    fl |= lb[0];
+                    long long x = (long long)lb[(size_t)S];  // identities of untouched slabs never win
+                    unsigned long long yv = lb[2 * (size_t)S], z = lb[3 * (size_t)S];
+                    iv = mn ? (x < iv ? x : iv) : (x > iv ? x : iv);
+                    fv = mn ? (yv < fv ? yv : fv) : (yv > fv ? yv : fv);
+                    sv = mn ? (z < sv ? z : sv) : (z > sv ? z : sv);
                 }
-                if (!fl) break;
+                fl = reduce_over_y<RED_OR>(red, fl);
+                if (mn) {
+                    iv = (long long)reduce_over_y<RED_MIN_I64>(red, (uint64_t)iv);
+                    fv = reduce_over_y<RED_MIN_U64>(red, fv);
+                    sv = reduce_over_y<RED_MIN_U64>(red, sv);
+                } else {
+                    iv = (long long)reduce_over_y<RED_MAX_I64>(red, (uint64_t)iv);
+                    fv = reduce_over_y<RED_MAX_U64>(red, fv);
+                    sv = reduce_over_y<RED_MAX_U64>(red, sv);
+                }
+                if (!w || !fl) break;
                 atomicOr(&w[0], fl);
                 if (fl & MM_INT) { if (mn) atomicMin((long long*)&w[1], iv); else atomicMax((long long*)&w[1], iv); }
                 if (fl & MM_FLOAT) { if (mn) atomicMin(&w[2], fv); else atomicMax(&w[2], fv); }

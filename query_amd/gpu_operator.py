@@ -237,7 +237,7 @@ class GpuFilterGroup:
     def stats(self) -> dict:
         s = _ffi.Stats()
         self._check(self._lib.n1k_get_stats(self._h, C.byref(s)))
-        return {f[0]: getattr(s, f[0]) for f in _ffi.Stats._fields_ if f[0] != "reserved"}
+        return {f[0]: getattr(s, f[0]) for f in _ffi.Stats._fields_}
 
     # ----------------------------------------------------------------- life cycle
     def reopen(self):
