@@ -49,6 +49,12 @@ def workloads():
                             "max(%s)" % D("price")]),
             "bytes_per_row": 13,
         },
+        "config3": {
+            "sql": "SELECT cat, COUNT(DISTINCT user_id), AVG(price) FROM default GROUP BY cat",
+            "cond": None, "keys": [D("cat")],
+            "aggs": sorted(["count(distinct %s)" % D("user_id"), "avg(%s)" % D("price")]),
+            "bytes_per_row": 22,
+        },
         "config5_keys": {
             "sql": "SELECT cat, region_id, SUM(price) FROM default GROUP BY cat, region_id",
             "cond": None, "keys": [D("cat"), D("region_id")], "aggs": ["sum(%s)" % D("price")],
@@ -119,6 +125,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rows"],
+                    help="multi-GPU: what crosses xGMI (auto = partial groups unless the plan has DISTINCT)")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +142,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the device path has no CPU fallback")
     torch.cuda.set_device(local_rank)
 
-    if world > 1:
+    if world > 1 or args.force_dist:
         from query_amd import distributed as qd
         return qd.bench_main(args, rank, world, local_rank)
 

@@ -271,10 +271,26 @@ n1k_status n1k_partition_device_batch(n1k_handle *h, const n1k_batch *batch, uin
                                       uint64_t capacity_rows, const n1k_col *out_cols, uint64_t *out_counts);
 
 /*
- * ≙ CumulateIntermediate over another handle's/rank's groups
- * (execution/group_intermediate.go:91-101): merge an exported group table into
- * this handle.  `blob` is what n1k_export_groups produced (host memory).
+ * Partial groups (the reference's Initial -> Intermediate hand-over, algebra/aggregate.go:25-40).
+ *
+ * n1k_export_partials_device: write every group of the handle (packed key + raw accumulators) into `nparts`
+ * regions of `out` (device memory) by hash(group key) % nparts — the same hash as
+ * n1k_partition_device_batch.  Region d (region_bytes = n1k_partial_region_bytes(h, capacity_groups)) is
+ *     [count u64][reserved u64][keys: capacity x u64][accumulators: capacity x n1k_partial_words(h) x u64]
+ * so that ONE all-to-all with equal splits moves all regions.  N1K_OOM when a region overflows.
+ *
+ * n1k_merge_partials_device: ≙ CumulateIntermediate (execution/group_intermediate.go:91-101) over `nregions`
+ * regions of that layout (device memory), e.g. what the all-to-all delivered.  The handle must have the same
+ * plan, column kinds and dictionary as the exporters.  DISTINCT aggregates cannot be merged this way
+ * (N1K_UNSUPPORTED): their sets would have to travel; use the row exchange instead.
+ *
+ * n1k_export_groups / n1k_merge_groups: the same through a host blob (one region), for merging operator copies
+ * inside one process.
  */
+uint32_t n1k_partial_words(const n1k_handle *h);
+uint64_t n1k_partial_region_bytes(const n1k_handle *h, uint64_t capacity_groups);
+n1k_status n1k_export_partials_device(n1k_handle *h, uint32_t nparts, uint64_t capacity_groups, void *out);
+n1k_status n1k_merge_partials_device(n1k_handle *h, uint32_t nregions, uint64_t capacity_groups, const void *in);
 n1k_status n1k_export_groups(n1k_handle *h, const void **blob, size_t *len);
 n1k_status n1k_merge_groups(n1k_handle *h, const void *blob, size_t len);
 

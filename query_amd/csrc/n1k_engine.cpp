@@ -98,13 +98,19 @@ struct n1k_handle {
     uint32_t col_kinds[kMaxCols]{};
     std::vector<std::string> agg_names;
     bool has_distinct = false;
+    uint32_t n_distinct = 0;
+    DevBuf<uint64_t> d_log_key[kMaxDistinct], d_log_val[kMaxDistinct], d_regions, d_set_table;
+    DevBuf<uint8_t> d_log_cls[kMaxDistinct];
+    uint64_t log_capacity = 0;
 
     // device state
     GlobalTable table{};
     DevBuf<uint64_t> d_keys, d_acc, d_rep, d_slabs;
     DevBuf<uint32_t> d_err;
-    DevBuf<unsigned long long> d_counters;  // [0] rows_selected [1] ngroups [2] out_count [3] filter total
+    DevBuf<unsigned long long> d_counters;  // [0] rows_selected [1] ngroups [2] out_count [3] filter total [4] rehash scratch
+                                            // [5] distinct region words [8..11] pair-log cursors
     uint64_t row_base = 0;
+    uint64_t merged_groups_bound = 0;  // groups that may have arrived through merges (bounds the table like rows do)
 
     // staging for host batches
     std::vector<DevBuf<uint8_t>> st_tags;
@@ -292,8 +298,20 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
         s.lds_off = lds_w;
         s.glob_off = glob_w;
         if (d.distinct) {
+            if (d.kind != AGG_COUNT && d.kind != AGG_COUNTN) {
+                err.unsupported = true;
+                err.msg = "SUM/AVG(DISTINCT) are not on the device path yet";
+                return false;
+            }
+            if (h->n_distinct >= kMaxDistinct) {
+                err.unsupported = true;
+                err.msg = "more than 4 DISTINCT aggregates";
+                return false;
+            }
             h->has_distinct = true;
-            glob_w += 1;
+            s.log_index = h->n_distinct++;
+            lds_w += kLdsWordsDistinct;
+            glob_w += kGlobWordsDistinct;
         } else if (d.kind == AGG_COUNT || d.kind == AGG_COUNTN) {
             lds_w += 1;
             glob_w += 1;
@@ -308,11 +326,6 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
             lds_w += kWordsMinMax;
             glob_w += kWordsMinMax;
         }
-    }
-    if (h->has_distinct) {
-        err.unsupported = true;
-        err.msg = "DISTINCT aggregates are not on the device path yet";
-        return false;
     }
     P.lds_words = lds_w;
     P.glob_words = glob_w ? glob_w : 1;
@@ -342,9 +355,9 @@ n1k_status ensure_device(n1k_handle* h) {
         h->own_stream = true;
     }
     HIP_TRY(h, h->d_err.ensure(4));
-    HIP_TRY(h, h->d_counters.ensure(8));
+    HIP_TRY(h, h->d_counters.ensure(16));
     HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4 * sizeof(uint32_t), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 8 * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
     h->device_ready = true;
     return N1K_OK;
 }
@@ -420,7 +433,7 @@ n1k_status alloc_table(n1k_handle* h, uint64_t capacity, GlobalTable& t, DevBuf<
 // Make sure the global table can take `incoming_rows` more rows worth of new groups (bounded by max_groups).
 n1k_status ensure_table(n1k_handle* h, uint64_t incoming_rows) {
     // groups <= rows pushed so far: an upper bound that needs no device round trip
-    uint64_t want_groups = std::min<uint64_t>(h->opt_max_groups, h->row_base + incoming_rows);
+    uint64_t want_groups = std::min<uint64_t>(h->opt_max_groups, h->row_base + h->merged_groups_bound + incoming_rows);
     if (h->prog.nkeys == 0) want_groups = 1;
     else {
         // all keys dictionary coded: the key domain bounds the number of groups (|dict| + MISSING + NULL per key)
@@ -586,6 +599,40 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     ScanArgs A{};
     A.nrows = b->nrows;
     A.row_base = h->row_base;
+    if (h->has_distinct) {
+        // every qualifying operand appends one (group key, value, class) pair: at most one per row and aggregate
+        uint64_t need = h->row_base + b->nrows;
+        if (need > h->log_capacity) {
+            uint64_t cap = std::max<uint64_t>(need, h->log_capacity * 2);
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            for (uint32_t d = 0; d < h->n_distinct; d++) {
+                DevBuf<uint64_t> nk, nv;
+                DevBuf<uint8_t> nc;
+                HIP_TRY(h, nk.ensure(cap));
+                HIP_TRY(h, nv.ensure(cap));
+                HIP_TRY(h, nc.ensure(cap));
+                if (h->log_capacity) {
+                    HIP_TRY(h, hipMemcpy(nk.p, h->d_log_key[d].p, h->log_capacity * 8, hipMemcpyDeviceToDevice));
+                    HIP_TRY(h, hipMemcpy(nv.p, h->d_log_val[d].p, h->log_capacity * 8, hipMemcpyDeviceToDevice));
+                    HIP_TRY(h, hipMemcpy(nc.p, h->d_log_cls[d].p, h->log_capacity, hipMemcpyDeviceToDevice));
+                }
+                h->d_log_key[d].release();
+                h->d_log_val[d].release();
+                h->d_log_cls[d].release();
+                h->d_log_key[d] = nk;
+                h->d_log_val[d] = nv;
+                h->d_log_cls[d] = nc;
+            }
+            h->log_capacity = cap;
+        }
+        for (uint32_t d = 0; d < h->n_distinct; d++) {
+            A.log_key[d] = h->d_log_key[d].p;
+            A.log_val[d] = h->d_log_val[d].p;
+            A.log_cls[d] = h->d_log_cls[d].p;
+        }
+        A.log_cursor = h->d_counters.p + 8;
+        A.log_capacity = h->log_capacity;
+    }
     uint32_t block = h->opt_block ? h->opt_block : 1024;
     uint32_t rpl = block == 1024 ? h->opt_rows_per_lane : 4;
     uint32_t max_slots = h->opt_lds_bytes / (P.lds_words * 8);
@@ -825,6 +872,13 @@ void n1k_destroy(n1k_handle* h) {
         h->d_acc.release();
         h->d_rep.release();
         h->d_slabs.release();
+        h->d_regions.release();
+        h->d_set_table.release();
+        for (uint32_t d = 0; d < kMaxDistinct; d++) {
+            h->d_log_key[d].release();
+            h->d_log_val[d].release();
+            h->d_log_cls[d].release();
+        }
         h->d_err.release();
         h->d_counters.release();
         for (auto& b : h->st_tags) b.release();
@@ -847,6 +901,7 @@ n1k_status n1k_reset(n1k_handle* h) {
     if (!h) return N1K_INVALID;
     h->stop_flag.store(0);
     h->row_base = 0;
+    h->merged_groups_bound = 0;
     h->selected.clear();
     h->r_keys.clear();
     h->r_aggs.clear();
@@ -859,7 +914,7 @@ n1k_status n1k_reset(n1k_handle* h) {
         drain_events(h);
         h->stats.device_ms = 0;
         HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4 * sizeof(uint32_t), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 8 * sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->stream));
     }
     return N1K_OK;
@@ -932,6 +987,7 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         PlanError err;
         h->agg_names.clear();
         h->has_distinct = false;
+        h->n_distinct = 0;
         if (!compile_plan(h, err)) return fail(h, N1K_INVALID, "%s", err.msg.c_str());
     } else
         return fail(h, N1K_INVALID, "unknown option %s", name);
@@ -1001,7 +1057,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     out->nkeys = nk;
     out->naggs = na;
     uint32_t err_flags = 0;
-    unsigned long long counters[8] = {0};
+    unsigned long long counters[16] = {0};
     if (h->device_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
@@ -1027,6 +1083,32 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     h->r_aggs.clear();
     h->r_parts.clear();
     h->r_rep.clear();
+    if (ng > 0 && h->has_distinct) {
+        // K6: de-duplicate the logged (group, value) pairs of every DISTINCT aggregate (≙ Set.Len(), value/set.go:198-215)
+        for (uint32_t a = 0; a < na; a++) {
+            const AggSpec& ag = h->prog.aggs[a];
+            if (!ag.distinct) continue;
+            uint64_t npairs = counters[8 + ag.log_index];
+            DistinctArgs D{};
+            D.log_key = h->d_log_key[ag.log_index].p;
+            D.log_val = h->d_log_val[ag.log_index].p;
+            D.log_cls = h->d_log_cls[ag.log_index].p;
+            D.npairs = npairs;
+            D.glob_off = ag.glob_off;
+            D.total_words = h->d_counters.p + 5;
+            HIP_TRY(h, h->d_regions.ensure(h->table.capacity * 6));
+            D.regions = h->d_regions.p;
+            HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 5, 0, sizeof(unsigned long long), h->stream));
+            HIP_TRY(h, launch_distinct_layout(h->prog, h->table, D, h->stream));
+            unsigned long long words = 0;
+            HIP_TRY(h, hipMemcpyAsync(&words, h->d_counters.p + 5, sizeof words, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, h->d_set_table.ensure(std::max<uint64_t>(words, 1)));
+            D.set_table = h->d_set_table.p;
+            if (words) HIP_TRY(h, hipMemsetAsync(h->d_set_table.p, 0xFF, words * 8, h->stream));
+            HIP_TRY(h, launch_distinct_insert(h->prog, h->table, D, h->d_err.p, h->stream));
+        }
+    }
     if (ng > 0) {
         HIP_TRY(h, h->d_okeys.ensure(ng * std::max(nk, 1u)));
         HIP_TRY(h, h->d_oaggs.ensure(ng * std::max(na, 1u)));
@@ -1150,16 +1232,97 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
     return N1K_OK;
 }
 
+uint32_t n1k_partial_words(const n1k_handle* h) { return h ? h->prog.glob_words : 0; }
+
+uint64_t n1k_partial_region_bytes(const n1k_handle* h, uint64_t capacity_groups) {
+    if (!h) return 0;
+    return 8ull * (2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words));
+}
+
+n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
+    if (!h || !out || nparts == 0 || capacity_groups == 0) return N1K_INVALID;
+    if (!h->plan.has_group) return fail(h, N1K_INVALID, "no groups in a Filter-only plan");
+    if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    uint64_t region_words = 2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words);
+    for (uint32_t d = 0; d < nparts; d++)
+        HIP_TRY(h, hipMemsetAsync((char*)out + (size_t)d * region_words * 8, 0, 16, h->stream));
+    if (h->table.capacity)
+        HIP_TRY(h, launch_export_partials(h->prog, h->table, nparts, capacity_groups, (uint64_t*)out, region_words,
+                                          h->d_err.p, h->stream));
+    uint32_t err_flags = 0;
+    HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (err_flags & ERR_TABLE_FULL) {
+        HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4, h->stream));
+        return fail(h, N1K_OOM, "more than %llu groups for one destination: raise the region capacity",
+                    (unsigned long long)capacity_groups);
+    }
+    return N1K_OK;
+}
+
+n1k_status n1k_merge_partials_device(n1k_handle* h, uint32_t nregions, uint64_t capacity_groups, const void* in) {
+    if (!h || !in || nregions == 0 || capacity_groups == 0) return N1K_INVALID;
+    if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
+    if (!h->layout_fixed) return fail(h, N1K_INVALID, "merge needs the key layout: push a batch (even an empty one) first");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    // the incoming groups bound the growth of the table
+    uint64_t saved = h->row_base;
+    h->row_base += (uint64_t)nregions * capacity_groups;
+    st = ensure_table(h, 0);
+    h->row_base = saved;
+    if (st != N1K_OK) return st;
+    uint64_t region_words = 2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words);
+    HIP_TRY(h, launch_merge_partials(h->prog, h->table, nregions, capacity_groups, (const uint64_t*)in, region_words,
+                                     h->d_err.p, h->d_counters.p + 1, h->stream));
+    h->merged_groups_bound += (uint64_t)nregions * capacity_groups;
+    return N1K_OK;
+}
+
 n1k_status n1k_export_groups(n1k_handle* h, const void** blob, size_t* len) {
-    if (!h) return N1K_INVALID;
-    (void)blob; (void)len;
-    return fail(h, N1K_UNSUPPORTED, "export not built yet");
+    if (!h || !blob || !len) return N1K_INVALID;
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    unsigned long long ng = 0;
+    HIP_TRY(h, hipMemcpyAsync(&ng, h->d_counters.p + 1, sizeof ng, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    uint64_t cap = std::max<uint64_t>(ng, 1);
+    uint64_t bytes = n1k_partial_region_bytes(h, cap);
+    DevBuf<uint64_t> tmp;
+    HIP_TRY(h, tmp.ensure(bytes / 8));
+    st = n1k_export_partials_device(h, 1, cap, tmp.p);
+    if (st == N1K_OK) {
+        h->export_blob.resize(bytes + 16);
+        uint64_t hdr[2] = {0x4e314b5041525431ull /* "N1KPART1" */, cap};
+        memcpy(h->export_blob.data(), hdr, 16);
+        hipError_t e = hipMemcpy(h->export_blob.data() + 16, tmp.p, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(h, N1K_DEVICE_ERROR, "copy of exported groups failed: %s", hipGetErrorString(e));
+    }
+    tmp.release();
+    if (st != N1K_OK) return st;
+    *blob = h->export_blob.data();
+    *len = h->export_blob.size();
+    return N1K_OK;
 }
 
 n1k_status n1k_merge_groups(n1k_handle* h, const void* blob, size_t len) {
-    if (!h) return N1K_INVALID;
-    (void)blob; (void)len;
-    return fail(h, N1K_UNSUPPORTED, "merge not built yet");
+    if (!h || !blob || len < 32) return N1K_INVALID;
+    uint64_t hdr[2];
+    memcpy(hdr, blob, 16);
+    if (hdr[0] != 0x4e314b5041525431ull) return fail(h, N1K_INVALID, "not an exported group blob");
+    uint64_t cap = hdr[1];
+    if (n1k_partial_region_bytes(h, cap) + 16 != len) return fail(h, N1K_INVALID, "blob does not match this plan");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    DevBuf<uint64_t> tmp;
+    HIP_TRY(h, tmp.ensure((len - 16) / 8));
+    HIP_TRY(h, hipMemcpy(tmp.p, (const char*)blob + 16, len - 16, hipMemcpyHostToDevice));
+    st = n1k_merge_partials_device(h, 1, cap, tmp.p);
+    if (st == N1K_OK) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    tmp.release();
+    return st;
 }
 
 n1k_status n1k_synth_columns(int device, void* stream, const n1k_synth_spec* spec, uint32_t* cat_codes, uint8_t* price_tags,

@@ -265,8 +265,12 @@ N1K_DEV void lds_table_init(const Program& P, uint64_t* lds, uint32_t S, uint32_
         for (uint32_t s = tid; s < S; s += BLOCK) lds[(size_t)P.rep_lds_word * S + s] = ~0ull;
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
-        if (ag.distinct) continue;
         uint64_t* w = lds + (size_t)ag.lds_off * S;
+        if (ag.distinct) {
+            for (uint32_t i = 0; i < kLdsWordsDistinct; i++)
+                for (uint32_t s = tid; s < S; s += BLOCK) w[(size_t)i * S + s] = 0;
+            continue;
+        }
         uint32_t nw = (ag.kind == AGG_COUNT || ag.kind == AGG_COUNTN) ? 1u : (ag.kind == AGG_SUM ? kLdsWordsSum : (ag.kind == AGG_AVG ? kLdsWordsAvg : kWordsMinMax));
         for (uint32_t i = 0; i < nw; i++) {
             uint64_t ident = 0;
@@ -281,7 +285,7 @@ __device__ __forceinline__ void glob_row_init(const Program& P, uint64_t* g) {
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
         uint64_t* w = g + ag.glob_off;
-        if (ag.distinct) { w[0] = 0; continue; }
+        if (ag.distinct) { for (int i = 0; i < (int)kGlobWordsDistinct; i++) w[i] = 0; continue; }
         switch (ag.kind) {
             case AGG_COUNT:
             case AGG_COUNTN: w[0] = 0; break;
@@ -404,9 +408,13 @@ N1K_DEV bool acc_lds(const Program& P, const AggSpec& ag, uint64_t* lds, uint32_
 N1K_DEV void merge_slot(const Program& P, const uint64_t* lds, uint32_t S, uint32_t slot, uint64_t* g) {
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
-        if (ag.distinct) continue;
         const uint64_t* l = lds + (size_t)ag.lds_off * S + slot;  // word i at l[i * S]
         unsigned long long* w = (unsigned long long*)(g + ag.glob_off);
+        if (ag.distinct) {
+            for (uint32_t i = 0; i < kLdsWordsDistinct; i++)
+                if (l[(size_t)i * S]) atomicAdd(&w[1 + i], (unsigned long long)l[(size_t)i * S]);
+            continue;
+        }
         switch (ag.kind) {
             case AGG_COUNT:
             case AGG_COUNTN:
@@ -440,6 +448,100 @@ N1K_DEV void merge_slot(const Program& P, const uint64_t* lds, uint32_t S, uint3
     }
 }
 
+// ------------------------------------------------------------------ K6: DISTINCT sets
+//
+// value.Set (value/set.go:22-110) keeps one hash map per type: ints and integral floats share the int map, other
+// floats their own, strings / arrays / objects are keyed by text (here: dictionary code), booleans by value.
+// CountDistinct adds every operand of type > NULL (algebra/agg_count_distinct.go:84-95), CountnDistinct every
+// NUMBER.  Returns false when the operand does not enter the set.
+N1K_DEV bool distinct_classify(uint32_t kind, uint32_t tag, uint64_t p, uint32_t& cls, uint64_t& val) {
+    if (tag <= T_NULL) return false;
+    if (tag == T_INT) { cls = DC_INT; val = p; return true; }
+    if (tag == T_FLOAT) {
+        double d = as_f64(p);
+        if (is_int_f64(d)) { cls = DC_INT; val = (uint64_t)go_f2i(d); }
+        else { cls = DC_FLOAT; val = p; }
+        return true;
+    }
+    if (kind != AGG_COUNT) return false;  // COUNTN / SUM / AVG (DISTINCT): NUMBER operands only
+    cls = DC_OTHER;
+    val = ((uint64_t)tag << 40) | (p & 0xFFFFFFFFFFull);
+    return true;
+}
+
+// read-only probe of the global table
+N1K_DEV long long global_find(const GlobalTable& G, uint64_t key) {
+    uint64_t mask = G.capacity - 1;
+    uint64_t h = mix64(key) & mask;
+    for (int probe = 0; probe < 8192; probe++) {
+        uint64_t cur = G.keys[h];
+        if (cur == key) return (long long)h;
+        if (cur == kEmptyKey) return -1;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// finish step 1: give every (group, class) of one DISTINCT aggregate an open-addressed region of
+// next_pow2(2 * operands) words inside one big table
+__global__ void distinct_layout_kernel(const Program P, const GlobalTable G, const DistinctArgs D) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.capacity) return;
+    uint64_t* reg = D.regions + s * 6;
+    uint64_t* w = &G.acc[s * P.glob_words + D.glob_off];
+    bool used = G.keys[s] != kEmptyKey;
+    w[0] = 0;  // the set size is recomputed from the whole log at every finish
+    w[4] = 0;
+    for (uint32_t c = 0; c < 3; c++) {
+        uint64_t n = used ? w[1 + c] : 0;
+        uint64_t cap = 0;
+        if (n) {
+            cap = 2;
+            while (cap < 2 * n) cap <<= 1;
+        }
+        uint64_t off = cap ? atomicAdd(D.total_words, (unsigned long long)cap) : 0ull;
+        reg[2 * c] = off;
+        reg[2 * c + 1] = cap ? cap - 1 : 0;
+    }
+}
+
+// finish step 2: insert every logged pair into its group's value set with ONE 64-bit compare-and-swap per probe
+// (the group and the class are implied by the region, so the value alone identifies the member: no multi-word
+// entries, no locks, no spinning).  A first insertion bumps the group's distinct count.
+__global__ void distinct_insert_kernel(const Program P, const GlobalTable G, const DistinctArgs D, uint32_t* err_flags) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.npairs) return;
+    long long g = global_find(G, D.log_key[i]);
+    if (g < 0) {
+        atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+        return;
+    }
+    uint32_t cls = D.log_cls[i];
+    uint64_t val = D.log_val[i];
+    unsigned long long* w = (unsigned long long*)&G.acc[(size_t)g * P.glob_words + D.glob_off];
+    if (val == kEmptyKey) {
+        // the one value that collides with the free marker (int -1): tracked by a flag bit per class
+        unsigned long long bit = 1ull << cls;
+        unsigned long long old = atomicOr(&w[4], bit);
+        if (!(old & bit)) atomicAdd(&w[0], 1ull);
+        return;
+    }
+    const uint64_t* reg = D.regions + (size_t)g * 6 + 2 * cls;
+    uint64_t off = reg[0], mask = reg[1];
+    uint64_t h = mix64(val) & mask;
+    for (uint64_t probe = 0; probe <= mask; probe++) {
+        unsigned long long* slot = (unsigned long long*)&D.set_table[off + h];
+        unsigned long long old = atomicCAS(slot, (unsigned long long)kEmptyKey, (unsigned long long)val);
+        if (old == kEmptyKey) {
+            atomicAdd(&w[0], 1ull);  // Set.Len() grows by one (value/set.go:198-215)
+            return;
+        }
+        if (old == val) return;  // already a member
+        h = (h + 1) & mask;
+    }
+    atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+}
+
 // ------------------------------------------------------------------ K1+K2+K3(+K4): scan -> filter -> group
 //
 // One persistent workgroup per CU slice walks tiles of BLOCK*R rows.  DIRECT = the group-key domain is small
@@ -452,6 +554,8 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
                                                           unsigned long long* ngroups) {
     extern __shared__ uint64_t lds[];
     __shared__ uint32_t lds_fill;
+    __shared__ uint32_t log_wave_cnt[BLOCK / 64];
+    __shared__ unsigned long long log_tile_base;
     const uint32_t S = A.lds_slots;
     const uint32_t tid = threadIdx.x;
 
@@ -529,10 +633,62 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
         // CumulateInitial of every aggregate (execution/group_initial.go:89-97)
         for (uint32_t a = 0; a < P.naggs; a++) {
             const AggSpec& ag = P.aggs[a];
-            if (ag.distinct) continue;
             uint32_t vt[R];
             uint64_t vp[R];
             if (ag.has_operand) load_operand<R>(P, ag.src, row, pass, vt, vp);
+            if (ag.distinct) {
+                // setAdd (algebra/agg_util.go:30-47): here the (group, value) pair is logged and de-duplicated at
+                // finish; the per-class operand counts size each group's value set.  Log space is reserved once
+                // per workgroup tile (one atomic on the cursor per BLOCK*R rows, not per wave).
+                uint32_t cls[R];
+                uint64_t val[R];
+                bool q[R];
+                uint32_t mine = 0;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    cls[j] = 0;
+                    val[j] = 0;
+                    q[j] = pass[j] && distinct_classify(ag.kind, vt[j], vp[j], cls[j], val[j]);
+                    if (q[j]) {
+                        mine++;
+                        if (slot[j] >= 0) lds_add_u64(lds_word(lds, (ag.lds_off + cls[j]) * S + (uint32_t)slot[j]), 1ull);
+                        else atomicAdd((unsigned long long*)&G.acc[(size_t)grow[j] * P.glob_words + ag.glob_off + 1 + cls[j]], 1ull);
+                    }
+                }
+                // exclusive prefix of `mine` over the workgroup: wave scan + per-wave totals in LDS
+                uint32_t incl = mine;
+                for (int off = 1; off < 64; off <<= 1) {
+                    uint32_t t = __shfl_up(incl, off, 64);
+                    if ((int)(tid & 63) >= off) incl += t;
+                }
+                if ((tid & 63) == 63) log_wave_cnt[tid >> 6] = incl;
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t run = 0;
+                    for (int w = 0; w < BLOCK / 64; w++) {
+                        uint32_t c = log_wave_cnt[w];
+                        log_wave_cnt[w] = run;
+                        run += c;
+                    }
+                    log_tile_base = run ? atomicAdd(&A.log_cursor[ag.log_index], (unsigned long long)run) : 0ull;
+                }
+                __syncthreads();
+                unsigned long long pos = log_tile_base + log_wave_cnt[tid >> 6] + (incl - mine);
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    if (!q[j]) continue;
+                    if (pos < A.log_capacity) {
+                        A.log_key[ag.log_index][pos] = key[j];
+                        A.log_val[ag.log_index][pos] = val[j];
+                        A.log_cls[ag.log_index][pos] = (uint8_t)cls[j];
+                    } else {
+                        atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                    }
+                    pos++;
+                }
+                __syncthreads();
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 if (!pass[j]) continue;
@@ -1069,6 +1225,80 @@ __global__ __launch_bounds__(1024) void merge_slabs_kernel(const Program P, cons
     }
 }
 
+// ------------------------------------------------------------------ multi-GPU: exchange of PARTIAL GROUPS
+//
+// When groups are few next to rows, every GPU first aggregates its own shard (scan kernels above) and only the
+// partial groups travel: hash-partitioned on the group key so that each key is finished on exactly one GPU
+// (≙ CumulateIntermediate on the owner, execution/group_intermediate.go:91-101).  Region d of `out` is
+//   [count u64][reserved u64][keys: cap x u64][acc: cap x glob_words x u64]
+__global__ void export_partials_kernel(const Program P, const GlobalTable G, uint32_t nparts, uint64_t cap,
+                                       uint64_t* out, uint64_t region_words, uint32_t* err_flags) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.capacity) return;
+    uint64_t key = G.keys[s];
+    if (key == kEmptyKey) return;
+    uint32_t d = (uint32_t)(((mix64(key) >> 32) * (uint64_t)nparts) >> 32);
+    uint64_t* region = out + (size_t)d * region_words;
+    unsigned long long pos = atomicAdd((unsigned long long*)&region[0], 1ull);
+    if (pos >= cap) {
+        atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+        return;
+    }
+    region[2 + pos] = key;
+    uint64_t* acc = region + 2 + cap + pos * P.glob_words;
+    for (uint32_t w = 0; w < P.glob_words; w++) acc[w] = G.acc[(size_t)s * P.glob_words + w];
+}
+
+// merge received partial groups into this GPU's table (one thread per record)
+__global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint32_t nregions, uint64_t cap,
+                                      const uint64_t* in, uint64_t region_words, uint32_t* err_flags,
+                                      unsigned long long* ngroups) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = (uint32_t)(i / cap);
+    uint64_t pos = i % cap;
+    if (r >= nregions) return;
+    const uint64_t* region = in + (size_t)r * region_words;
+    uint64_t count = region[0] < cap ? region[0] : cap;
+    if (pos >= count) return;
+    uint64_t key = region[2 + pos];
+    const uint64_t* l = region + 2 + cap + pos * P.glob_words;
+    long long g = global_find_or_insert(G, key, err_flags, ngroups);
+    if (g < 0) return;
+    for (uint32_t a = 0; a < P.naggs; a++) {
+        const AggSpec& ag = P.aggs[a];
+        const uint64_t* p = l + ag.glob_off;
+        unsigned long long* w = (unsigned long long*)&G.acc[(size_t)g * P.glob_words + ag.glob_off];
+        if (ag.distinct) {  // set members do not travel with partial groups: the caller uses the row exchange
+            atomicOr(err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
+            continue;
+        }
+        switch (ag.kind) {
+            case AGG_COUNT:
+            case AGG_COUNTN:
+                if (p[0]) atomicAdd(&w[0], (unsigned long long)p[0]);
+                break;
+            case AGG_SUM:
+            case AGG_AVG:
+                if (!p[3]) break;
+                atomicAdd(&w[0], (unsigned long long)p[0]);
+                atomicAdd(&w[1], (unsigned long long)p[1]);
+                if (p[3] & SF_FLOAT) atomicAdd((double*)&w[2], as_f64(p[2]));
+                atomicOr(&w[3], (unsigned long long)p[3]);
+                if (ag.kind == AGG_AVG) atomicAdd(&w[4], (unsigned long long)p[4]);
+                break;
+            default: {
+                if (!p[0]) break;
+                bool mn = ag.kind == AGG_MIN;
+                atomicOr(&w[0], (unsigned long long)p[0]);
+                if (p[0] & MM_INT) { if (mn) atomicMin((long long*)&w[1], (long long)p[1]); else atomicMax((long long*)&w[1], (long long)p[1]); }
+                if (p[0] & MM_FLOAT) { if (mn) atomicMin(&w[2], (unsigned long long)p[2]); else atomicMax(&w[2], (unsigned long long)p[2]); }
+                if (p[0] & MM_STRING) { if (mn) atomicMin(&w[3], (unsigned long long)p[3]); else atomicMax(&w[3], (unsigned long long)p[3]); }
+                break;
+            }
+        }
+    }
+}
+
 // grow the global table: re-insert every occupied slot (keys keep their packed form)
 __global__ void rehash_kernel(const Program P, const GlobalTable oldt, const GlobalTable newt, uint32_t* err_flags,
                               unsigned long long* scratch) {
@@ -1408,6 +1638,36 @@ hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalT
     uint32_t blocks = (F.lds_slots + 63) / 64;
     uint32_t ychunks = nblocks >= 512 ? 4 : (nblocks >= 128 ? 2 : 1);  // 16 * ychunks parallel chunks of workgroups
     hipLaunchKernelGGL(merge_slabs_kernel, dim3(blocks, ychunks), dim3(64, 16), 0, st, P, F, G, nblocks, ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_distinct_layout(const Program& P, const GlobalTable& G, const DistinctArgs& D, hipStream_t st) {
+    uint32_t blocks = (uint32_t)((G.capacity + 255) / 256);
+    hipLaunchKernelGGL(distinct_layout_kernel, dim3(blocks), dim3(256), 0, st, P, G, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_distinct_insert(const Program& P, const GlobalTable& G, const DistinctArgs& D, uint32_t* err_flags,
+                                  hipStream_t st) {
+    if (D.npairs == 0) return hipSuccess;
+    uint32_t blocks = (uint32_t)((D.npairs + 255) / 256);
+    hipLaunchKernelGGL(distinct_insert_kernel, dim3(blocks), dim3(256), 0, st, P, G, D, err_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_partials(const Program& P, const GlobalTable& G, uint32_t nparts, uint64_t cap, uint64_t* out,
+                                  uint64_t region_words, uint32_t* err_flags, hipStream_t st) {
+    uint32_t blocks = (uint32_t)((G.capacity + 255) / 256);
+    hipLaunchKernelGGL(export_partials_kernel, dim3(blocks), dim3(256), 0, st, P, G, nparts, cap, out, region_words, err_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_partials(const Program& P, const GlobalTable& G, uint32_t nregions, uint64_t cap, const uint64_t* in,
+                                 uint64_t region_words, uint32_t* err_flags, unsigned long long* ngroups, hipStream_t st) {
+    uint64_t total = (uint64_t)nregions * cap;
+    if (!total) return hipSuccess;
+    uint32_t blocks = (uint32_t)((total + 255) / 256);
+    hipLaunchKernelGGL(merge_partials_kernel, dim3(blocks), dim3(256), 0, st, P, G, nregions, cap, in, region_words, err_flags, ngroups);
     return hipGetLastError();
 }
 

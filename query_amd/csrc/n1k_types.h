@@ -90,7 +90,7 @@ struct AggSpec {
     uint32_t has_operand;
     uint32_t lds_off;   // first accumulator word inside an LDS slot
     uint32_t glob_off;  // first accumulator word inside a global-table row
-    uint32_t pad;
+    uint32_t log_index; // DISTINCT: which pair log this aggregate appends to
     Operand src;
 };
 
@@ -99,13 +99,15 @@ struct AggSpec {
 //   SUM          : [isum i64][fsum f64][flags]          one atomic per row; flags are read-mostly
 //   AVG          : [isum i64][fsum f64][flags][n]
 //   MIN/MAX      : [flags][ival i64][fval sortable u64][sval rank<<32|code]
-//   * DISTINCT   : (none; pairs go to the distinct log)
+//   * DISTINCT   : [n_int][n_float][n_other]   operands per value class (sizes the dedupe regions); the
+//                  (group key, class, value) pairs go to the aggregate's pair log
 // global accumulator words per aggregate
 //   COUNT/COUNTN : [cnt]
 //   SUM          : [isum_lo][isum_hi][fsum][flags]
 //   AVG          : [isum_lo][isum_hi][fsum][flags][n]
 //   MIN/MAX      : [flags][ival][fval][sval]
-//   * DISTINCT   : [distinct count]  (filled at finish)
+//   * DISTINCT   : [distinct count (filled at finish)][n_int][n_float][n_other][special]
+constexpr uint32_t kLdsWordsDistinct = 3, kGlobWordsDistinct = 5, kMaxDistinct = 4;
 constexpr uint32_t kLdsWordsSum = 3, kLdsWordsAvg = 4, kGlobWordsSum = 4, kGlobWordsAvg = 5, kWordsMinMax = 4;
 
 // SUM/AVG flag bits: which kinds of NUMBER operands were met.  intValue.Add keeps an int64 only for same-sign
@@ -156,6 +158,27 @@ struct ScanArgs {
     unsigned long long* rows_selected;  // device counter
     uint32_t wave_reduce;
     uint32_t compact;
+    // DISTINCT pair logs (one per DISTINCT aggregate): (group key, value, class) of every qualifying operand
+    uint64_t* log_key[kMaxDistinct];
+    uint64_t* log_val[kMaxDistinct];
+    uint8_t* log_cls[kMaxDistinct];
+    unsigned long long* log_cursor;  // kMaxDistinct counters
+    uint64_t log_capacity;
+};
+
+// value classes of the DISTINCT sets (value/set.go:22-35 keeps one map per type; integral floats join the ints)
+enum : uint32_t { DC_INT = 0, DC_FLOAT = 1, DC_OTHER = 2 };
+
+struct DistinctArgs {
+    const uint64_t* log_key;
+    const uint64_t* log_val;
+    const uint8_t* log_cls;
+    uint64_t npairs;
+    uint64_t* regions;     // capacity * 3 * 2 words: (offset, mask) per (slot, class)
+    uint64_t* set_table;   // concatenated per-(group, class) open-addressed value sets, kEmptyKey when free
+    unsigned long long* total_words;  // out: words needed by the regions
+    uint32_t glob_off;     // first global word of the aggregate
+    uint32_t pad;
 };
 
 // ---- "fast" scan kernel: bounded plan shapes with every descriptor at a static index ------------------------

@@ -89,6 +89,47 @@ class ShardedFilterGroup:
         self.send_paths = self.sender.column_paths
         self.recv_paths = self.receiver.column_paths
         self._bufs = None
+        self.has_distinct = any("(distinct " in a.lower() for a in aggs)
+        self.partial_capacity = int(options.get("partial_capacity", 4096)) if options else 4096
+        self._pbuf = None
+
+    # ------------------------------------------------------------------ exchange of partial groups
+    def run_partials(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
+        """Few groups next to rows: aggregate the local shard first (same kernels as on one GPU), then move only
+        the partial groups: ONE all_to_all_single of fixed-size regions, hash-partitioned on the group key, merged
+        by the owner (≙ IntermediateGroup) and finalised there."""
+        import torch
+        import torch.distributed as dist
+        from query_amd import _ffi
+        op = self.sender  # Filter + InitialGroup over the local shard
+        lib = op._lib
+        op.reopen()
+        op.process_device_items(nrows, [cols_by_path[p] for p in self.send_paths])
+        dev = torch.device("cuda", self.device)
+        while True:
+            cap = self.partial_capacity
+            region = int(lib.n1k_partial_region_bytes(op._h, cap))
+            if self._pbuf is None or self._pbuf[0].numel() != region * self.world:
+                self._pbuf = (torch.empty(region * self.world, dtype=torch.uint8, device=dev),
+                              torch.empty(region * self.world, dtype=torch.uint8, device=dev))
+            send, recv = self._pbuf
+            st = lib.n1k_export_partials_device(op._h, self.world, cap, send.data_ptr())
+            if st == _ffi.OOM:  # a destination got more groups than a region holds: grow and retry (all ranks agree below)
+                grow = torch.ones(1, dtype=torch.int32, device=dev)
+            else:
+                op._check(st)
+                grow = torch.zeros(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(grow, op=dist.ReduceOp.MAX)
+            if int(grow.item()) == 0:
+                break
+            self.partial_capacity *= 4
+        stats = op.stats()
+        dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
+        op.reopen()                          # the owner starts from an empty table (plan, dictionary, layout stay)
+        torch.cuda.synchronize()
+        op._check(lib.n1k_merge_partials_device(op._h, self.world, cap, recv.data_ptr()))
+        raw = op.after_items_raw()
+        return raw, {"mode": "partials", "region_bytes": region, "rows_selected": int(stats["rows_selected"])}
 
     def _alloc(self, capacity: int, kinds: Sequence[int]):
         import torch
@@ -165,6 +206,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     import torch.distributed as dist
     import bench
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "MASTER_ADDR" not in os.environ:  # --force-dist without a launcher
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     wl = bench.workloads()[args.workload]
     total_rows = args.rows * world
@@ -174,7 +219,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     dev = torch.device("cuda", local_rank)
 
     def step():
-        raw, info = op.run(args.rows, cols.by_path)
+        raw, info = (op.run(args.rows, cols.by_path) if op.has_distinct or args.exchange == "rows"
+                     else op.run_partials(args.rows, cols.by_path))
         rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
                               raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1) \
             if raw["ngroups"] else np.zeros((0, 16 * (raw["nkeys"] + raw["naggs"])), np.uint8)
@@ -207,9 +253,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
             "vs_baseline": None,
             "dtype": "int64/f64 tagged scalars (u8 tag + 8 B payload), u32 dictionary codes",
             "data": "synthetic",
-            "config": {"workload": "%s: %s @ %d rows per GPU x %d GPUs, K_cat=%d, rows hash-partitioned on the group "
+            "config": {"workload": "%s: %s @ %d rows per GPU x %d GPUs, K_cat=%d, %s hash-partitioned on the group "
                                    "key by RCCL all-to-all, final groups gathered on rank 0" %
-                                   (args.workload, wl["sql"], args.rows, world, args.kcat),
+                                   (args.workload, wl["sql"], args.rows, world, args.kcat,
+                                    "partial groups" if info.get("mode") == "partials" else "filtered rows"),
                        "rows_per_gpu": args.rows, "groups": int(allg.shape[0]) if allg is not None else None,
                        "exchange_rows_rank0": info},
         }

@@ -1,0 +1,191 @@
+"""GPU side of the N>1 path on ONE device: the hash-partition kernel, and the full rank pipeline with a
+world_size-1 RCCL group (partition -> all_to_all_single -> local group -> gather)."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import parity_util as pu
+import query_amd
+from oracle import n1o
+from query_amd import _ffi, plan
+
+pytestmark = pytest.mark.gpu
+
+
+def D(*names):
+    return plan.field_path("default", *names)
+
+
+COND = "(50 < %s)" % D("price")
+KEYS = [D("cat")]
+AGGS = sorted(["count(*)", "sum(%s)" % D("price"), "max(%s)" % D("user_id")])
+
+
+def _device_cols(t, paths):
+    import torch
+    by = {c.name: c for c in t.columns}
+    keep, dev = [], {}
+    for p in paths:
+        c = by[p]
+        if c.kind == n1o.COL_DICT32:
+            x = torch.from_numpy(c.codes.view(np.int32)).cuda()
+            keep.append(x)
+            dev[p] = (_ffi.COL_DICT32, None, None, x.data_ptr())
+        else:
+            a = torch.from_numpy(c.tags).cuda()
+            b = torch.from_numpy(c.payload.view(np.int64)).cuda()
+            keep += [a, b]
+            dev[p] = (_ffi.COL_TAGGED64, a.data_ptr(), b.data_ptr(), None)
+    torch.cuda.synchronize()
+    return dev, keep
+
+
+@pytest.mark.parametrize("nparts", [1, 3, 8])
+def test_partition_kernel_routes_every_survivor_once(nparts):
+    import torch
+    n = 90_001
+    t = n1o.synth_table(n, k_cat=29, zipf=True)
+    sender = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, KEYS, AGGS))
+    sender.intern(list(t.dictionary))
+    paths = sender.column_paths
+    dev, keep = _device_cols(t, paths)
+    cols = [dev[p] for p in paths]
+    batch, arr = sender._make_batch(n, cols)
+    cap = n
+    out = (_ffi.Col * len(cols))()
+    bufs = []
+    for i, c in enumerate(cols):
+        out[i].kind = c[0]
+        if c[0] == _ffi.COL_DICT32:
+            b = torch.zeros(cap * nparts, dtype=torch.int32, device="cuda")
+            out[i].codes = b.data_ptr()
+            bufs.append((b,))
+        else:
+            a = torch.zeros(cap * nparts, dtype=torch.uint8, device="cuda")
+            b = torch.zeros(cap * nparts, dtype=torch.int64, device="cuda")
+            out[i].tags, out[i].payload = a.data_ptr(), b.data_ptr()
+            bufs.append((a, b))
+    counts = torch.zeros(nparts, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    st = sender._lib.n1k_partition_device_batch(sender._h, C.byref(batch), nparts, cap, out, counts.data_ptr())
+    sender._check(st)
+    cnt = counts.cpu().numpy()
+    ora_sel = n1o.run(t, COND, [], [], has_group=False).selected
+    assert int(cnt.sum()) == len(ora_sel)  # every survivor exactly once
+    # a group key lives in exactly one part, and the union of the parts' groups is the oracle's answer
+    ora = n1o.run(t, COND, KEYS, AGGS)
+    seen = {}
+    merged_keys, merged_aggs = [], []
+    for d in range(nparts):
+        recv = query_amd.GpuFilterGroup(plan.filter_group_plan(None, KEYS, AGGS))
+        recv.intern(list(t.dictionary))
+        rcols = []
+        for p in recv.column_paths:
+            i = paths.index(p)
+            if cols[i][0] == _ffi.COL_DICT32:
+                rcols.append((_ffi.COL_DICT32, None, None, bufs[i][0].data_ptr() + 4 * d * cap))
+            else:
+                rcols.append((_ffi.COL_TAGGED64, bufs[i][0].data_ptr() + d * cap, bufs[i][1].data_ptr() + 8 * d * cap, None))
+        recv.process_device_items(int(cnt[d]), rcols)
+        rows = recv.after_items()
+        recv.done()
+        for k, a in zip(rows.keys, rows.aggs):
+            assert k not in seen, "group %r landed in two parts" % (k,)
+            seen[k] = d
+            merged_keys.append(k)
+            merged_aggs.append(a)
+    sender.done()
+    from query_amd.gpu_operator import GroupRows
+    pu.assert_same_groups(GroupRows(1, len(AGGS), merged_keys, merged_aggs, []), ora, aggs=AGGS)
+
+
+def test_partial_groups_export_merge_roundtrip():
+    """Partial groups exported in hash-partitioned regions and merged back (as the owner ranks would after the
+    all-to-all) give the single-handle answer; merging the same regions twice doubles the additive aggregates."""
+    import torch
+    n = 80_000
+    t = n1o.synth_table(n, k_cat=300)
+    aggs = sorted(["count(*)", "sum(%s)" % D("price"), "avg(%s)" % D("price"), "min(%s)" % D("price"), "max(%s)" % D("user_id")])
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, KEYS, aggs))
+    op.intern(list(t.dictionary))
+    dev, keep = _device_cols(t, op.column_paths)
+    op.process_device_items(n, [dev[p] for p in op.column_paths])
+    nparts, cap = 4, 256
+    lib = op._lib
+    region = int(lib.n1k_partial_region_bytes(op._h, cap))
+    buf = torch.zeros(region * nparts, dtype=torch.uint8, device="cuda")
+    op._check(lib.n1k_export_partials_device(op._h, nparts, cap, buf.data_ptr()))
+    counts = [int(buf[d * region: d * region + 8].view(torch.int64).item()) for d in range(nparts)]
+    assert sum(counts) == 302 or sum(counts) <= 302  # 300 categories (+ none missing here)
+    with pytest.raises(query_amd.N1kError):  # too small a region is reported, not truncated
+        small = torch.zeros(int(lib.n1k_partial_region_bytes(op._h, 8)) * nparts, dtype=torch.uint8, device="cuda")
+        op._check(lib.n1k_export_partials_device(op._h, nparts, 8, small.data_ptr()))
+    op.reopen()
+    op._check(lib.n1k_merge_partials_device(op._h, nparts, cap, buf.data_ptr()))
+    merged = op.after_items()
+    op.done()
+    ora = n1o.run(t, COND, KEYS, aggs)
+    pu.assert_same_groups(merged, ora, aggs=aggs)
+
+
+def test_rank_pipeline_partials_world1_rccl():
+    import torch
+    import torch.distributed as dist
+    from query_amd import distributed as qd
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n = 120_000
+        t = n1o.synth_table(n, k_cat=5000)  # more groups than the initial region capacity: exercises the retry
+        op = qd.ShardedFilterGroup(COND, KEYS, AGGS, t.dictionary, 0, 1, 0)
+        dev, keep = _device_cols(t, op.send_paths)
+        raw, info = op.run_partials(n, dev)
+        ora = n1o.run(t, COND, KEYS, AGGS)
+        assert info["rows_selected"] == ora.rows_passed and raw["ngroups"] == len(ora.keys)
+        cache = {}
+        from query_amd.gpu_operator import GroupRows
+        got = GroupRows(1, len(AGGS), op.sender._py_values(raw["keys"], cache), op.sender._py_values(raw["aggs"], cache), [])
+        pu.assert_same_groups(got, ora, aggs=AGGS)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_pipeline_world1_rccl():
+    import torch
+    import torch.distributed as dist
+    from query_amd import distributed as qd
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n = 120_000
+        t = n1o.synth_table(n, k_cat=50)
+        op = qd.ShardedFilterGroup(COND, KEYS, AGGS, t.dictionary, 0, 1, 0)
+        dev, keep = _device_cols(t, op.send_paths)
+        raw, info = op.run(n, dev)
+        ora = n1o.run(t, COND, KEYS, AGGS)
+        assert info["sent_rows"] == info["recv_rows"] == ora.rows_passed
+        assert raw["ngroups"] == len(ora.keys)
+        rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
+                              raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1)
+        allg = qd.gather_groups(rec, device=torch.device("cuda", 0))
+        assert allg.shape == rec.shape
+        cache = {}
+        keys = op.receiver._py_values(raw["keys"], cache)
+        aggs = op.receiver._py_values(raw["aggs"], cache)
+        from query_amd.gpu_operator import GroupRows
+        pu.assert_same_groups(GroupRows(1, len(AGGS), keys, aggs, []), ora, aggs=AGGS)
+    finally:
+        dist.destroy_process_group()

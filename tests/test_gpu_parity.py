@@ -186,6 +186,53 @@ def test_int64_exact_sum_and_sign_rule():
     assert kinds[0] == n1o.T_INT and kinds[1] == n1o.T_INT and kinds[2] == n1o.T_FLOAT and kinds[3] == n1o.T_FLOAT
 
 
+CONFIG3 = (None, [D("cat")], sorted(["count(distinct %s)" % D("user_id"), "avg(%s)" % D("price")]))
+
+
+@pytest.mark.parametrize("batches", [1, 3])
+def test_config3_count_distinct_avg(batches):
+    """BASELINE config 3: COUNT(DISTINCT user_id) + AVG(price) GROUP BY cat (exact set semantics, value/set.go)."""
+    t = n1o.synth_table(200_000, k_cat=100, total_rows=20_000)  # user_id in [0, 2000): many duplicates per group
+    cond, keys, aggs = CONFIG3
+    ora = n1o.run(t, cond, keys, aggs, threads=2)
+    gpu, _ = pu.run_gpu(t, cond, keys, aggs, batches=batches, device_resident=(batches == 1))
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+
+
+def test_distinct_over_mixed_types_and_edge_values():
+    """Integral floats join the ints, -1 collides with the free marker, strings/booleans count by value,
+    NULL/MISSING never enter the set; COUNTN(DISTINCT) takes numbers only."""
+    n = 6000
+    rng = np.random.default_rng(11)
+    grp = rng.integers(0, 5, n).astype(np.uint64)
+    tags = np.zeros(n, np.uint8)
+    pay = np.zeros(n, np.uint64)
+    strs = [b"a", b"b", b"", b"zz"]
+    for i in range(n):
+        r = rng.integers(0, 10)
+        if r < 3:
+            tags[i], pay[i] = n1o.T_INT, np.int64(rng.integers(-3, 4)).view(np.uint64)
+        elif r < 5:
+            f = float(rng.integers(-3, 4)) if rng.integers(0, 2) else float(rng.integers(0, 8)) / 4.0 + 0.125
+            tags[i], pay[i] = n1o.T_FLOAT, np.float64(f).view(np.uint64)  # some integral floats (unfolded on purpose)
+        elif r < 7:
+            tags[i], pay[i] = n1o.T_STRING, rng.integers(0, len(strs))
+        elif r == 7:
+            tags[i] = n1o.T_TRUE if rng.integers(0, 2) else n1o.T_FALSE
+        elif r == 8:
+            tags[i] = n1o.T_NULL
+        else:
+            tags[i] = n1o.T_MISSING
+    gt = np.full(n, n1o.T_INT, np.uint8)
+    t = n1o.Table([n1o.Column(D("g"), n1o.COL_TAGGED64, tags=gt, payload=grp),
+                   n1o.Column(D("v"), n1o.COL_TAGGED64, tags=tags, payload=pay)], strs)
+    aggs = sorted(["count(distinct %s)" % D("v"), "countn(distinct %s)" % D("v"), "count(%s)" % D("v")])
+    for keys in ([D("g")], []):
+        ora = n1o.run(t, None, keys, aggs)
+        gpu, _ = pu.run_gpu(t, None, keys, aggs, batches=2)
+        pu.assert_same_groups(gpu, ora, aggs=aggs)
+
+
 def test_filter_only_selected_rows():
     t = n1o.synth_table(100_003, k_cat=10)
     for cond in ["(50 < %s)" % D("price"), "(%s is missing)" % D("price"), "(%s = \"cat_3\")" % D("cat")]:
