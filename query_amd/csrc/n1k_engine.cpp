@@ -106,7 +106,7 @@ struct n1k_handle {
     // device state
     GlobalTable table{};
     DevBuf<uint64_t> d_keys, d_acc, d_rep, d_slabs;
-    DevBuf<uint32_t> d_err;
+    uint32_t* d_errp = nullptr;  // lives inside d_counters ([12]) so one copy reads counters and flags
     DevBuf<unsigned long long> d_counters;  // [0] rows_selected [1] ngroups [2] out_count [3] filter total [4] rehash scratch
                                             // [5] distinct region words [8..11] pair-log cursors
     uint64_t row_base = 0;
@@ -126,9 +126,8 @@ struct n1k_handle {
     std::vector<n1k_value> r_keys, r_aggs;
     std::vector<n1k_partial> r_parts;
     std::vector<uint64_t> r_rep;
-    DevBuf<OutValue> d_okeys, d_oaggs;
-    DevBuf<OutPartial> d_oparts;
-    DevBuf<uint64_t> d_orep;
+    DevBuf<char> d_out;            // finalize output: [keys][aggs][partials][rep rows], copied to the host at once
+    std::vector<char> out_host;
     std::vector<char> export_blob;
 
     // stats
@@ -354,9 +353,8 @@ n1k_status ensure_device(n1k_handle* h) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
     }
-    HIP_TRY(h, h->d_err.ensure(4));
     HIP_TRY(h, h->d_counters.ensure(16));
-    HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4 * sizeof(uint32_t), h->stream));
+    h->d_errp = (uint32_t*)(h->d_counters.p + 12);
     HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
     h->device_ready = true;
     return N1K_OK;
@@ -426,7 +424,7 @@ n1k_status alloc_table(n1k_handle* h, uint64_t capacity, GlobalTable& t, DevBuf<
     t.acc = acc.p;
     t.rep_row = h->prog.want_rep_row ? rep.p : nullptr;
     t.capacity = capacity;
-    HIP_TRY(h, launch_init_table(h->prog, t, 0, capacity, h->stream));
+    HIP_TRY(h, launch_init_table(h->prog, t, 0, capacity, nullptr, h->stream));
     return N1K_OK;
 }
 
@@ -453,7 +451,7 @@ n1k_status ensure_table(n1k_handle* h, uint64_t incoming_rows) {
     DevBuf<uint64_t> nk, na, nr;
     n1k_status st = alloc_table(h, cap, nt, nk, na, nr);
     if (st != N1K_OK) return st;
-    HIP_TRY(h, launch_rehash(h->prog, h->table, nt, h->d_err.p, h->d_counters.p + 4, h->stream));
+    HIP_TRY(h, launch_rehash(h->prog, h->table, nt, h->d_errp, h->d_counters.p + 4, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->d_keys.release();
     h->d_acc.release();
@@ -651,7 +649,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         uint32_t fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
         // slabs + merge kernel pay off once the table is more than a few KiB
         const bool use_slabs = h->opt_slabs == 1 ? table_bytes >= 4096 : h->opt_slabs == 2;
-        F.err_flags = h->d_err.p;
+        F.err_flags = h->d_errp;
         F.rows_selected = h->d_counters.p + 0;
         hipEvent_t e0 = get_event(h), e1 = get_event(h);
         if (e0) (void)hipEventRecord(e0, h->stream);
@@ -732,7 +730,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     if (P.nkeys == 0) slots = 2;
     A.lds_slots = slots;
     A.lds_max_fill = std::max(1u, (uint32_t)((uint64_t)slots * 5 / 8));
-    A.err_flags = h->d_err.p;
+    A.err_flags = h->d_errp;
     A.rows_selected = h->d_counters.p + 0;
     A.wave_reduce = h->opt_wave_reduce;
     A.compact = h->opt_compact;
@@ -760,7 +758,7 @@ n1k_status run_filter_batch(n1k_handle* h, const n1k_batch* b) {
     uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)h->num_cus * 8);
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
     if (e0) (void)hipEventRecord(e0, h->stream);
-    HIP_TRY(h, launch_filter_mask(P, b->nrows, h->d_mask.p, h->d_tile_cnt.p, h->d_err.p, grid, h->stream));
+    HIP_TRY(h, launch_filter_mask(P, b->nrows, h->d_mask.p, h->d_tile_cnt.p, h->d_errp, grid, h->stream));
     HIP_TRY(h, launch_tile_scan(h->d_tile_cnt.p, h->d_tile_off.p, ntiles, h->d_counters.p + 3, h->stream));
     unsigned long long total = 0;
     HIP_TRY(h, hipMemcpyAsync(&total, h->d_counters.p + 3, sizeof total, hipMemcpyDeviceToHost, h->stream));
@@ -879,7 +877,6 @@ void n1k_destroy(n1k_handle* h) {
             h->d_log_val[d].release();
             h->d_log_cls[d].release();
         }
-        h->d_err.release();
         h->d_counters.release();
         for (auto& b : h->st_tags) b.release();
         for (auto& b : h->st_payload) b.release();
@@ -888,10 +885,7 @@ void n1k_destroy(n1k_handle* h) {
         h->d_tile_off.release();
         h->d_sel.release();
         h->d_tile_cnt.release();
-        h->d_okeys.release();
-        h->d_oaggs.release();
-        h->d_oparts.release();
-        h->d_orep.release();
+        h->d_out.release();
         if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -913,9 +907,9 @@ n1k_status n1k_reset(n1k_handle* h) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         drain_events(h);
         h->stats.device_ms = 0;
-        HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4 * sizeof(uint32_t), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
-        if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->stream));
+        // one launch: table back to empty and all counters / error flags to zero
+        if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
+        else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
     }
     return N1K_OK;
 }
@@ -1060,9 +1054,9 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     unsigned long long counters[16] = {0};
     if (h->device_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
-        HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        err_flags = (uint32_t)counters[12];
         drain_events(h);
     } else if (h->stats.rows_in == 0) {
         // no batch was ever pushed: nothing ran on the device; only the empty-input row can be produced
@@ -1106,31 +1100,30 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             HIP_TRY(h, h->d_set_table.ensure(std::max<uint64_t>(words, 1)));
             D.set_table = h->d_set_table.p;
             if (words) HIP_TRY(h, hipMemsetAsync(h->d_set_table.p, 0xFF, words * 8, h->stream));
-            HIP_TRY(h, launch_distinct_insert(h->prog, h->table, D, h->d_err.p, h->stream));
+            HIP_TRY(h, launch_distinct_insert(h->prog, h->table, D, h->d_errp, h->stream));
         }
     }
     if (ng > 0) {
-        HIP_TRY(h, h->d_okeys.ensure(ng * std::max(nk, 1u)));
-        HIP_TRY(h, h->d_oaggs.ensure(ng * std::max(na, 1u)));
-        HIP_TRY(h, h->d_oparts.ensure(ng * std::max(na, 1u)));
-        HIP_TRY(h, h->d_orep.ensure(ng));
+        const size_t rec_keys = (size_t)nk * sizeof(OutValue), rec_aggs = (size_t)na * sizeof(OutValue),
+                     rec_parts = (size_t)na * sizeof(OutPartial);
+        const size_t off_aggs = ng * rec_keys, off_parts = off_aggs + ng * rec_aggs, off_rep = off_parts + ng * rec_parts;
+        const size_t total = off_rep + ng * 8;
+        HIP_TRY(h, h->d_out.ensure(total + 16));
+        char* d = h->d_out.p;
         HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
-        HIP_TRY(h, launch_finalize(h->prog, h->table, h->d_okeys.p, h->d_oaggs.p, h->d_oparts.p, h->d_orep.p,
-                                   h->d_counters.p + 2, ng, h->d_err.p, h->stream));
-        h->r_keys.resize(ng * nk);
-        h->r_aggs.resize(ng * na);
-        h->r_rep.resize(ng);
-        std::vector<OutPartial> parts(ng * na);
-        if (nk) HIP_TRY(h, hipMemcpyAsync(h->r_keys.data(), h->d_okeys.p, ng * nk * sizeof(n1k_value), hipMemcpyDeviceToHost, h->stream));
-        if (na) {
-            HIP_TRY(h, hipMemcpyAsync(h->r_aggs.data(), h->d_oaggs.p, ng * na * sizeof(n1k_value), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipMemcpyAsync(parts.data(), h->d_oparts.p, ng * na * sizeof(OutPartial), hipMemcpyDeviceToHost, h->stream));
-        }
-        HIP_TRY(h, hipMemcpyAsync(h->r_rep.data(), h->d_orep.p, ng * 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
+                                   (uint64_t*)(d + off_rep), h->d_counters.p + 2, ng, h->d_errp, h->stream));
+        h->out_host.resize(total);
+        HIP_TRY(h, hipMemcpyAsync(h->out_host.data(), d, total, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const char* hp = h->out_host.data();
+        h->r_keys.assign((const n1k_value*)hp, (const n1k_value*)hp + ng * nk);
+        h->r_aggs.assign((const n1k_value*)(hp + off_aggs), (const n1k_value*)(hp + off_aggs) + ng * na);
+        h->r_rep.assign((const uint64_t*)(hp + off_rep), (const uint64_t*)(hp + off_rep) + ng);
+        const OutPartial* parts = (const OutPartial*)(hp + off_parts);
         h->r_parts.resize(ng * na);
-        for (size_t i = 0; i < parts.size(); i++) {
+        for (size_t i = 0; i < ng * na; i++) {
             n1k_partial& p = h->r_parts[i];
             memset(&p, 0, sizeof p);
             p.count = parts[i].count;
@@ -1210,7 +1203,7 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
     A.capacity = capacity_rows;
     A.nparts = nparts;
     A.counts = (unsigned long long*)out_counts;
-    A.err_flags = h->d_err.p;
+    A.err_flags = h->d_errp;
     HIP_TRY(h, hipMemsetAsync(out_counts, 0, nparts * sizeof(uint64_t), h->stream));
     if (batch->nrows) {
         uint64_t ntiles = (batch->nrows + 1023) / 1024;
@@ -1222,7 +1215,7 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
         h->events.emplace_back(e0, e1);
     }
     uint32_t err_flags = 0;
-    HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (err_flags & ERR_TABLE_FULL) return fail(h, N1K_OOM, "partition region capacity (%llu rows) exceeded", (unsigned long long)capacity_rows);
     if (err_flags & ERR_UNPACKABLE_KEY) return fail(h, N1K_UNSUPPORTED_DATA, "a group key value does not fit the packed key");
@@ -1246,16 +1239,18 @@ n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t c
     n1k_status st = ensure_device(h);
     if (st != N1K_OK) return st;
     uint64_t region_words = 2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words);
-    for (uint32_t d = 0; d < nparts; d++)
-        HIP_TRY(h, hipMemsetAsync((char*)out + (size_t)d * region_words * 8, 0, 16, h->stream));
+    HIP_TRY(h, hipMemsetAsync(out, 0, (size_t)nparts * region_words * 8, h->stream));  // headers (and padding) to zero
     if (h->table.capacity)
         HIP_TRY(h, launch_export_partials(h->prog, h->table, nparts, capacity_groups, (uint64_t*)out, region_words,
-                                          h->d_err.p, h->stream));
+                                          h->d_errp, h->stream));
     uint32_t err_flags = 0;
-    HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long sel = 0;
+    HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&sel, h->d_counters.p, sizeof sel, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stats.rows_selected = sel;
     if (err_flags & ERR_TABLE_FULL) {
-        HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_errp, 0, 4, h->stream));
         return fail(h, N1K_OOM, "more than %llu groups for one destination: raise the region capacity",
                     (unsigned long long)capacity_groups);
     }
@@ -1276,7 +1271,7 @@ n1k_status n1k_merge_partials_device(n1k_handle* h, uint32_t nregions, uint64_t 
     if (st != N1K_OK) return st;
     uint64_t region_words = 2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words);
     HIP_TRY(h, launch_merge_partials(h->prog, h->table, nregions, capacity_groups, (const uint64_t*)in, region_words,
-                                     h->d_err.p, h->d_counters.p + 1, h->stream));
+                                     h->d_errp, h->d_counters.p + 1, h->stream));
     h->merged_groups_bound += (uint64_t)nregions * capacity_groups;
     return N1K_OK;
 }

@@ -999,8 +999,10 @@ const std::vector<SpecEntry>& spec_registry() {
     return reg;
 }
 
-__global__ void init_table_kernel(const Program P, const GlobalTable G, uint64_t first, uint64_t count) {
+__global__ void init_table_kernel(const Program P, const GlobalTable G, uint64_t first, uint64_t count,
+                                  unsigned long long* counters) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (counters && i < 16) counters[i] = 0;  // reopen(): counters and error flags go back to zero in the same launch
     if (i >= count) return;
     uint64_t s = first + i;
     G.keys[s] = kEmptyKey;
@@ -1575,10 +1577,11 @@ __global__ void synth_kernel(SynthArgs a) {
 
 // ------------------------------------------------------------------ launchers (called by the host engine)
 
-hipError_t launch_init_table(const Program& P, const GlobalTable& G, uint64_t first, uint64_t count, hipStream_t st) {
+hipError_t launch_init_table(const Program& P, const GlobalTable& G, uint64_t first, uint64_t count,
+                             unsigned long long* counters, hipStream_t st) {
     if (count == 0) return hipSuccess;
     uint32_t blocks = (uint32_t)((count + 255) / 256);
-    hipLaunchKernelGGL(init_table_kernel, dim3(blocks), dim3(256), 0, st, P, G, first, count);
+    hipLaunchKernelGGL(init_table_kernel, dim3(blocks), dim3(256), 0, st, P, G, first, count, counters);
     return hipGetLastError();
 }
 

@@ -73,6 +73,42 @@ def gather_groups(local: np.ndarray, device=None, dst: int = 0, group=None) -> O
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, width), np.uint8)
 
 
+class FixedGather:
+    """Gather of the finished groups with ONE collective: every rank contributes a fixed-size slot
+    [count i64][records ...]; if some rank has more records than a slot holds, every rank sees it in the gathered
+    headers and all retry with larger slots."""
+
+    def __init__(self, record_bytes: int, capacity: int = 4096):
+        self.record_bytes = max(int(record_bytes), 1)
+        self.capacity = capacity
+        self._bufs = None
+
+    def __call__(self, local: np.ndarray, device, group=None) -> np.ndarray:
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        n = int(local.shape[0])
+        while True:
+            slot = 8 + self.capacity * self.record_bytes
+            if self._bufs is None or self._bufs[0].numel() != slot:
+                self._bufs = (torch.zeros(slot, dtype=torch.uint8, device=device),
+                              torch.zeros(slot * world, dtype=torch.uint8, device=device))
+            mine, allb = self._bufs
+            host = np.zeros(slot, dtype=np.uint8)
+            host[:8] = np.array([n], dtype=np.int64).view(np.uint8)
+            k = min(n, self.capacity)
+            host[8:8 + k * self.record_bytes] = local[:k].reshape(-1)
+            mine.copy_(torch.from_numpy(host))
+            dist.all_gather_into_tensor(allb, mine, group=group)
+            got = allb.cpu().numpy().reshape(world, slot)
+            counts = got[:, :8].copy().view(np.int64).reshape(world)
+            if counts.max() <= self.capacity:
+                parts = [got[r, 8:8 + int(counts[r]) * self.record_bytes].reshape(int(counts[r]), self.record_bytes)
+                         for r in range(world)]
+                return np.concatenate(parts, axis=0)
+            self.capacity = int(2 ** int(np.ceil(np.log2(counts.max()))))
+
+
 class ShardedFilterGroup:
     """One rank's share of the distributed operator (device path through libn1k.so)."""
 
@@ -113,20 +149,20 @@ class ShardedFilterGroup:
                 self._pbuf = (torch.empty(region * self.world, dtype=torch.uint8, device=dev),
                               torch.empty(region * self.world, dtype=torch.uint8, device=dev))
             send, recv = self._pbuf
-            st = lib.n1k_export_partials_device(op._h, self.world, cap, send.data_ptr())
-            if st == _ffi.OOM:  # a destination got more groups than a region holds: grow and retry (all ranks agree below)
-                grow = torch.ones(1, dtype=torch.int32, device=dev)
+            st = lib.n1k_export_partials_device(op._h, self.world, cap, send.data_ptr())  # synchronises the handle's stream
+            if st == _ffi.OOM:
+                # a destination got more groups than a region holds: tell every receiver through the region headers
+                # (word 1), so that all ranks agree to retry with larger regions without an extra collective
+                send.view(torch.int64)[1::region // 8] = 1
             else:
                 op._check(st)
-                grow = torch.zeros(1, dtype=torch.int32, device=dev)
-            dist.all_reduce(grow, op=dist.ReduceOp.MAX)
-            if int(grow.item()) == 0:
+            dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
+            overflow = int(recv.view(torch.int64)[1::region // 8].max().item())  # also orders the collective before the merge
+            if not overflow:
                 break
             self.partial_capacity *= 4
         stats = op.stats()
-        dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
-        op.reopen()                          # the owner starts from an empty table (plan, dictionary, layout stay)
-        torch.cuda.synchronize()
+        op.reopen()  # the owner starts from an empty table (plan, dictionary, key layout stay)
         op._check(lib.n1k_merge_partials_device(op._h, self.world, cap, recv.data_ptr()))
         raw = op.after_items_raw()
         return raw, {"mode": "partials", "region_bytes": region, "rows_selected": int(stats["rows_selected"])}
@@ -217,14 +253,18 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     op = ShardedFilterGroup(wl["cond"], wl["keys"], wl["aggs"], bench.synth_dictionary(args.kcat), rank, world,
                             local_rank)
     dev = torch.device("cuda", local_rank)
+    gather = None
 
     def step():
+        nonlocal gather
         raw, info = (op.run(args.rows, cols.by_path) if op.has_distinct or args.exchange == "rows"
                      else op.run_partials(args.rows, cols.by_path))
         rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
                               raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1) \
             if raw["ngroups"] else np.zeros((0, 16 * (raw["nkeys"] + raw["naggs"])), np.uint8)
-        allg = gather_groups(rec, device=dev)
+        if gather is None:
+            gather = FixedGather(rec.shape[1], capacity=max(1024, 2 * rec.shape[0]))
+        allg = gather(rec, dev)  # every rank holds the result; rank 0 reports it
         return allg, info
 
     for _ in range(args.warmup):

@@ -85,6 +85,9 @@ def _worker(rank, port, result_path):
                 flat[g, 2 + 2 * i] = v if v is not None else 0
     # 4. gather on rank 0
     allg = qd.gather_groups(rec, dst=0)
+    fixed = qd.FixedGather(rec.shape[1], capacity=4)(rec, torch.device("cpu"))  # too small on purpose: must retry
+    if rank == 0:
+        assert fixed.shape == allg.shape and np.array_equal(np.sort(fixed.view(np.int64)[:, 0]), np.sort(allg.view(np.int64)[:, 0]))
     if rank == 0:
         np.save(result_path, allg.view(np.int64))
     dist.barrier()
