@@ -464,7 +464,8 @@ static node *parse_paren(parser *p) {
     p->pos++; /* '(' */
     skipws(p);
     /* (-x)  expression/stringer.go:95-101 */
-    if (peekc(p) == '-') {
+    if (peekc(p) == '-' && !(p->pos + 1 < p->len && p->s[p->pos + 1] >= '0' && p->s[p->pos + 1] <= '9')) {
+        /* "(-5 + x)" starts with a negative literal, "(-x)" / "(-(..))" is a negation */
         p->pos++;
         node *o = parse_expr(p);
         if (!o) return NULL;

@@ -147,6 +147,61 @@ N1K_DEV uint32_t logic_or(uint64_t& st, uint32_t n) {
 // Not.Apply (expression/logic_not.go:57-69)
 N1K_DEV uint32_t logic_not(uint32_t v) { return v >= L_NULL ? v : (v ^ 1u); }
 
+// ---- NumberValue arithmetic (value/integer.go:266-352, value/float.go:331-385); a number is (tag INT|FLOAT, payload)
+struct Num {
+    uint32_t tag;
+    uint64_t p;
+};
+N1K_DEV Num num_int(int64_t v) { return Num{T_INT, (uint64_t)v}; }
+N1K_DEV Num num_flt(double v) { return Num{T_FLOAT, f64_bits(v)}; }
+// value.NewValue(float64): integral values fold to int64 (value/value.go:377-382)
+N1K_DEV Num num_new_value(double d) { return is_int_f64(d) ? num_int(go_f2i(d)) : num_flt(d); }
+// intValue.Add keeps int64 only for same-sign operands without overflow (value/integer.go:266-277)
+N1K_DEV Num num_add(Num a, Num b) {
+    if (a.tag == T_INT && b.tag == T_INT) {
+        int64_t x = (int64_t)a.p, y = (int64_t)b.p;
+        int64_t rv = (int64_t)((uint64_t)x + (uint64_t)y);
+        if ((x >= 0 && y >= 0 && rv >= 0) || (x < 0 && y < 0 && rv < 0)) return num_int(rv);
+        return num_flt((double)x + (double)y);
+    }
+    return num_flt(num_actual(a.tag, a.p) + num_actual(b.tag, b.p));
+}
+N1K_DEV Num num_neg(Num a) {  // value/integer.go:331-335
+    if (a.tag == T_FLOAT) return num_flt(-as_f64(a.p));
+    int64_t x = (int64_t)a.p;
+    if (x == INT64_MIN) return num_flt(-(double)x);
+    return num_int(-x);
+}
+N1K_DEV Num num_sub(Num a, Num b) {  // value/integer.go:337-346
+    if (a.tag == T_INT && b.tag == T_INT && (int64_t)b.p > INT64_MIN) return num_add(a, num_int(-(int64_t)b.p));
+    return num_flt(num_actual(a.tag, a.p) - num_actual(b.tag, b.p));
+}
+N1K_DEV Num num_mult(Num a, Num b) {  // value/integer.go:318-329
+    if (a.tag == T_INT && b.tag == T_INT) {
+        int64_t x = (int64_t)a.p, y = (int64_t)b.p;
+        int64_t rv = (int64_t)((uint64_t)x * (uint64_t)y);
+        if (x == 0) return num_int(rv);
+        bool trap = x == -1 && rv == INT64_MIN;  // the one division that would trap; Go: MinInt64 / -1 == MinInt64
+        if (!trap && rv / x == y) return num_int(rv);
+        if (trap && y == INT64_MIN) return num_int(rv);
+        return num_flt((double)x * (double)y);
+    }
+    return num_flt(num_actual(a.tag, a.p) * num_actual(b.tag, b.p));
+}
+// IDiv / IMod (value/integer.go:279-316, value/float.go:335-367): NULL (tag T_NULL) on a zero divisor
+N1K_DEV Num num_idiv_imod(Num a, Num b, bool mod) {
+    int64_t x = a.tag == T_FLOAT ? go_f2i(as_f64(a.p)) : (int64_t)a.p;
+    int64_t d;
+    if (b.tag == T_INT) d = (int64_t)b.p;
+    else {
+        if (as_f64(b.p) == 0.0) return Num{T_NULL, 0};
+        d = go_f2i(as_f64(b.p));
+    }
+    if (d == 0) return Num{T_NULL, 0};
+    if (x == INT64_MIN && d == -1) return num_int(mod ? 0 : INT64_MIN);
+    return num_int(mod ? x % d : x / d);
+}
+
 N1K_DEV uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
     x *= 0xff51afd7ed558ccdull;

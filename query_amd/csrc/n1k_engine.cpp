@@ -99,6 +99,11 @@ struct n1k_handle {
     std::vector<std::string> agg_names;
     bool has_distinct = false;
     uint32_t n_distinct = 0;
+    // arithmetic operands -> derived columns (input columns first, then one per arithmetic node)
+    struct Derived { uint32_t op, nops; Operand ops[4]; };
+    std::vector<Derived> derived;
+    std::vector<DevBuf<uint8_t>> dv_tags;
+    std::vector<DevBuf<uint64_t>> dv_payload;
     DevBuf<uint64_t> d_log_key[kMaxDistinct], d_log_val[kMaxDistinct], d_regions, d_set_table;
     DevBuf<uint8_t> d_log_cls[kMaxDistinct];
     uint64_t log_capacity = 0;
@@ -188,9 +193,55 @@ bool to_operand(n1k_handle* h, const Expr* e, Operand& o, PlanError& err) {
         o.cpayload = e->ctag == T_STRING ? intern(h, e->cstr) : e->cpayload;
         return true;
     }
-    err.unsupported = true;
-    err.msg = "computed operands (arithmetic / nested predicates) are not on the device path yet";
-    return false;
+    // arithmetic node -> derived column evaluated once per batch (expression/arith_*.go)
+    uint32_t op;
+    switch (e->kind) {
+        case EK::Add: op = AR_ADD; break;
+        case EK::Mult: op = AR_MULT; break;
+        case EK::Sub: op = AR_SUB; break;
+        case EK::Div: op = AR_DIV; break;
+        case EK::Mod: op = AR_MOD; break;
+        case EK::Neg: op = AR_NEG; break;
+        case EK::IDiv: op = AR_IDIV; break;
+        case EK::IMod: op = AR_IMOD; break;
+        default:
+            err.unsupported = true;
+            err.msg = "a predicate used as a value is not on the device path";
+            return false;
+    }
+    auto emit = [&](const n1k_handle::Derived& d, Operand& out) -> bool {
+        if (h->plan.paths.size() + h->derived.size() >= (size_t)kMaxCols) {
+            err.unsupported = true;
+            err.msg = "too many columns (inputs + arithmetic nodes > 16)";
+            return false;
+        }
+        memset(&out, 0, sizeof out);
+        out.is_const = 0;
+        out.col = (uint32_t)(h->plan.paths.size() + h->derived.size());
+        h->derived.push_back(d);
+        return true;
+    };
+    std::vector<Operand> ops;
+    for (auto& c : e->ch) {
+        Operand x;
+        if (!to_operand(h, c.get(), x, err)) return false;
+        if (x.is_const && x.ctag == T_STRING) h->need_rank = h->need_rank;  // strings just make the result NULL
+        ops.push_back(x);
+    }
+    // n-ary Add / Mult fold left to right, at most 4 operands per kernel: ((a+b+c+d) + e + ...)
+    size_t i = 0;
+    Operand acc{};
+    bool have_acc = false;
+    do {
+        n1k_handle::Derived d{};
+        d.op = op;
+        if (have_acc) d.ops[d.nops++] = acc;
+        while (i < ops.size() && d.nops < 4) d.ops[d.nops++] = ops[i++];
+        if (!emit(d, acc)) return false;
+        have_acc = true;
+    } while (i < ops.size());
+    o = acc;
+    return true;
 }
 
 // condition tree -> postfix over predicate terms
@@ -258,18 +309,14 @@ bool compile_cond(n1k_handle* h, const Expr* e, PlanError& err) {
         case EK::IsNotMissing: return push_term(TERM_IS_NOT_MISSING, e->ch[0].get(), nullptr, nullptr);
         case EK::IsValued: return push_term(TERM_IS_VALUED, e->ch[0].get(), nullptr, nullptr);
         case EK::IsNotValued: return push_term(TERM_IS_NOT_VALUED, e->ch[0].get(), nullptr, nullptr);
-        case EK::Path:
-        case EK::Const: return push_term(TERM_TRUTH, e, nullptr, nullptr);
-        default:
-            err.unsupported = true;
-            err.msg = "arithmetic inside a condition is not on the device path yet";
-            return false;
+        default: return push_term(TERM_TRUTH, e, nullptr, nullptr);  // a value used as a condition (incl. arithmetic)
     }
 }
 
 bool compile_plan(n1k_handle* h, PlanError& err) {
     Program& P = h->prog;
     memset(&P, 0, sizeof P);
+    h->derived.clear();
     const ParsedPlan& pl = h->plan;
     if (pl.paths.size() > (size_t)kMaxCols) { err.unsupported = true; err.msg = "more than 16 leaf paths"; return false; }
     if (pl.keys.size() > (size_t)kMaxKeys) { err.unsupported = true; err.msg = "more than 4 group keys"; return false; }
@@ -328,6 +375,7 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
     }
     P.lds_words = lds_w;
     P.glob_words = glob_w ? glob_w : 1;
+    P.ncols = (uint32_t)(pl.paths.size() + h->derived.size());  // inputs, then derived columns
     return true;
 }
 
@@ -382,7 +430,8 @@ n1k_status ensure_rank(n1k_handle* h) {
 // Decide the key bit fields once the column kinds are known (first batch).
 n1k_status fix_layout(n1k_handle* h, const n1k_batch* b) {
     Program& P = h->prog;
-    for (uint32_t c = 0; c < P.ncols; c++) h->col_kinds[c] = b->cols[c].kind;
+    for (uint32_t c = 0; c < (uint32_t)h->plan.paths.size(); c++) h->col_kinds[c] = b->cols[c].kind;
+    for (uint32_t c = (uint32_t)h->plan.paths.size(); c < P.ncols; c++) h->col_kinds[c] = N1K_COL_TAGGED64;  // derived columns
     uint32_t n_dict = 0, n_tag = 0;
     for (uint32_t k = 0; k < P.nkeys; k++) {
         KeySpec& ks = P.keys[k];
@@ -486,7 +535,7 @@ void drain_events(n1k_handle* h) {
 
 n1k_status validate_batch(n1k_handle* h, const n1k_batch* b) {
     if (!b) return fail(h, N1K_INVALID, "null batch");
-    if (b->ncols != h->prog.ncols) return fail(h, N1K_INVALID, "batch has %u columns, plan needs %u", b->ncols, h->prog.ncols);
+    if (b->ncols != (uint32_t)h->plan.paths.size()) return fail(h, N1K_INVALID, "batch has %u columns, plan needs %u", b->ncols, (uint32_t)h->plan.paths.size());
     for (uint32_t c = 0; c < b->ncols; c++) {
         const n1k_col& col = b->cols[c];
         if (col.kind == N1K_COL_DICT32) {
@@ -503,7 +552,7 @@ n1k_status validate_batch(n1k_handle* h, const n1k_batch* b) {
 
 uint64_t batch_bytes_per_row(const n1k_handle* h) {
     uint64_t b = 0;
-    for (uint32_t c = 0; c < h->prog.ncols; c++) b += h->col_kinds[c] == N1K_COL_DICT32 ? 4 : 9;
+    for (uint32_t c = 0; c < (uint32_t)h->plan.paths.size(); c++) b += h->col_kinds[c] == N1K_COL_DICT32 ? 4 : 9;
     return b;
 }
 
@@ -777,6 +826,46 @@ n1k_status run_filter_batch(n1k_handle* h, const n1k_batch* b) {
     return N1K_OK;
 }
 
+// Point the program at this batch's input columns and evaluate the arithmetic nodes into derived columns.
+n1k_status bind_columns(n1k_handle* h, const n1k_batch* b) {
+    Program& P = h->prog;
+    const uint32_t ni = (uint32_t)h->plan.paths.size();
+    for (uint32_t c = 0; c < ni; c++) {
+        P.cols[c].kind = b->cols[c].kind == N1K_COL_DICT32 ? COLK_DICT32 : COLK_TAGGED64;
+        P.cols[c].tags = b->cols[c].tags;
+        P.cols[c].payload = b->cols[c].payload;
+        P.cols[c].codes = b->cols[c].codes;
+    }
+    P.dict_size = (uint32_t)h->dict.size();
+    P.empty_str_code = lookup_code(h, "");
+    P.empty_arr_code = lookup_code(h, "[]");
+    P.empty_obj_code = lookup_code(h, "{}");
+    if (h->derived.empty()) return N1K_OK;
+    h->dv_tags.resize(h->derived.size());
+    h->dv_payload.resize(h->derived.size());
+    for (size_t i = 0; i < h->derived.size(); i++) {
+        // an earlier launch may still read the previous batch's derived columns
+        if (h->dv_tags[i].n < b->nrows) HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, h->dv_tags[i].ensure(std::max<uint64_t>(b->nrows, 1)));
+        HIP_TRY(h, h->dv_payload[i].ensure(std::max<uint64_t>(b->nrows, 1)));
+        ArithArgs A{};
+        A.op = h->derived[i].op;
+        A.nops = h->derived[i].nops;
+        for (uint32_t k = 0; k < A.nops; k++) A.ops[k] = h->derived[i].ops[k];
+        for (uint32_t c = 0; c < ni + i; c++) A.cols[c] = P.cols[c];
+        A.nrows = b->nrows;
+        A.out_tags = h->dv_tags[i].p;
+        A.out_payload = h->dv_payload[i].p;
+        HIP_TRY(h, launch_arith(A, h->stream));
+        DevCol& d = P.cols[ni + i];
+        d.kind = COLK_TAGGED64;
+        d.tags = A.out_tags;
+        d.payload = A.out_payload;
+        d.codes = nullptr;
+    }
+    return N1K_OK;
+}
+
 n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
     n1k_status st = ensure_device(h);
@@ -788,16 +877,8 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
         if (st != N1K_OK) return st;
     }
     Program& P = h->prog;
-    for (uint32_t c = 0; c < P.ncols; c++) {
-        P.cols[c].kind = b->cols[c].kind == N1K_COL_DICT32 ? COLK_DICT32 : COLK_TAGGED64;
-        P.cols[c].tags = b->cols[c].tags;
-        P.cols[c].payload = b->cols[c].payload;
-        P.cols[c].codes = b->cols[c].codes;
-    }
-    P.dict_size = (uint32_t)h->dict.size();
-    P.empty_str_code = lookup_code(h, "");
-    P.empty_arr_code = lookup_code(h, "[]");
-    P.empty_obj_code = lookup_code(h, "{}");
+    st = bind_columns(h, b);
+    if (st != N1K_OK) return st;
     st = ensure_rank(h);
     if (st != N1K_OK) return st;
     if (b->nrows) {
@@ -870,6 +951,8 @@ void n1k_destroy(n1k_handle* h) {
         h->d_acc.release();
         h->d_rep.release();
         h->d_slabs.release();
+        for (auto& b : h->dv_tags) b.release();
+        for (auto& b : h->dv_payload) b.release();
         h->d_regions.release();
         h->d_set_table.release();
         for (uint32_t d = 0; d < kMaxDistinct; d++) {
@@ -1183,20 +1266,15 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
     }
     Program& P = h->prog;
     PartArgs A{};
-    for (uint32_t c = 0; c < P.ncols; c++) {
-        P.cols[c].kind = batch->cols[c].kind == N1K_COL_DICT32 ? COLK_DICT32 : COLK_TAGGED64;
-        P.cols[c].tags = batch->cols[c].tags;
-        P.cols[c].payload = batch->cols[c].payload;
-        P.cols[c].codes = batch->cols[c].codes;
+    st = bind_columns(h, batch);
+    if (st != N1K_OK) return st;
+    A.ncopy = (uint32_t)h->plan.paths.size();  // derived columns are recomputed by the receiver
+    for (uint32_t c = 0; c < A.ncopy; c++) {
         if (out_cols[c].kind != batch->cols[c].kind) return fail(h, N1K_INVALID, "output column %u has another kind", c);
         A.out_tags[c] = (uint8_t*)out_cols[c].tags;
         A.out_payload[c] = (uint64_t*)out_cols[c].payload;
         A.out_codes[c] = (uint32_t*)out_cols[c].codes;
     }
-    P.dict_size = (uint32_t)h->dict.size();
-    P.empty_str_code = lookup_code(h, "");
-    P.empty_arr_code = lookup_code(h, "[]");
-    P.empty_obj_code = lookup_code(h, "{}");
     st = ensure_rank(h);
     if (st != N1K_OK) return st;
     A.nrows = batch->nrows;

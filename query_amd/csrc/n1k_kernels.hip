@@ -199,6 +199,75 @@ N1K_DEV void eval_predicate(const Program& P, const uint64_t (&row)[R], const bo
     for (int j = 0; j < R; j++) pass[j] = valid[j] && (P.nlogic == 0 || (st[j] & 3ull) == L_TRUE);
 }
 
+// ------------------------------------------------------------------ derived columns (arithmetic operands)
+//
+// Add/Mult.Apply (expression/arith_add.go:51-70, arith_mult.go:51-70): any MISSING operand -> MISSING, else any
+// non-number -> NULL, else the fold from int 0 / int 1.  Sub/Div/Mod/IDiv/IMod/Neg: arith_sub.go:53-61,
+// arith_div.go:46-64, arith_mod.go:48-66, arith_idiv.go:46-56, arith_imod.go, arith_neg.go:51-59.
+__global__ void arith_kernel(const ArithArgs A) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.nrows) return;
+    uint32_t tg[4];
+    uint64_t pv[4];
+    for (uint32_t k = 0; k < A.nops; k++) {
+        const Operand& o = A.ops[k];
+        if (o.is_const) {
+            tg[k] = o.ctag;
+            pv[k] = o.cpayload;
+        } else {
+            const DevCol& c = A.cols[o.col];
+            if (c.kind == COLK_DICT32) {
+                uint32_t code = c.codes[i];
+                tg[k] = code == 0xFFFFFFFFu ? (uint32_t)T_MISSING : (code == 0xFFFFFFFEu ? (uint32_t)T_NULL : (uint32_t)T_STRING);
+                pv[k] = code;
+            } else {
+                tg[k] = c.tags[i];
+                pv[k] = c.payload[i];
+            }
+        }
+    }
+    auto is_num = [](uint32_t t) { return t == T_INT || t == T_FLOAT; };
+    uint32_t rt = T_NULL;
+    uint64_t rp = 0;
+    if (A.op == AR_ADD || A.op == AR_MULT) {
+        bool null = false, missing = false;
+        Num acc = num_int(A.op == AR_ADD ? 0 : 1);
+        for (uint32_t k = 0; k < A.nops; k++) {
+            if (!null && is_num(tg[k])) acc = A.op == AR_ADD ? num_add(acc, Num{tg[k], pv[k]}) : num_mult(acc, Num{tg[k], pv[k]});
+            else if (tg[k] == T_MISSING) missing = true;
+            else null = true;
+        }
+        if (missing) rt = T_MISSING;
+        else if (null) rt = T_NULL;
+        else { rt = acc.tag; rp = acc.p; }
+    } else if (A.op == AR_NEG) {
+        if (is_num(tg[0])) { Num r = num_neg(Num{tg[0], pv[0]}); rt = r.tag; rp = r.p; }
+        else rt = tg[0] == T_MISSING ? (uint32_t)T_MISSING : (uint32_t)T_NULL;
+    } else {
+        bool both = is_num(tg[0]) && is_num(tg[1]);
+        if (tg[0] == T_MISSING || tg[1] == T_MISSING) rt = T_MISSING;
+        else if (A.op == AR_SUB) {
+            if (both) { Num r = num_sub(Num{tg[0], pv[0]}, Num{tg[1], pv[1]}); rt = r.tag; rp = r.p; }
+        } else if (A.op == AR_DIV || A.op == AR_MOD) {
+            if (is_num(tg[1])) {
+                double d = num_actual(tg[1], pv[1]);
+                if (d != 0.0 && is_num(tg[0])) {
+                    double x = num_actual(tg[0], pv[0]);
+                    Num r = num_new_value(A.op == AR_DIV ? x / d : fmod(x, d));
+                    rt = r.tag;
+                    rp = r.p;
+                }
+            }
+        } else if (both) {  // IDIV / IMOD
+            Num r = num_idiv_imod(Num{tg[0], pv[0]}, Num{tg[1], pv[1]}, A.op == AR_IMOD);
+            rt = r.tag;
+            rp = r.p;
+        }
+    }
+    A.out_tags[i] = (uint8_t)rt;
+    A.out_payload[i] = rp;
+}
+
 // ------------------------------------------------------------------ hash tables
 
 // The workgroup's LDS table is word-major: word w of slot s lives at lds[w * S + s] (consecutive slots fall
@@ -1071,7 +1140,7 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
                 }
             }
         }
-        for (uint32_t c = 0; c < P.ncols; c++) {
+        for (uint32_t c = 0; c < A.ncopy; c++) {
             Operand o{};
             o.is_const = 0;
             o.col = c;
@@ -1671,6 +1740,13 @@ hipError_t launch_merge_partials(const Program& P, const GlobalTable& G, uint32_
     if (!total) return hipSuccess;
     uint32_t blocks = (uint32_t)((total + 255) / 256);
     hipLaunchKernelGGL(merge_partials_kernel, dim3(blocks), dim3(256), 0, st, P, G, nregions, cap, in, region_words, err_flags, ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_arith(const ArithArgs& A, hipStream_t st) {
+    if (A.nrows == 0) return hipSuccess;
+    uint32_t blocks = (uint32_t)((A.nrows + 255) / 256);
+    hipLaunchKernelGGL(arith_kernel, dim3(blocks), dim3(256), 0, st, A);
     return hipGetLastError();
 }
 

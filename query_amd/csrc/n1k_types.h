@@ -211,10 +211,22 @@ struct FastArgs {
     uint64_t* slabs;  // when non-null: workgroup b stores its LDS table at slabs[b * lds_words * S ..] instead of merging
 };
 
+// derived columns: arithmetic nodes of the plan are evaluated once per batch by an element-wise kernel into a
+// temporary TAGGED64 column; the scan kernels then see them as ordinary columns
+enum : uint32_t { AR_ADD = 0, AR_MULT, AR_SUB, AR_DIV, AR_MOD, AR_NEG, AR_IDIV, AR_IMOD };
+struct ArithArgs {
+    uint32_t op, nops;
+    Operand ops[4];
+    DevCol cols[kMaxCols];
+    uint64_t nrows;
+    uint8_t* out_tags;
+    uint64_t* out_payload;
+};
+
 struct PartArgs {
     uint64_t nrows;
     uint64_t capacity;  // rows per destination region
-    uint32_t nparts, pad;
+    uint32_t nparts, ncopy;      // ncopy: number of (input) columns shipped
     unsigned long long* counts;  // nparts counters (rows written per destination)
     uint32_t* err_flags;
     uint8_t* out_tags[kMaxCols];

@@ -233,6 +233,27 @@ def test_distinct_over_mixed_types_and_edge_values():
         pu.assert_same_groups(gpu, ora, aggs=aggs)
 
 
+ARITH_CASES = [
+    # (condition, keys, aggregates)
+    ("(100 < (%s + %s))" % (D("price"), D("region_id")), [D("cat")], ["count(*)", "sum((%s * %s))" % (D("price"), D("region_id"))]),
+    ("((%s * 2) < 51)" % D("price"), [D("cat")], ["avg((%s - 10))" % D("price"), "max((-%s))" % D("price")]),
+    (None, ["(%s %% 4)" % D("region_id")], ["sum((%s / 4))" % D("price"), "min((%s / (%s - 7)))" % (D("price"), D("region_id"))]),
+    (None, ["idiv(%s, 1000)" % D("user_id"), "imod(%s, 3)" % D("region_id")], ["count(*)", "sum((%s + %s + %s + %s + %s))" % ((D("region_id"),) * 5)]),
+    ("(((%s + 1) * (%s + 1)) between 100 and 2000)" % (D("region_id"), D("price")), [], ["count(*)", "countn((%s + %s))" % (D("price"), D("cat"))]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(ARITH_CASES)))
+def test_arithmetic_operands_as_derived_columns(case):
+    """expression/arith_*.go on the device: arithmetic nodes become derived columns (element-wise kernel per node)."""
+    cond, keys, aggs = ARITH_CASES[case]
+    aggs = sorted(aggs)
+    t = n1o.synth_table(70_000, k_cat=12)
+    ora = n1o.run(t, cond, keys, aggs)
+    gpu, _ = pu.run_gpu(t, cond, keys, aggs, batches=2)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+
+
 def test_filter_only_selected_rows():
     t = n1o.synth_table(100_003, k_cat=10)
     for cond in ["(50 < %s)" % D("price"), "(%s is missing)" % D("price"), "(%s = \"cat_3\")" % D("cat")]:
