@@ -30,6 +30,11 @@ namespace n1k {
         static constexpr SpecAgg aggs[kFastAggs] = {A0, A1, A2, A3, A4};                                      \
     }
 
+// flag bits: fire-and-forget ds_or (no LDS read, so the row loop never waits on lgkmcnt)
+#ifndef SPEC_FLAG
+#define SPEC_FLAG(ptr, bit) lds_or_u64((ptr), (bit))
+#endif
+
 template <class Spec>
 N1K_DEV bool spec_term_true(int t, const FastArgs& F, uint32_t tg, uint64_t p) {
     constexpr int kT = kFastTerms;
@@ -85,11 +90,11 @@ N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32
             int64_t x = (int64_t)p;
             if (x >= (1ll << 40) || x <= -(1ll << 40)) return false;
             lds_add_u64(w, (unsigned long long)x);
-            lds_set_flag(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
+            SPEC_FLAG(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
         } else if (tag == T_FLOAT) {
             lds_add_f64(w + S, as_f64(p));
-            lds_set_flag(w + 2 * S, (unsigned long long)SF_FLOAT);
+            SPEC_FLAG(w + 2 * S, (unsigned long long)SF_FLOAT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
         }
         return true;
@@ -139,13 +144,13 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
         slot += f * F.keys[k].stride;
     }
     selected++;
-    if (lds_peek(lds_word(lds, slot)) == kEmptyKey) *(volatile lds_u64*)lds_word(lds, slot) = 1ull;
+    *(volatile lds_u64*)lds_word(lds, slot) = 1ull;  // "touched": every writer stores the same value, nobody reads it here
 #pragma unroll
     for (int a = 0; a < Spec::naggs; a++) {
         const uint32_t c = Spec::aggs[a].has_operand ? Spec::aggs[a].col : 0u;
         const uint32_t t = Spec::aggs[a].has_operand ? tg[c] : (uint32_t)T_NULL;
         const uint64_t p = Spec::aggs[a].has_operand ? pv[c] : 0ull;
-        if (!spec_acc<Spec>(a, P, lds, S, slot, t, p)) {
+        if (!spec_acc<Spec>(a, P, lds, S, slot, t, p)) {  // rare: an integer too large for the narrow LDS sum
             long long g = global_find_or_insert(G, fast_slot_key(F, slot), F.err_flags, ngroups);
             if (g >= 0) acc_global(P, P.aggs[a], &G.acc[(size_t)g * P.glob_words], t, p);
         }

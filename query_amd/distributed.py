@@ -161,11 +161,13 @@ class ShardedFilterGroup:
             if not overflow:
                 break
             self.partial_capacity *= 4
+        op.sync()  # drains the HIP events: stats now hold this step's scan time
         stats = op.stats()
         op.reopen()  # the owner starts from an empty table (plan, dictionary, key layout stay)
         op._check(lib.n1k_merge_partials_device(op._h, self.world, cap, recv.data_ptr()))
         raw = op.after_items_raw()
-        return raw, {"mode": "partials", "region_bytes": region, "rows_selected": int(stats["rows_selected"])}
+        return raw, {"mode": "partials", "region_bytes": region, "rows_selected": int(stats["rows_selected"]),
+                     "scan_ms": float(stats["device_ms"]), "spec_kernel": int(stats["spec_kernel"])}
 
     def _alloc(self, capacity: int, kinds: Sequence[int]):
         import torch
@@ -298,7 +300,14 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                    (args.workload, wl["sql"], args.rows, world, args.kcat,
                                     "partial groups" if info.get("mode") == "partials" else "filtered rows"),
                        "rows_per_gpu": args.rows, "groups": int(allg.shape[0]) if allg is not None else None,
-                       "exchange_rows_rank0": info},
+                       "exchange_rank0": info},
         }
+        if info.get("scan_ms"):
+            alg = wl["bytes_per_row"] * args.rows
+            ach = alg / (info["scan_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / bench.HBM_PEAK_GBS, "traffic": None, "kernel_ms": info["scan_ms"],
+                               "kernel": "rank 0: scan_spec_kernel(+merge_slabs_kernel)" if info.get("spec_kernel")
+                               else "rank 0: scan kernel", "algorithmic_bytes_per_launch": alg}
         print(json.dumps(out))
     dist.destroy_process_group()
