@@ -69,7 +69,6 @@ class DeviceColumns:
     def __init__(self, nrows: int, k_cat: int, zipf: bool, first_row: int, total_rows: int, device: int):
         import torch
         from query_amd import _ffi
-        from oracle import n1o  # only for the zipf cdf table (data, 8 KB)
         dev = torch.device("cuda", device)
         self.nrows = nrows
         self.cat = torch.empty(nrows, dtype=torch.int32, device=dev)
@@ -79,7 +78,7 @@ class DeviceColumns:
         self.user_p = torch.empty(nrows, dtype=torch.int64, device=dev)
         self.region_t = torch.empty(nrows, dtype=torch.uint8, device=dev)
         self.region_p = torch.empty(nrows, dtype=torch.int64, device=dev)
-        cdf = torch.from_numpy(n1o.zipf_cdf(k_cat)).to(dev) if zipf else None
+        cdf = torch.from_numpy(zipf_cdf(k_cat)).to(dev) if zipf else None
         spec = _ffi.SynthSpec(SEED, first_row, nrows, total_rows, k_cat, 1 if zipf else 0,
                               cdf.data_ptr() if zipf else None)
         st = _ffi.lib().n1k_synth_columns(device, None, C.byref(spec), self.cat.data_ptr(), self.price_t.data_ptr(),
@@ -95,6 +94,21 @@ class DeviceColumns:
             D("user_id"): (f.COL_TAGGED64, self.user_t.data_ptr(), self.user_p.data_ptr(), None),
             D("region_id"): (f.COL_TAGGED64, self.region_t.data_ptr(), self.region_p.data_ptr(), None),
         }
+
+
+def zipf_cdf(k: int):
+    """Zipf(s=1) cdf over k categories, same sequential float64 arithmetic as the C generators."""
+    import numpy as np
+    h = 0.0
+    for i in range(k):
+        h += 1.0 / float(i + 1)
+    acc, out = 0.0, np.zeros(k, dtype=np.float64)
+    for i in range(k):
+        acc += (1.0 / float(i + 1)) / h
+        out[i] = acc
+    if k:
+        out[k - 1] = 1.0
+    return out
 
 
 def synth_dictionary(k_cat: int):

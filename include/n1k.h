@@ -217,10 +217,10 @@ n1k_status n1k_dict_get(const n1k_handle *h, uint32_t code, const char **ptr, si
 
 /* ---------------------------------------------------------------- options -- */
 
-/* name ∈ {"agg_mode" (n1k_agg_mode), "max_groups" (capacity hint, default 1<<22),
- *         "grid_blocks" (0 = auto), "device" (ordinal; before the first push),
- *         "compact" (0/1: LDS-staged compaction of filter survivors),
- *         "wave_reduce" (0/1: wavefront pre-reduction of equal keys)} */
+/* name ∈ {"device" (ordinal) | "stream" (hipStream_t) | "rep_row" (0/1): before the first push;
+ *         "max_groups" (group-table capacity bound, default 1<<22), "agg_mode" (n1k_agg_mode),
+ *         "grid_blocks" / "block" / "rows_per_lane" / "lds_bytes" (launch tuning, 0 = auto),
+ *         "fast" / "spec" / "wide" / "slabs" (0/1: kernel selection switches used by the ablation tests)} */
 n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);
 
 /* ----------------------------------------------------------------- data ---- */

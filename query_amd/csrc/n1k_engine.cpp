@@ -76,7 +76,7 @@ struct n1k_handle {
     int64_t opt_agg_mode = N1K_MODE_AUTO;
     uint64_t opt_max_groups = 1ull << 22;
     uint32_t opt_grid_blocks = 0;
-    uint32_t opt_compact = 1, opt_wave_reduce = 1, opt_rep_row = 0;
+    uint32_t opt_rep_row = 0;
     uint32_t opt_lds_bytes = 64 * 1024;   // HASH mode: LDS table bytes per workgroup
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     int device = -1;
@@ -781,8 +781,6 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     A.lds_max_fill = std::max(1u, (uint32_t)((uint64_t)slots * 5 / 8));
     A.err_flags = h->d_errp;
     A.rows_selected = h->d_counters.p + 0;
-    A.wave_reduce = h->opt_wave_reduce;
-    A.compact = h->opt_compact;
     uint64_t tile_rows = (uint64_t)block * rpl;
     uint64_t ntiles = (b->nrows + tile_rows - 1) / tile_rows;
     uint32_t per_cu = block == 1024 ? 1 : (block == 512 ? 2 : 4);
@@ -804,9 +802,11 @@ n1k_status run_filter_batch(n1k_handle* h, const n1k_batch* b) {
     HIP_TRY(h, h->d_mask.ensure(ntiles * (kFilterTile / 64)));
     HIP_TRY(h, h->d_tile_cnt.ensure(ntiles));
     HIP_TRY(h, h->d_tile_off.ensure(ntiles));
-    uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)h->num_cus * 8);
+    uint64_t nchunks = (b->nrows + 1023) / 1024;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nchunks, (uint64_t)h->num_cus * 8);
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
     if (e0) (void)hipEventRecord(e0, h->stream);
+    HIP_TRY(h, hipMemsetAsync(h->d_tile_cnt.p, 0, ntiles * sizeof(uint32_t), h->stream));
     HIP_TRY(h, launch_filter_mask(P, b->nrows, h->d_mask.p, h->d_tile_cnt.p, h->d_errp, grid, h->stream));
     HIP_TRY(h, launch_tile_scan(h->d_tile_cnt.p, h->d_tile_off.p, ntiles, h->d_counters.p + 3, h->stream));
     unsigned long long total = 0;
@@ -814,12 +814,15 @@ n1k_status run_filter_batch(n1k_handle* h, const n1k_batch* b) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (total) {
         HIP_TRY(h, h->d_sel.ensure(total));
-        HIP_TRY(h, launch_filter_compact(h->d_mask.p, h->d_tile_off.p, b->nrows, h->row_base, h->d_sel.p, grid, h->stream));
+        uint32_t cgrid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)h->num_cus * 8);
+        HIP_TRY(h, launch_filter_compact(h->d_mask.p, h->d_tile_off.p, b->nrows, h->row_base, h->d_sel.p, cgrid, h->stream));
+        if (e1) (void)hipEventRecord(e1, h->stream);  // device time excludes the PCIe copy of the ordinals
         size_t old = h->selected.size();
         h->selected.resize(old + total);
         HIP_TRY(h, hipMemcpyAsync(h->selected.data() + old, h->d_sel.p, total * 8, hipMemcpyDeviceToHost, h->stream));
+    } else if (e1) {
+        (void)hipEventRecord(e1, h->stream);
     }
-    if (e1) (void)hipEventRecord(e1, h->stream);
     h->events.emplace_back(e0, e1);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stats.rows_selected += total;
@@ -1038,8 +1041,6 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     if (n == "agg_mode") h->opt_agg_mode = value;
     else if (n == "max_groups") h->opt_max_groups = value > 0 ? (uint64_t)value : 1;
     else if (n == "grid_blocks") h->opt_grid_blocks = (uint32_t)std::max<int64_t>(0, value);
-    else if (n == "compact") h->opt_compact = value ? 1 : 0;
-    else if (n == "wave_reduce") h->opt_wave_reduce = value ? 1 : 0;
     else if (n == "fast") h->opt_fast = value ? 1 : 0;
     else if (n == "spec") h->opt_spec = value ? 1 : 0;
     else if (n == "wide") h->opt_wide = value ? 1 : 0;

@@ -6,7 +6,7 @@
 
 namespace n1k {
 
-constexpr int kFilterTile = 256;  // rows per tile of the Filter-only path
+constexpr int kFilterTile = 4096;  // rows per tile of the Filter-only path (64 ballot words)
 
 struct OutValue {  // same 16-byte layout as n1k_value
     uint64_t tag;  // low byte = tag (little endian), rest zero

@@ -1501,31 +1501,36 @@ __global__ void finalize_kernel(const Program P, const GlobalTable G, OutValue* 
 }
 
 // ------------------------------------------------------------------ Filter alone: mask, scan, compaction
-
-// K1: one bit per row through a wave ballot; per-tile survivor counts.  Tile = FILTER_TILE rows.
-template <int BLOCK>
+//
+// Filter.processItem forwards the rows whose condition is TRUE, in input order (execution/filter.go:49-61).
+// K1: every wave evaluates 64 x R consecutive rows and stores one ballot word per 64 rows (1 bit/row) plus a
+//     survivor count per tile of kFilterTile rows.  K2 (after an exclusive scan of the tile counts): LDS-staged,
+//     ordered stream compaction of the set bits into row ordinals.
+template <int R, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void filter_mask_kernel(const Program P, uint64_t nrows, uint64_t* mask_words,
                                                            uint32_t* tile_counts, uint32_t* err_flags) {
-    __shared__ uint32_t wave_cnt[BLOCK / 64];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t unsupported = 0;
-    const uint64_t ntiles = (nrows + BLOCK - 1) / BLOCK;
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        uint64_t row[1] = {tile * BLOCK + tid};
-        bool valid[1] = {row[0] < nrows}, pass[1];
-        eval_predicate<1>(P, row, valid, pass, unsupported);
-        unsigned long long b = __ballot(pass[0]);
-        if ((tid & 63) == 0) {
-            mask_words[row[0] >> 6] = b;
-            wave_cnt[tid >> 6] = (uint32_t)__popcll(b);
+    const uint64_t chunk_rows = (uint64_t)BLOCK * R;
+    const uint64_t nchunks = (nrows + chunk_rows - 1) / chunk_rows;
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint64_t wave_base = chunk * chunk_rows + (uint64_t)wave * 64 * R;
+        uint64_t row[R];
+        bool valid[R], pass[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            row[j] = wave_base + (uint64_t)j * 64 + lane;
+            valid[j] = row[j] < nrows;
         }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t c = 0;
-            for (int w = 0; w < BLOCK / 64; w++) c += wave_cnt[w];
-            tile_counts[tile] = c;
+        eval_predicate<R>(P, row, valid, pass, unsupported);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            unsigned long long b = __ballot(pass[j]);
+            cnt += (uint32_t)__popcll(b);
+            if (lane == 0 && wave_base + (uint64_t)j * 64 < nrows) mask_words[(wave_base >> 6) + j] = b;
         }
-        __syncthreads();
+        if (lane == 0 && cnt) atomicAdd(&tile_counts[wave_base / kFilterTile], cnt);  // 64*R divides kFilterTile
     }
     if (unsupported) atomicOr(err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
 }
@@ -1557,23 +1562,37 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* counts,
     if (tid == 0) *total = carry;
 }
 
-// K2: ordered compaction: row ordinals of the set bits, ascending
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void filter_compact_kernel(const uint64_t* mask_words, const uint64_t* tile_offsets,
-                                                              uint64_t nrows, uint64_t row_base, uint64_t* out_rows) {
-    __shared__ uint32_t wave_off[BLOCK / 64];
+// K2: one workgroup per tile of kFilterTile rows (64 mask words): word offsets through LDS, then every lane
+// writes the ordinal of its set bit at its rank -> ascending, densely packed output
+__global__ __launch_bounds__(256) void filter_compact_kernel(const uint64_t* mask_words, const uint64_t* tile_offsets,
+                                                            uint64_t nrows, uint64_t row_base, uint64_t* out_rows) {
+    __shared__ uint32_t word_off[kFilterTile / 64];
+    __shared__ uint64_t words[kFilterTile / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t ntiles = (nrows + BLOCK - 1) / BLOCK;
+    const uint64_t ntiles = (nrows + kFilterTile - 1) / kFilterTile;
+    constexpr uint32_t kWords = kFilterTile / 64;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        uint64_t row = tile * BLOCK + tid;
-        uint64_t word = (tile * BLOCK + (uint64_t)wave * 64) < nrows ? mask_words[(tile * BLOCK >> 6) + wave] : 0ull;
-        if (lane == 0) wave_off[wave] = (uint32_t)__popcll(word);
+        const uint64_t first_word = tile * kWords;
+        if (tid < kWords) {
+            uint64_t w = (first_word + tid) * 64 < nrows ? mask_words[first_word + tid] : 0ull;
+            words[tid] = w;
+            // exclusive scan of the 64 popcounts inside wave 0
+            uint32_t c = (uint32_t)__popcll(w), incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t t = __shfl_up(incl, off, 64);
+                if ((int)lane >= off) incl += t;
+            }
+            word_off[tid] = incl - c;
+        }
         __syncthreads();
-        uint32_t before = 0;
-        for (uint32_t w = 0; w < wave; w++) before += wave_off[w];
-        bool set = (word >> lane) & 1ull;
-        uint32_t rank = (uint32_t)__popcll(word & ((1ull << lane) - 1ull));
-        if (set) out_rows[tile_offsets[tile] + before + rank] = row_base + row;
+        const uint64_t out_base = tile_offsets[tile];
+        for (uint32_t w = wave; w < kWords; w += 256 / 64) {
+            uint64_t m = words[w];
+            if ((m >> lane) & 1ull) {
+                uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                out_rows[out_base + word_off[w] + rank] = row_base + (first_word + w) * 64 + lane;
+            }
+        }
         __syncthreads();
     }
 }
@@ -1766,8 +1785,8 @@ hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out
 
 hipError_t launch_filter_mask(const Program& P, uint64_t nrows, uint64_t* mask_words, uint32_t* tile_counts,
                               uint32_t* err_flags, uint32_t grid, hipStream_t st) {
-    hipLaunchKernelGGL((filter_mask_kernel<kFilterTile>), dim3(grid), dim3(kFilterTile), 0, st, P, nrows, mask_words,
-                       tile_counts, err_flags);
+    hipLaunchKernelGGL((filter_mask_kernel<4, 256>), dim3(grid), dim3(256), 0, st, P, nrows, mask_words, tile_counts,
+                       err_flags);
     return hipGetLastError();
 }
 
@@ -1779,8 +1798,8 @@ hipError_t launch_tile_scan(const uint32_t* counts, uint64_t* offsets, uint64_t 
 
 hipError_t launch_filter_compact(const uint64_t* mask_words, const uint64_t* tile_offsets, uint64_t nrows,
                                  uint64_t row_base, uint64_t* out_rows, uint32_t grid, hipStream_t st) {
-    hipLaunchKernelGGL((filter_compact_kernel<kFilterTile>), dim3(grid), dim3(kFilterTile), 0, st, mask_words,
-                       tile_offsets, nrows, row_base, out_rows);
+    hipLaunchKernelGGL(filter_compact_kernel, dim3(grid), dim3(256), 0, st, mask_words, tile_offsets, nrows, row_base,
+                       out_rows);
     return hipGetLastError();
 }
 

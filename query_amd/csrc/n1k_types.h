@@ -156,8 +156,6 @@ struct ScanArgs {
     uint32_t direct_radix[kMaxKeys];
     uint32_t* err_flags;      // device word, OR of ERR_*
     unsigned long long* rows_selected;  // device counter
-    uint32_t wave_reduce;
-    uint32_t compact;
     // DISTINCT pair logs (one per DISTINCT aggregate): (group key, value, class) of every qualifying operand
     uint64_t* log_key[kMaxDistinct];
     uint64_t* log_val[kMaxDistinct];

@@ -48,6 +48,7 @@ def main():
                 variants.append(("config2 spec b%d g%d slabs%d" % (block, grid, slabs), c2[0], c2[1], c2[2],
                                  {"block": block, "grid_blocks": grid, "slabs": slabs}, False))
         variants += [
+            ("filter-only", c2[0], [], [], {}, True),
             ("config2 fast(no spec)", c2[0], c2[1], c2[2], {"spec": 0}, False),
             ("config2 interp direct", c2[0], c2[1], c2[2], {"fast": 0}, False),
             ("nofilter sum", None, [D("cat")], ["sum(%s)" % D("price")], {}, False),
