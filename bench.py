@@ -169,12 +169,12 @@ def main():
         k, v = o.split("=")
         op.set_option(k, int(v))
     op.intern(synth_dictionary(args.kcat))
-    batch = [cols.by_path[p] for p in op.column_paths]
+    batch = op.make_device_batch(args.rows, [cols.by_path[p] for p in op.column_paths])
 
     def step():
-        op.reopen()
-        op.process_device_items(args.rows, batch)
-        return op.after_items_raw()
+        op.reopen()                     # n1k_reset: groups dropped (one kernel, no host sync)
+        op.process_device_batch(batch)  # n1k_push_device_batch: scan (+ merge) kernels, asynchronous
+        return op.after_items_raw()     # n1k_finish: FinalGroup + groups copied to the host (one sync)
 
     for _ in range(args.warmup):
         rows = step()

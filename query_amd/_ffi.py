@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libn1k.so")
+LIB_PATH = os.environ.get("N1K_LIB") or os.path.join(_HERE, "libn1k.so")  # N1K_LIB: ablation builds only
 
 # n1k_status
 OK, UNSUPPORTED, EVAL_ERROR, DEVICE_ERROR, OOM, STOPPED, INVALID, UNSUPPORTED_DATA = range(8)

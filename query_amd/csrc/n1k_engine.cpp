@@ -111,6 +111,7 @@ struct n1k_handle {
     // device state
     GlobalTable table{};
     DevBuf<uint64_t> d_keys, d_acc, d_rep, d_slabs;
+    DevBuf<unsigned long long> d_block_sel;
     uint32_t* d_errp = nullptr;  // lives inside d_counters ([12]) so one copy reads counters and flags
     DevBuf<unsigned long long> d_counters;  // [0] rows_selected [1] ngroups [2] out_count [3] filter total [4] rehash scratch
                                             // [5] distinct region words [8..11] pair-log cursors
@@ -586,22 +587,34 @@ bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F) {
             ft.op = TERM_STR_EQ; ft.col = c->col; ft.ctag = T_STRING; ft.cpayload = k->cpayload;
         } else return false;
     }
-    // keys: dictionary columns with a domain that fits the LDS table
+    // keys: dictionary columns whose domain fits the LDS table are addressed by perfect hash (DIRECT); anything else
+    // (integer keys, big dictionaries) goes through an open-addressed LDS table on the packed key (hashed)
     uint64_t domain = 1;
+    bool direct = true;
     F.nkeys = P.nkeys;
     for (uint32_t k = 0; k < P.nkeys; k++) {
         const KeySpec& ks = P.keys[k];
-        if (ks.mode != KEYM_DICT || ks.src.is_const) return false;
+        if (ks.src.is_const) return false;
+        F.keys[k].col = ks.src.col;
+        F.keys[k].shift = ks.shift;
+        if (ks.mode != KEYM_DICT) { direct = false; continue; }
         uint64_t radix = (uint64_t)h->dict.size() + 2;
         if (ks.bits < 64 && radix > (1ull << ks.bits)) return false;
-        F.keys[k].col = ks.src.col;
-        F.keys[k].stride = (uint32_t)domain;
+        F.keys[k].stride = (uint32_t)std::min<uint64_t>(domain, 0xFFFFFFFFull);
         F.keys[k].radix = (uint32_t)radix;
-        F.keys[k].shift = ks.shift;
         domain *= radix;
-        if (domain > max_slots) return false;
+        if (domain > max_slots) direct = false;
     }
-    F.lds_slots = (uint32_t)std::max<uint64_t>(domain, 2);
+    if (direct) {
+        F.hashed = 0;
+        F.lds_slots = (uint32_t)std::max<uint64_t>(domain, 2);
+    } else {
+        F.hashed = 1;
+        uint32_t slots = (uint32_t)std::min<uint64_t>(h->opt_lds_bytes / (P.lds_words * 8), 1u << 15);
+        if (slots < 16) return false;
+        F.lds_slots = slots;
+        F.lds_max_fill = std::max(1u, (uint32_t)((uint64_t)slots * 5 / 8));
+    }
     F.naggs = P.naggs;
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
@@ -621,6 +634,7 @@ const SpecEntry* find_spec(const n1k_handle* h, const FastArgs& F) {
     const Program& P = h->prog;
     SpecSig g{};
     g.ncols = (int)F.ncols; g.nterms = (int)F.nterms; g.nkeys = (int)F.nkeys; g.naggs = (int)F.naggs;
+    g.hashed = (int)F.hashed;  // a dictionary domain beyond the LDS has no prebuilt kernel: interpreter
     for (uint32_t c = 0; c < F.ncols; c++) g.col_kind[c] = F.cols[c].kind;
     for (uint32_t t = 0; t < F.nterms; t++) {
         g.terms[t].op = F.terms[t].op;
@@ -697,14 +711,15 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         uint32_t frpl = h->opt_rows_per_lane;
         uint32_t fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
         // slabs + merge kernel pay off once the table is more than a few KiB
-        const bool use_slabs = h->opt_slabs == 1 ? table_bytes >= 4096 : h->opt_slabs == 2;
+        const bool use_slabs = !F.hashed && (h->opt_slabs == 1 ? table_bytes >= 4096 : h->opt_slabs == 2);
         F.err_flags = h->d_errp;
         F.rows_selected = h->d_counters.p + 0;
-        hipEvent_t e0 = get_event(h), e1 = get_event(h);
-        if (e0) (void)hipEventRecord(e0, h->stream);
         // a prebuilt plan-specialised kernel of exactly this shape?
         const SpecEntry* spec = h->opt_spec ? find_spec(h, F) : nullptr;
         h->stats.spec_kernel = spec ? 1u : 0u;
+        if (F.hashed && !spec) goto interpreter;  // the bounded-shape kernel is DIRECT only
+        hipEvent_t e0 = get_event(h), e1 = get_event(h);
+        if (e0) (void)hipEventRecord(e0, h->stream);
         const uint64_t chunk = 1ull << 31;  // 32-bit row indices inside one launch
         for (uint64_t off = 0; off < b->nrows; off += chunk) {
             uint64_t n = std::min<uint64_t>(chunk, b->nrows - off);
@@ -730,7 +745,9 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 F.slabs = nullptr;
                 if (use_slabs && g > 1) {
                     HIP_TRY(h, h->d_slabs.ensure((size_t)g * P.lds_words * F.lds_slots));
+                    HIP_TRY(h, h->d_block_sel.ensure(g));
                     F.slabs = h->d_slabs.p;
+                    F.block_selected = h->d_block_sel.p;
                 }
                 HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, h->stream));
                 if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
@@ -753,7 +770,9 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             F.slabs = nullptr;
             if (use_slabs && g > 1) {
                 HIP_TRY(h, h->d_slabs.ensure((size_t)g * P.lds_words * F.lds_slots));
+                HIP_TRY(h, h->d_block_sel.ensure(g));
                 F.slabs = h->d_slabs.p;
+                F.block_selected = h->d_block_sel.p;
             }
             HIP_TRY(h, launch_scan_fast(P, F, h->table, h->d_counters.p + 1, g, fblock, frpl, h->stream));
             if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
@@ -761,9 +780,10 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         }
         if (e1) (void)hipEventRecord(e1, h->stream);
         h->events.emplace_back(e0, e1);
-        h->stats.agg_mode = N1K_MODE_LDS_DIRECT;
+        h->stats.agg_mode = F.hashed ? N1K_MODE_LDS_HASH : N1K_MODE_LDS_DIRECT;
         return N1K_OK;
     }
+interpreter:
     // DIRECT: every key is dictionary coded and the whole key domain fits the LDS table -> perfect hash
     bool direct = h->opt_agg_mode != N1K_MODE_LDS_HASH;
     uint64_t domain = 1;
@@ -954,6 +974,7 @@ void n1k_destroy(n1k_handle* h) {
         h->d_acc.release();
         h->d_rep.release();
         h->d_slabs.release();
+        h->d_block_sel.release();
         for (auto& b : h->dv_tags) b.release();
         for (auto& b : h->dv_payload) b.release();
         h->d_regions.release();
@@ -990,10 +1011,12 @@ n1k_status n1k_reset(n1k_handle* h) {
     memset(&h->stats, 0, sizeof h->stats);
     if (h->device_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        drain_events(h);
+        if (!h->events.empty()) {  // pushes that were never finished: their events must complete before reuse
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            drain_events(h);
+        }
         h->stats.device_ms = 0;
-        // one launch: table back to empty and all counters / error flags to zero
+        // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
     }

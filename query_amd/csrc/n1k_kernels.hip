@@ -777,11 +777,14 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
 
     if (unsupported) atomicOr(A.err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
     if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
-    // rows that passed the Filter (≙ Filter #itemsOut)
-    for (int off = 32; off > 0; off >>= 1) selected += __shfl_down(selected, off, 64);
-    if ((tid & 63) == 0 && selected) atomicAdd(A.rows_selected, selected);
-
+    // rows that passed the Filter (≙ Filter #itemsOut): one global atomic per workgroup
+    __shared__ unsigned long long block_selected;
+    if (tid == 0) block_selected = 0;
     __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) selected += __shfl_down(selected, off, 64);
+    if ((tid & 63) == 0 && selected) atomicAdd(&block_selected, selected);
+    __syncthreads();
+    if (tid == 0 && block_selected) atomicAdd(A.rows_selected, block_selected);
     // K4: merge this workgroup's partial groups into the global table (≙ IntermediateGroup)
     for (uint32_t s = tid; s < S; s += BLOCK) {
         uint64_t key = lds[s];
@@ -976,15 +979,19 @@ __global__ __launch_bounds__(BLOCK) void scan_fast_kernel(const Program P, const
     }
 
     if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+    __shared__ unsigned int block_selected;
+    if (tid == 0) block_selected = 0;
+    __syncthreads();
     for (int off = 32; off > 0; off >>= 1) selected += __shfl_down(selected, off, 64);
-    if ((tid & 63) == 0 && selected) atomicAdd(F.rows_selected, (unsigned long long)selected);
-
+    if ((tid & 63) == 0 && selected) atomicAdd(&block_selected, selected);
     __syncthreads();
     if (F.slabs) {
         uint64_t* slab = F.slabs + (size_t)blockIdx.x * P.lds_words * S;
         for (uint32_t i = tid; i < P.lds_words * S; i += BLOCK) slab[i] = lds[i];
+        if (tid == 0) F.block_selected[blockIdx.x] = block_selected;
         return;
     }
+    if (tid == 0 && block_selected) atomicAdd(F.rows_selected, (unsigned long long)block_selected);
     // K4: merge this workgroup's partial groups into the global table (≙ IntermediateGroup)
     for (uint32_t s = tid; s < S; s += BLOCK) {
         if (lds[s] == kEmptyKey) continue;
@@ -1022,6 +1029,10 @@ N1K_DEFINE_SPEC(Spec_avg, 2, D32, T64, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_
 N1K_DEFINE_SPEC(Spec_count, 1, D32, 0, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_COUNT, 0, 0), NOAGG, NOAGG, NOAGG, NOAGG);
 // SELECT COUNT(*) / SUM(x) WHERE x > int
 N1K_DEFINE_SPEC(Spec_gt_nokey_count, 1, T64, 0, 0, 1, ST(TERM_NUM_GT, 0, 1), NOTERM, 0, 0, 0, 1, SA(AGG_COUNT, 0, 0), NOAGG, NOAGG, NOAGG, NOAGG);
+// integer (TAGGED64) keys: open-addressed LDS table
+N1K_DEFINE_SPEC(Spec_ik_count, 1, T64, 0, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_COUNT, 0, 0), NOAGG, NOAGG, NOAGG, NOAGG);
+N1K_DEFINE_SPEC(Spec_ik_sum, 2, T64, T64, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_SUM, 1, 1), NOAGG, NOAGG, NOAGG, NOAGG);
+N1K_DEFINE_SPEC(Spec_dik_sum, 3, D32, T64, T64, 0, NOTERM, NOTERM, 2, 0, 1, 1, SA(AGG_SUM, 1, 2), NOAGG, NOAGG, NOAGG, NOAGG);
 // SELECT k1, k2, SUM(x) GROUP BY k1, k2 (two dictionary keys)
 N1K_DEFINE_SPEC(Spec_2k_sum, 3, D32, D32, T64, 0, NOTERM, NOTERM, 2, 0, 1, 1, SA(AGG_SUM, 1, 2), NOAGG, NOAGG, NOAGG, NOAGG);
 #undef T64
@@ -1035,6 +1046,7 @@ template <class Spec>
 static SpecSig make_sig() {
     SpecSig g{};
     g.ncols = Spec::ncols; g.nterms = Spec::nterms; g.nkeys = Spec::nkeys; g.naggs = Spec::naggs;
+    g.hashed = spec_hashed<Spec>() ? 1 : 0;
     for (int c = 0; c < kFastCols; c++) g.col_kind[c] = c < Spec::ncols ? Spec::col_kind[c] : 0;
     for (int t = 0; t < kFastTerms; t++) if (t < Spec::nterms) g.terms[t] = Spec::terms[t];
     for (int k = 0; k < kFastKeys; k++) g.key_col[k] = k < Spec::nkeys ? Spec::key_col[k] : 0;
@@ -1063,6 +1075,7 @@ const std::vector<SpecEntry>& spec_registry() {
 #define N1K_REG(S) SpecEntry{#S, make_sig<S>(), &launch_spec<S>}
         N1K_REG(Spec_gt_sum), N1K_REG(Spec_lt_sum), N1K_REG(Spec_gtf_sum), N1K_REG(Spec_gt_all), N1K_REG(Spec_gt_count),
         N1K_REG(Spec_sum), N1K_REG(Spec_avg), N1K_REG(Spec_count), N1K_REG(Spec_gt_nokey_count), N1K_REG(Spec_2k_sum),
+        N1K_REG(Spec_ik_count), N1K_REG(Spec_ik_sum), N1K_REG(Spec_dik_sum),
 #undef N1K_REG
     };
     return reg;
@@ -1205,6 +1218,13 @@ __global__ __launch_bounds__(1024) void merge_slabs_kernel(const Program P, cons
     const uint32_t S = F.lds_slots;
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
     const bool in_range = s < S;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.y == 0) {
+        // survivor counts of the scan's workgroups -> Filter #itemsOut (wave 0 of the first block)
+        unsigned long long c = 0;
+        for (uint32_t b = threadIdx.x; b < nblocks_total; b += 64) c += F.block_selected[b];
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (threadIdx.x == 0 && c) atomicAdd(F.rows_selected, c);
+    }
     const uint32_t Y = 16 * gridDim.y, y = blockIdx.y * 16 + threadIdx.y;
     const size_t slab_words = (size_t)P.lds_words * S * Y;  // stride between the slabs this thread reads
     const uint32_t nblocks = (in_range && y < nblocks_total) ? (nblocks_total - y + Y - 1) / Y : 0;

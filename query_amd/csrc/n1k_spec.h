@@ -35,6 +35,15 @@ namespace n1k {
 #define SPEC_FLAG(ptr, bit) lds_or_u64((ptr), (bit))
 #endif
 
+// a Spec whose keys are not all dictionary columns uses the open-addressed LDS table (decided at compile time, so
+// the perfect-hash kernels carry none of the hashing code)
+template <class Spec>
+constexpr bool spec_hashed() {
+    bool h = false;
+    for (int k = 0; k < Spec::nkeys; k++) h = h || Spec::col_kind[Spec::key_col[k]] != COLK_DICT32;
+    return h;
+}
+
 template <class Spec>
 N1K_DEV bool spec_term_true(int t, const FastArgs& F, uint32_t tg, uint64_t p) {
     constexpr int kT = kFastTerms;
@@ -88,7 +97,9 @@ N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32
     if (kind == AGG_SUM || kind == AGG_AVG) {
         if (tag == T_INT) {
             int64_t x = (int64_t)p;
+#ifndef N1K_ABLATE_BIGINT
             if (x >= (1ll << 40) || x <= -(1ll << 40)) return false;
+#endif
             lds_add_u64(w, (unsigned long long)x);
             SPEC_FLAG(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
@@ -126,32 +137,58 @@ N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32
 // one row, everything about the plan shape folded at compile time
 template <class Spec>
 N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
-                      uint64_t* lds, uint32_t S, const uint32_t (&tg)[kFastCols], const uint64_t (&pv)[kFastCols],
-                      uint32_t& selected, uint32_t& unpackable) {
+                      uint64_t* lds, uint32_t S, uint32_t* lds_fill, const uint32_t (&tg)[kFastCols],
+                      const uint64_t (&pv)[kFastCols], uint32_t& selected, uint32_t& unpackable) {
     bool pass = true;
 #pragma unroll
     for (int t = 0; t < Spec::nterms; t++) pass = pass && spec_term_true<Spec>(t, F, tg[Spec::terms[t].col], pv[Spec::terms[t].col]);
     if (!pass) return;
     uint32_t slot = 0;
+    uint64_t key = 0;
+    long long grow = -1;
+    constexpr bool kHashed = spec_hashed<Spec>();
+    if (kHashed) {
+        // open-addressed LDS table on the packed key (integer / mixed keys, or a dictionary domain beyond the LDS)
 #pragma unroll
-    for (int k = 0; k < Spec::nkeys; k++) {
-        const uint32_t t = tg[Spec::key_col[k]];
-        uint32_t f = t == T_MISSING ? 0u : (t == T_NULL ? 1u : (uint32_t)pv[Spec::key_col[k]] + 2u);
-        if ((t > T_NULL && t != T_STRING) || f >= F.keys[k].radix) {
-            unpackable = 1;
-            return;
+        for (int k = 0; k < Spec::nkeys; k++) {
+            uint64_t f = 0;
+            if (!pack_key_field(P.keys[k], tg[Spec::key_col[k]], pv[Spec::key_col[k]], f)) {
+                unpackable = 1;
+                return;
+            }
+            key |= f << P.keys[k].shift;
         }
-        slot += f * F.keys[k].stride;
+        int sl = lds_find_or_insert(lds, S, key, lds_fill, F.lds_max_fill);
+        if (sl < 0) {
+            grow = global_find_or_insert(G, key, F.err_flags, ngroups);
+            if (grow < 0) return;
+        }
+        slot = (uint32_t)sl;
+    } else {
+#pragma unroll
+        for (int k = 0; k < Spec::nkeys; k++) {
+            const uint32_t t = tg[Spec::key_col[k]];
+            uint32_t f = t == T_MISSING ? 0u : (t == T_NULL ? 1u : (uint32_t)pv[Spec::key_col[k]] + 2u);
+#ifndef N1K_ABLATE_KEYCHECK
+            if ((t > T_NULL && t != T_STRING) || f >= F.keys[k].radix) {
+                unpackable = 1;
+                return;
+            }
+#endif
+            slot += f * F.keys[k].stride;
+        }
+        *(volatile lds_u64*)lds_word(lds, slot) = 1ull;  // "touched": every writer stores the same value, nobody reads it here
     }
     selected++;
-    *(volatile lds_u64*)lds_word(lds, slot) = 1ull;  // "touched": every writer stores the same value, nobody reads it here
 #pragma unroll
     for (int a = 0; a < Spec::naggs; a++) {
         const uint32_t c = Spec::aggs[a].has_operand ? Spec::aggs[a].col : 0u;
         const uint32_t t = Spec::aggs[a].has_operand ? tg[c] : (uint32_t)T_NULL;
         const uint64_t p = Spec::aggs[a].has_operand ? pv[c] : 0ull;
-        if (!spec_acc<Spec>(a, P, lds, S, slot, t, p)) {  // rare: an integer too large for the narrow LDS sum
-            long long g = global_find_or_insert(G, fast_slot_key(F, slot), F.err_flags, ngroups);
+        if (kHashed && grow >= 0) {  // the LDS table is full: this group lives in the global table only
+            acc_global(P, P.aggs[a], &G.acc[(size_t)grow * P.glob_words], t, p);
+        } else if (!spec_acc<Spec>(a, P, lds, S, slot, t, p)) {  // rare: an integer too large for the narrow LDS sum
+            long long g = global_find_or_insert(G, kHashed ? key : fast_slot_key(F, slot), F.err_flags, ngroups);
             if (g >= 0) acc_global(P, P.aggs[a], &G.acc[(size_t)g * P.glob_words], t, p);
         }
     }
@@ -161,9 +198,11 @@ template <class Spec, int R, int BLOCK, bool WIDE>
 __global__ __launch_bounds__(BLOCK) void scan_spec_kernel(const Program P, const FastArgs F, const GlobalTable G,
                                                          unsigned long long* ngroups) {
     extern __shared__ uint64_t lds[];
+    __shared__ uint32_t lds_fill;
     const uint32_t S = F.lds_slots;
     const uint32_t tid = threadIdx.x;
     lds_table_init<BLOCK>(P, lds, S, tid);
+    if (tid == 0) lds_fill = 0;
     __syncthreads();
 
     uint32_t unpackable = 0, selected = 0;
@@ -220,26 +259,32 @@ __global__ __launch_bounds__(BLOCK) void scan_spec_kernel(const Program P, const
             if (valid[j]) {
 #pragma unroll
                 for (int h = 0; h < (int)kRowsPerItem; h++)
-                    spec_row<Spec>(P, F, G, ngroups, lds, S, tg[j][h], pv[j][h], selected, unpackable);
+                    spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable);
             }
         }
     }
 
     if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+    // rows that passed the Filter (≙ Filter #itemsOut): wave shuffle, then ONE LDS counter per workgroup — thousands of
+    // same-address global atomics at the end of the kernel cost ~10 % of its time
+    __shared__ unsigned int block_selected;
+    if (tid == 0) block_selected = 0;
+    __syncthreads();
     for (int off = 32; off > 0; off >>= 1) selected += __shfl_down(selected, off, 64);
-    if ((tid & 63) == 0 && selected) atomicAdd(F.rows_selected, (unsigned long long)selected);
-
+    if ((tid & 63) == 0 && selected) atomicAdd(&block_selected, selected);
     __syncthreads();
     if (F.slabs) {
         // hand the workgroup's partial groups to merge_slabs_kernel: plain coalesced stores, no atomics
         uint64_t* slab = F.slabs + (size_t)blockIdx.x * P.lds_words * S;
         for (uint32_t i = tid; i < P.lds_words * S; i += BLOCK) slab[i] = lds[i];
+        if (tid == 0) F.block_selected[blockIdx.x] = block_selected;
         return;
     }
+    if (tid == 0 && block_selected) atomicAdd(F.rows_selected, (unsigned long long)block_selected);
     // K4: merge this workgroup's partial groups into the global table (≙ IntermediateGroup)
     for (uint32_t s = tid; s < S; s += BLOCK) {
         if (lds[s] == kEmptyKey) continue;
-        long long g = global_find_or_insert(G, fast_slot_key(F, s), F.err_flags, ngroups);
+        long long g = global_find_or_insert(G, spec_hashed<Spec>() ? lds[s] : fast_slot_key(F, s), F.err_flags, ngroups);
         if (g < 0) continue;
         merge_slot(P, lds, S, s, &G.acc[(size_t)g * P.glob_words]);
     }

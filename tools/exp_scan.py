@@ -49,6 +49,10 @@ def main():
                                  {"block": block, "grid_blocks": grid, "slabs": slabs}, False))
         variants += [
             ("filter-only", c2[0], [], [], {}, True),
+            ("intkey sum spec", None, [D("region_id")], ["sum(%s)" % D("price")], {}, False),
+            ("intkey sum interp", None, [D("region_id")], ["sum(%s)" % D("price")], {"fast": 0}, False),
+            ("cat+region sum spec", None, [D("cat"), D("region_id")], ["sum(%s)" % D("price")], {}, False),
+            ("cat+region sum interp", None, [D("cat"), D("region_id")], ["sum(%s)" % D("price")], {"fast": 0}, False),
             ("config2 fast(no spec)", c2[0], c2[1], c2[2], {"spec": 0}, False),
             ("config2 interp direct", c2[0], c2[1], c2[2], {"fast": 0}, False),
             ("nofilter sum", None, [D("cat")], ["sum(%s)" % D("price")], {}, False),
