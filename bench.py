@@ -218,6 +218,19 @@ def main():
                      "kernel_ms": scan_ms,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
+    # HBM traffic of the dominant kernel from the committed PMC passes of this same command (rocprofv3 --pmc cannot run
+    # inside the timed process): FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950 counts a wide coalesced
+    # read at half its bytes), WRITE_SIZE is exact; both are KB per dispatch.
+    pmc = os.path.join(ROOT, "profiles", "r01_bench_config2_100M_pmc_fetch_write.json")
+    if args.workload == "config2" and args.rows == 100_000_000 and args.kcat == 1000 and os.path.exists(pmc):
+        try:
+            with open(pmc) as fh:
+                c = json.load(fh)
+            k = [n for n in c["FETCH_SIZE"] if "scan_spec_kernel" in n][0]
+            out["roofline"]["traffic"] = 1024.0 * (2.0 * c["FETCH_SIZE"][k]["avg_KB"] + c["WRITE_SIZE"][k]["avg_KB"])
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc) + " (scan_spec_kernel, 2*FETCH_SIZE + WRITE_SIZE)"
+        except Exception:
+            pass
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(wl, args.kcat, bool(args.zipf), total_rows,
                                            min(args.cpu_sample, args.rows))
