@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include "n1k_device.h"
 #include "n1k_kernels.h"
+#include <algorithm>
 #include <vector>
 
 namespace n1k {
@@ -576,39 +577,51 @@ __global__ void distinct_layout_kernel(const Program P, const GlobalTable G, con
 
 // finish step 2: insert every logged pair into its group's value set with ONE 64-bit compare-and-swap per probe
 // (the group and the class are implied by the region, so the value alone identifies the member: no multi-word
-// entries, no locks, no spinning).  A first insertion bumps the group's distinct count.
-__global__ void distinct_insert_kernel(const Program P, const GlobalTable G, const DistinctArgs D, uint32_t* err_flags) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= D.npairs) return;
-    long long g = global_find(G, D.log_key[i]);
-    if (g < 0) {
-        atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
-        return;
-    }
-    uint32_t cls = D.log_cls[i];
-    uint64_t val = D.log_val[i];
-    unsigned long long* w = (unsigned long long*)&G.acc[(size_t)g * P.glob_words + D.glob_off];
-    if (val == kEmptyKey) {
-        // the one value that collides with the free marker (int -1): tracked by a flag bit per class
-        unsigned long long bit = 1ull << cls;
-        unsigned long long old = atomicOr(&w[4], bit);
-        if (!(old & bit)) atomicAdd(&w[0], 1ull);
-        return;
-    }
-    const uint64_t* reg = D.regions + (size_t)g * 6 + 2 * cls;
-    uint64_t off = reg[0], mask = reg[1];
-    uint64_t h = mix64(val) & mask;
-    for (uint64_t probe = 0; probe <= mask; probe++) {
-        unsigned long long* slot = (unsigned long long*)&D.set_table[off + h];
-        unsigned long long old = atomicCAS(slot, (unsigned long long)kEmptyKey, (unsigned long long)val);
-        if (old == kEmptyKey) {
-            atomicAdd(&w[0], 1ull);  // Set.Len() grows by one (value/set.go:198-215)
-            return;
+// entries, no locks, no spinning).  First insertions are counted per group in an LDS table of counters (when the
+// group table is small enough) and added to the global rows once per workgroup.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void distinct_insert_kernel(const Program P, const GlobalTable G, const DistinctArgs D,
+                                                               uint32_t* err_flags, uint32_t lds_counters) {
+    extern __shared__ uint32_t cnt[];  // lds_counters entries (== G.capacity) or none
+    for (uint32_t i = threadIdx.x; i < lds_counters; i += BLOCK) cnt[i] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < D.npairs; i += (uint64_t)gridDim.x * BLOCK) {
+        long long g = global_find(G, D.log_key[i]);
+        if (g < 0) {
+            atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+            continue;
         }
-        if (old == val) return;  // already a member
-        h = (h + 1) & mask;
+        uint32_t cls = D.log_cls[i];
+        uint64_t val = D.log_val[i];
+        unsigned long long* w = (unsigned long long*)&G.acc[(size_t)g * P.glob_words + D.glob_off];
+        bool fresh = false;
+        if (val == kEmptyKey) {
+            // the one value that collides with the free marker (int -1): tracked by a flag bit per class
+            unsigned long long bit = 1ull << cls;
+            unsigned long long old = atomicOr(&w[4], bit);
+            fresh = !(old & bit);
+        } else {
+            const uint64_t* reg = D.regions + (size_t)g * 6 + 2 * cls;
+            uint64_t off = reg[0], mask = reg[1];
+            uint64_t h = mix64(val) & mask;
+            bool done = false;
+            for (uint64_t probe = 0; probe <= mask && !done; probe++) {
+                unsigned long long* slot = (unsigned long long*)&D.set_table[off + h];
+                unsigned long long old = atomicCAS(slot, (unsigned long long)kEmptyKey, (unsigned long long)val);
+                if (old == kEmptyKey) { fresh = true; done = true; }
+                else if (old == val) done = true;  // already a member
+                h = (h + 1) & mask;
+            }
+            if (!done) atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+        }
+        if (fresh) {  // Set.Len() grows by one (value/set.go:198-215)
+            if (lds_counters) atomicAdd(&cnt[g], 1u);
+            else atomicAdd(&w[0], 1ull);
+        }
     }
-    atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < lds_counters; i += BLOCK)
+        if (cnt[i]) atomicAdd((unsigned long long*)&G.acc[(size_t)i * P.glob_words + D.glob_off], (unsigned long long)cnt[i]);
 }
 
 // ------------------------------------------------------------------ K1+K2+K3(+K4): scan -> filter -> group
@@ -1761,8 +1774,10 @@ hipError_t launch_distinct_layout(const Program& P, const GlobalTable& G, const 
 hipError_t launch_distinct_insert(const Program& P, const GlobalTable& G, const DistinctArgs& D, uint32_t* err_flags,
                                   hipStream_t st) {
     if (D.npairs == 0) return hipSuccess;
-    uint32_t blocks = (uint32_t)((D.npairs + 255) / 256);
-    hipLaunchKernelGGL(distinct_insert_kernel, dim3(blocks), dim3(256), 0, st, P, G, D, err_flags);
+    uint32_t lds_counters = G.capacity <= 16384 ? (uint32_t)G.capacity : 0u;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((D.npairs + 511) / 512, 2048);
+    hipLaunchKernelGGL((distinct_insert_kernel<512>), dim3(blocks), dim3(512), lds_counters * 4, st, P, G, D, err_flags,
+                       lds_counters);
     return hipGetLastError();
 }
 

@@ -325,3 +325,49 @@ def test_reopen_and_stop():
         op.process_items(cols, t.dictionary)
     assert ei.value.status == _ffi.STOPPED
     op.done()
+
+
+def test_error_paths_are_reported_not_silent():
+    """Run-time conditions outside the device subset surface as status codes (never as wrong groups)."""
+    t = n1o.synth_table(50_000, k_cat=2000)
+    by = {c.name: c for c in t.columns}
+    # 1. group table capacity exceeded -> N1K_OOM (the caller can raise max_groups)
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(None, [D("user_id")], ["count(*)"]), max_groups=64)
+    op.process_items([by[p] for p in op.column_paths], t.dictionary)
+    with pytest.raises(query_amd.N1kError) as ei:
+        op.after_items()
+    assert ei.value.status == _ffi.OOM
+    op.done()
+    # 2. a batch with the wrong number of columns -> N1K_INVALID
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(None, [D("cat")], ["sum(%s)" % D("price")]))
+    with pytest.raises(query_amd.N1kError) as ei:
+        op.process_items([by[D("cat")]], t.dictionary)
+    assert ei.value.status == _ffi.INVALID
+    # 3. a column that changes kind between batches -> N1K_INVALID
+    op.process_items([by[p] for p in op.column_paths], t.dictionary)
+    wrong = n1o.Column(D("cat"), n1o.COL_TAGGED64, tags=np.full(10, n1o.T_STRING, np.uint8), payload=np.zeros(10, np.uint64))
+    with pytest.raises(query_amd.N1kError) as ei:
+        op.process_items([wrong if p == D("cat") else _head(by[p], 10) for p in op.column_paths], t.dictionary)
+    assert ei.value.status == _ffi.INVALID
+    op.done()
+
+
+def _head(c, n):
+    if c.kind == n1o.COL_DICT32:
+        return n1o.Column(c.name, c.kind, codes=c.codes[:n])
+    return n1o.Column(c.name, c.kind, tags=c.tags[:n], payload=c.payload[:n])
+
+
+def test_empty_batches_and_zero_rows():
+    t = n1o.synth_table(1000, k_cat=5)
+    by = {c.name: c for c in t.columns}
+    aggs = sorted(["count(*)", "sum(%s)" % D("price")])
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan("(50 < %s)" % D("price"), [D("cat")], aggs))
+    cols = [by[p] for p in op.column_paths]
+    op.process_items([_head(c, 0) for c in cols], t.dictionary)  # an empty batch is legal
+    op.process_items(cols, t.dictionary)
+    op.process_items([_head(c, 0) for c in cols], t.dictionary)
+    gpu = op.after_items()
+    op.done()
+    ora = n1o.run(t, "(50 < %s)" % D("price"), [D("cat")], aggs)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
