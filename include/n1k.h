@@ -148,7 +148,7 @@ typedef struct n1k_stats {
     double device_ms;       /* hipEvent time of all device work (≙ execTime) */
     uint64_t bytes_scanned; /* algorithmic column bytes read by the scan kernel */
     uint32_t agg_mode;      /* n1k_agg_mode actually used by the last batch */
-    uint32_t spec_kernel;   /* 1: a plan-specialised kernel ran the last batch */
+    uint32_t spec_kernel;   /* plan-specialised kernel that ran the last batch: 0 none, 1 prebuilt, 2 built at run time */
 } n1k_stats;
 
 typedef enum n1k_agg_mode {
@@ -209,7 +209,9 @@ const char *n1k_aggregate_name(const n1k_handle *h, uint32_t i);
 
 /* Intern n strings (bytes[offsets[i]..offsets[i+1])) into the handle's
  * dictionary; out_codes[i] receives the code.  Equal byte strings always get
- * equal codes (string equality ≙ value/string.go:82-96). */
+ * equal codes (string equality ≙ value/string.go:82-96).  Codes are handed out in
+ * interning order starting at 0; the plan's own string constants are interned at the
+ * first push, so a dictionary interned right after n1k_create keeps code == index. */
 n1k_status n1k_dict_intern(n1k_handle *h, uint32_t n, const uint64_t *offsets, const char *bytes,
                            uint32_t *out_codes);
 uint32_t n1k_dict_size(const n1k_handle *h);
@@ -220,7 +222,9 @@ n1k_status n1k_dict_get(const n1k_handle *h, uint32_t code, const char **ptr, si
 /* name ∈ {"device" (ordinal) | "stream" (hipStream_t) | "rep_row" (0/1): before the first push;
  *         "max_groups" (group-table capacity bound, default 1<<22), "agg_mode" (n1k_agg_mode),
  *         "grid_blocks" / "block" / "rows_per_lane" / "lds_bytes" (launch tuning, 0 = auto),
- *         "fast" / "spec" / "wide" / "slabs" (0/1: kernel selection switches used by the ablation tests)} */
+ *         "fast" / "spec" / "wide" / "slabs" (0/1: kernel selection switches used by the ablation tests),
+ *         "jit" (0 off, 1 = compile a specialised kernel for large batches of unregistered shapes, 2 = always),
+ *         "jit_min_rows"} */
 n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);
 
 /* ----------------------------------------------------------------- data ---- */
@@ -251,6 +255,15 @@ n1k_status n1k_sync(n1k_handle *h);
 n1k_status n1k_finish(n1k_handle *h, n1k_result *out);
 
 n1k_status n1k_get_stats(const n1k_handle *h, n1k_stats *out);
+
+/*
+ * Build (but do not run) the plan-specialised scan kernel of this plan for the given column kinds through the
+ * in-process compiler (hiprtc): what the engine does lazily for large batches of a plan shape that has no
+ * ahead-of-time instantiation.  Needs no GPU; a prepared-statement cache (plan/prepared.go) would call it at
+ * PREPARE time.  `log` receives the compiler output.  N1K_UNSUPPORTED when the shape is outside the bounded family
+ * (the interpreter kernel then runs the plan).
+ */
+n1k_status n1k_jit_check(n1k_handle *h, const uint32_t *col_kinds, uint32_t ncols, char *log, size_t loglen);
 
 /* ------------------------------------------------- multi-GPU (one per rank) -- */
 

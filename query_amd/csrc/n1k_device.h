@@ -4,7 +4,9 @@
 // equality, truth and 4-valued logic rules.  Each helper cites the Go source
 // it reproduces (paths relative to the reference tree).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 #include "n1k_types.h"
 
 namespace n1k {

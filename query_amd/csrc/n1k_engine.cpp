@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/n1k.h"
+#include "n1k_jit.h"
 #include "n1k_kernels.h"
 #include "n1k_plan.h"
 
@@ -79,6 +80,9 @@ struct n1k_handle {
     uint32_t opt_rep_row = 0;
     uint32_t opt_lds_bytes = 64 * 1024;   // HASH mode: LDS table bytes per workgroup
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
+    uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
+    uint64_t opt_jit_min_rows = 4u << 20;
+    std::string jit_log;
     int device = -1;
     bool device_ready = false;
     hipStream_t stream = nullptr;
@@ -102,6 +106,7 @@ struct n1k_handle {
     // arithmetic operands -> derived columns (input columns first, then one per arithmetic node)
     struct Derived { uint32_t op, nops; Operand ops[4]; };
     std::vector<Derived> derived;
+    std::vector<std::string> const_strings;  // string constants of the plan, interned lazily (see to_operand)
     std::vector<DevBuf<uint8_t>> dv_tags;
     std::vector<DevBuf<uint64_t>> dv_payload;
     DevBuf<uint64_t> d_log_key[kMaxDistinct], d_log_val[kMaxDistinct], d_regions, d_set_table;
@@ -191,7 +196,14 @@ bool to_operand(n1k_handle* h, const Expr* e, Operand& o, PlanError& err) {
     if (e->kind == EK::Const) {
         o.is_const = 1;
         o.ctag = e->ctag;
-        o.cpayload = e->ctag == T_STRING ? intern(h, e->cstr) : e->cpayload;
+        o.cpayload = e->cpayload;
+        if (e->ctag == T_STRING) {
+            // string constants are interned at the first push, AFTER whatever dictionary the caller interned, so that
+            // a caller who interns its dictionary right after n1k_create keeps its own codes (code == index)
+            o.pad = 1;
+            o.cpayload = h->const_strings.size();
+            h->const_strings.push_back(e->cstr);
+        }
         return true;
     }
     // arithmetic node -> derived column evaluated once per batch (expression/arith_*.go)
@@ -318,6 +330,7 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
     Program& P = h->prog;
     memset(&P, 0, sizeof P);
     h->derived.clear();
+    h->const_strings.clear();
     const ParsedPlan& pl = h->plan;
     if (pl.paths.size() > (size_t)kMaxCols) { err.unsupported = true; err.msg = "more than 16 leaf paths"; return false; }
     if (pl.keys.size() > (size_t)kMaxKeys) { err.unsupported = true; err.msg = "more than 4 group keys"; return false; }
@@ -345,11 +358,6 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
         s.lds_off = lds_w;
         s.glob_off = glob_w;
         if (d.distinct) {
-            if (d.kind != AGG_COUNT && d.kind != AGG_COUNTN) {
-                err.unsupported = true;
-                err.msg = "SUM/AVG(DISTINCT) are not on the device path yet";
-                return false;
-            }
             if (h->n_distinct >= kMaxDistinct) {
                 err.unsupported = true;
                 err.msg = "more than 4 DISTINCT aggregates";
@@ -358,7 +366,7 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
             h->has_distinct = true;
             s.log_index = h->n_distinct++;
             lds_w += kLdsWordsDistinct;
-            glob_w += kGlobWordsDistinct;
+            glob_w += (d.kind == AGG_SUM || d.kind == AGG_AVG) ? kGlobWordsDistinctSum : kGlobWordsDistinct;
         } else if (d.kind == AGG_COUNT || d.kind == AGG_COUNTN) {
             lds_w += 1;
             glob_w += 1;
@@ -629,8 +637,8 @@ bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F) {
     return true;
 }
 
-// exact-shape lookup among the ahead-of-time instantiated plan shapes (n1k_spec.h)
-const SpecEntry* find_spec(const n1k_handle* h, const FastArgs& F) {
+// shape of the compiled plan (what a plan-specialised kernel is instantiated for)
+SpecSig make_plan_sig(const n1k_handle* h, const FastArgs& F) {
     const Program& P = h->prog;
     SpecSig g{};
     g.ncols = (int)F.ncols; g.nterms = (int)F.nterms; g.nkeys = (int)F.nkeys; g.naggs = (int)F.naggs;
@@ -648,6 +656,11 @@ const SpecEntry* find_spec(const n1k_handle* h, const FastArgs& F) {
         g.aggs[a].has_operand = P.aggs[a].has_operand;
         g.aggs[a].col = P.aggs[a].has_operand ? F.agg_col[a] : 0u;
     }
+    return g;
+}
+
+// exact-shape lookup among the ahead-of-time instantiated plan shapes (n1k_spec.h)
+const SpecEntry* find_spec(const SpecSig& g) {
     for (const SpecEntry& e : spec_registry())
         if (memcmp(&e.sig, &g, sizeof g) == 0) return &e;
     return nullptr;
@@ -715,9 +728,27 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         F.err_flags = h->d_errp;
         F.rows_selected = h->d_counters.p + 0;
         // a prebuilt plan-specialised kernel of exactly this shape?
-        const SpecEntry* spec = h->opt_spec ? find_spec(h, F) : nullptr;
-        h->stats.spec_kernel = spec ? 1u : 0u;
-        if (F.hashed && !spec) goto interpreter;  // the bounded-shape kernel is DIRECT only
+        const SpecSig sig = make_plan_sig(h, F);
+        const SpecEntry* spec = h->opt_spec ? find_spec(sig) : nullptr;
+        // no prebuilt kernel of this shape: instantiate the same template at run time (large batches, or forced)
+        const JitKernel* jit = nullptr;
+        bool key_kinds_hashed = false;
+        for (uint32_t k = 0; k < F.nkeys; k++) key_kinds_hashed |= F.cols[F.keys[k].col].kind != COLK_DICT32;
+        if (!spec && h->opt_spec && h->opt_jit && (h->opt_jit == 2 || b->nrows >= h->opt_jit_min_rows) &&
+            table_bytes <= 64 * 1024 && key_kinds_hashed == (F.hashed != 0)) {
+            jit = jit_get(sig);
+            if (jit->failed) {
+                h->jit_log = jit->log;
+                jit = nullptr;
+            }
+        }
+        if (jit && fblock != 512) {  // run-time instantiations are built for 512-thread workgroups
+            fblock = 512;
+            per_cu = table_bytes <= 48 * 1024 ? 3u : 2u;
+            fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
+        }
+        h->stats.spec_kernel = spec ? 1u : (jit ? 2u : 0u);
+        if (F.hashed && !spec && !jit) goto interpreter;  // the bounded-shape kernel is DIRECT only
         hipEvent_t e0 = get_event(h), e1 = get_event(h);
         if (e0) (void)hipEventRecord(e0, h->stream);
         const uint64_t chunk = 1ull << 31;  // 32-bit row indices inside one launch
@@ -733,7 +764,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 aligned &= ((uintptr_t)F.cols[c].tags % 2 == 0) && ((uintptr_t)F.cols[c].payload % 16 == 0) &&
                            ((uintptr_t)F.cols[c].codes % 8 == 0);
             }
-            if (spec) {
+            if (spec || jit) {
                 // WIDE launch over the even prefix (2 adjacent rows per lane and load), scalar launch for an odd last row
                 bool wide = aligned && h->opt_wide && n >= 2;
                 uint64_t n_main = wide ? (n & ~1ull) : n;
@@ -749,7 +780,8 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                     F.slabs = h->d_slabs.p;
                     F.block_selected = h->d_block_sel.p;
                 }
-                HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, h->stream));
+                if (spec) HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, h->stream));
+                else HIP_TRY(h, jit_launch(jit, P, F, h->table, h->d_counters.p + 1, g, wide, h->stream));
                 if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
                 F.slabs = nullptr;
                 if (n_main < n) {
@@ -760,7 +792,8 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                     }
                     F.nrows = (uint32_t)(n - n_main);
                     F.row_base += n_main;
-                    HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, 1, fblock, false, h->stream));
+                    if (spec) HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, 1, fblock, false, h->stream));
+                    else HIP_TRY(h, jit_launch(jit, P, F, h->table, h->d_counters.p + 1, 1, false, h->stream));
                 }
                 continue;
             }
@@ -852,6 +885,18 @@ n1k_status run_filter_batch(n1k_handle* h, const n1k_batch* b) {
 // Point the program at this batch's input columns and evaluate the arithmetic nodes into derived columns.
 n1k_status bind_columns(n1k_handle* h, const n1k_batch* b) {
     Program& P = h->prog;
+    // first push: give the plan's string constants their dictionary codes
+    auto resolve = [&](Operand& o) {
+        if (o.is_const && o.ctag == T_STRING && o.pad == 1) {
+            o.cpayload = intern(h, h->const_strings[(size_t)o.cpayload]);
+            o.pad = 0;
+        }
+    };
+    for (uint32_t t = 0; t < P.nterms; t++) { resolve(P.terms[t].a); resolve(P.terms[t].b); resolve(P.terms[t].c); }
+    for (uint32_t k = 0; k < P.nkeys; k++) resolve(P.keys[k].src);
+    for (uint32_t a = 0; a < P.naggs; a++) resolve(P.aggs[a].src);
+    for (auto& d : h->derived)
+        for (uint32_t k = 0; k < d.nops; k++) resolve(d.ops[k]);
     const uint32_t ni = (uint32_t)h->plan.paths.size();
     for (uint32_t c = 0; c < ni; c++) {
         P.cols[c].kind = b->cols[c].kind == N1K_COL_DICT32 ? COLK_DICT32 : COLK_TAGGED64;
@@ -1067,6 +1112,8 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fast") h->opt_fast = value ? 1 : 0;
     else if (n == "spec") h->opt_spec = value ? 1 : 0;
     else if (n == "wide") h->opt_wide = value ? 1 : 0;
+    else if (n == "jit") h->opt_jit = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
+    else if (n == "jit_min_rows") h->opt_jit_min_rows = (uint64_t)std::max<int64_t>(value, 0);
     else if (n == "slabs") h->opt_slabs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);  // 0 off, 1 auto, 2 always
     else if (n == "block") {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(h, N1K_INVALID, "block must be 0 (auto), 256, 512 or 1024");
@@ -1196,6 +1243,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             D.log_cls = h->d_log_cls[ag.log_index].p;
             D.npairs = npairs;
             D.glob_off = ag.glob_off;
+            D.kind = ag.kind;
             D.total_words = h->d_counters.p + 5;
             HIP_TRY(h, h->d_regions.ensure(h->table.capacity * 6));
             D.regions = h->d_regions.p;
@@ -1266,6 +1314,34 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     out->rep_row = h->r_rep.data();
     h->stats.groups_out = ng;
     return N1K_OK;
+}
+
+n1k_status n1k_jit_check(n1k_handle* h, const uint32_t* col_kinds, uint32_t ncols, char* log, size_t loglen) {
+    if (!h || !col_kinds) return N1K_INVALID;
+    if (log && loglen) log[0] = 0;
+    if (ncols != h->plan.paths.size()) return fail(h, N1K_INVALID, "plan has %zu columns", h->plan.paths.size());
+    if (!h->plan.has_group) return fail(h, N1K_UNSUPPORTED, "Filter-only plans use fixed kernels");
+    // fix the key layout from the column kinds alone (no data, no device)
+    std::vector<n1k_col> cols(ncols ? ncols : 1);
+    for (uint32_t c = 0; c < ncols; c++) cols[c].kind = col_kinds[c];
+    n1k_batch b{};
+    b.nrows = 0;
+    b.ncols = ncols;
+    b.cols = cols.data();
+    if (!h->layout_fixed) {
+        n1k_status st = fix_layout(h, &b);
+        if (st != N1K_OK) return st;
+    }
+    for (uint32_t c = 0; c < ncols; c++) h->prog.cols[c].kind = col_kinds[c] == N1K_COL_DICT32 ? COLK_DICT32 : COLK_TAGGED64;
+    for (uint32_t c = ncols; c < h->prog.ncols; c++) h->prog.cols[c].kind = COLK_TAGGED64;
+    FastArgs F;
+    const uint32_t max_slots = (uint32_t)std::min<uint64_t>((156u * 1024u) / (h->prog.lds_words * 8), 1u << 15);
+    if (!build_fast_args(h, max_slots, F)) return fail(h, N1K_UNSUPPORTED, "the plan shape is outside the bounded family");
+    SpecSig sig = make_plan_sig(h, F);
+    std::string l;
+    bool ok = jit_compile_check(sig, &l);
+    if (log && loglen) snprintf(log, loglen, "%s", l.c_str());
+    return ok ? N1K_OK : fail(h, N1K_DEVICE_ERROR, "run-time compilation failed: %s", l.substr(0, 300).c_str());
 }
 
 n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {

@@ -1,0 +1,131 @@
+// n1k_jit.cpp — run-time instantiation of scan_spec_body for one plan shape (see n1k_jit.h).
+#include "n1k_jit.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <vector>
+
+namespace n1k {
+namespace {
+
+std::mutex g_mu;
+std::map<std::string, JitKernel*> g_cache;
+
+std::string csrc_dir() {
+    if (const char* e = getenv("N1K_CSRC")) return e;
+    Dl_info info;
+    if (dladdr((const void*)&csrc_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t slash = p.rfind('/');
+        if (slash != std::string::npos) return p.substr(0, slash) + "/csrc";
+    }
+    return "query_amd/csrc";
+}
+
+std::string sig_key(const SpecSig& s) { return std::string((const char*)&s, sizeof s); }
+
+bool compile(const SpecSig& sig, std::vector<char>& code, std::string& log) {
+    std::string src = jit_source(sig);
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "n1k_jit_shape.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        log = "hiprtcCreateProgram failed";
+        return false;
+    }
+    std::string inc = "-I" + csrc_dir();
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", inc.c_str()};
+    hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    if (ls > 1) {
+        log.resize(ls);
+        hiprtcGetProgramLog(prog, &log[0]);
+    }
+    bool ok = r == HIPRTC_SUCCESS;
+    if (ok) {
+        size_t cs = 0;
+        hiprtcGetCodeSize(prog, &cs);
+        code.resize(cs);
+        ok = cs > 0 && hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+    }
+    hiprtcDestroyProgram(&prog);
+    return ok;
+}
+
+}  // namespace
+
+std::string jit_source(const SpecSig& g) {
+    std::ostringstream o;
+    o << "#include \"n1k_spec.h\"\nnamespace n1k {\n";
+    auto term = [&](int t) {
+        std::ostringstream x;
+        if (t < g.nterms) x << "SpecTerm{" << g.terms[t].op << "u, " << g.terms[t].col << "u, " << g.terms[t].const_int << "u}";
+        else x << "SpecTerm{0u, 0u, 0u}";
+        return x.str();
+    };
+    auto agg = [&](int a) {
+        std::ostringstream x;
+        if (a < g.naggs) x << "SpecAgg{" << g.aggs[a].kind << "u, " << g.aggs[a].has_operand << "u, " << g.aggs[a].col << "u}";
+        else x << "SpecAgg{0u, 0u, 0u}";
+        return x.str();
+    };
+    o << "struct SpecJ {\n"
+      << "    static constexpr int ncols = " << g.ncols << ", nterms = " << g.nterms << ", nkeys = " << g.nkeys
+      << ", naggs = " << g.naggs << ";\n"
+      << "    static constexpr uint32_t col_kind[kFastCols] = {" << g.col_kind[0] << "u, " << g.col_kind[1] << "u, "
+      << g.col_kind[2] << "u};\n"
+      << "    static constexpr SpecTerm terms[kFastTerms] = {" << term(0) << ", " << term(1) << "};\n"
+      << "    static constexpr uint32_t key_col[kFastKeys] = {" << g.key_col[0] << "u, " << g.key_col[1] << "u};\n"
+      << "    static constexpr SpecAgg aggs[kFastAggs] = {" << agg(0) << ", " << agg(1) << ", " << agg(2) << ", " << agg(3)
+      << ", " << agg(4) << "};\n};\n}  // namespace n1k\n"
+      << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_wide(const n1k::Program P, const n1k::FastArgs F,\n"
+      << "        const n1k::GlobalTable G, unsigned long long* ngroups) {\n"
+      << "    n1k::scan_spec_body<n1k::SpecJ, 2, 512, true>(P, F, G, ngroups);\n}\n"
+      << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
+      << "        const n1k::GlobalTable G, unsigned long long* ngroups) {\n"
+      << "    n1k::scan_spec_body<n1k::SpecJ, 4, 512, false>(P, F, G, ngroups);\n}\n";
+    return o.str();
+}
+
+bool jit_compile_check(const SpecSig& sig, std::string* log) {
+    std::vector<char> code;
+    std::string l;
+    bool ok = compile(sig, code, l);
+    if (log) *log = l;
+    return ok;
+}
+
+const JitKernel* jit_get(const SpecSig& sig) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    std::string key = sig_key(sig);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) return it->second;
+    JitKernel* k = new JitKernel();
+    g_cache[key] = k;
+    std::vector<char> code;
+    if (!compile(sig, code, k->log)) {
+        k->failed = true;
+        return k;
+    }
+    if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
+        hipModuleGetFunction(&k->wide, k->module, "n1k_jit_wide") != hipSuccess ||
+        hipModuleGetFunction(&k->narrow, k->module, "n1k_jit_narrow") != hipSuccess) {
+        k->failed = true;
+        k->log += "\nhipModuleLoadData / hipModuleGetFunction failed";
+    }
+    return k;
+}
+
+hipError_t jit_launch(const JitKernel* k, const Program& P, const FastArgs& F, const GlobalTable& G,
+                      unsigned long long* ngroups, uint32_t grid, bool wide, hipStream_t st) {
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8;
+    void* args[] = {(void*)&P, (void*)&F, (void*)&G, (void*)&ngroups};
+    return hipModuleLaunchKernel(wide ? k->wide : k->narrow, grid, 1, 1, 512, 1, 1, (unsigned)shmem, st, args, nullptr);
+}
+
+}  // namespace n1k

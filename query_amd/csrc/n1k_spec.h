@@ -9,9 +9,7 @@
 //
 // WIDE: two adjacent rows per lane and load: payload 16 B, tags 2 B, codes 8 B per lane (needs aligned bases).
 #pragma once
-#include <hip/hip_runtime.h>
-#include "n1k_device.h"
-#include "n1k_types.h"
+#include "n1k_tables.h"
 
 namespace n1k {
 
@@ -195,8 +193,7 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
 }
 
 template <class Spec, int R, int BLOCK, bool WIDE>
-__global__ __launch_bounds__(BLOCK) void scan_spec_kernel(const Program P, const FastArgs F, const GlobalTable G,
-                                                         unsigned long long* ngroups) {
+N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups) {
     extern __shared__ uint64_t lds[];
     __shared__ uint32_t lds_fill;
     const uint32_t S = F.lds_slots;
@@ -288,6 +285,13 @@ __global__ __launch_bounds__(BLOCK) void scan_spec_kernel(const Program P, const
         if (g < 0) continue;
         merge_slot(P, lds, S, s, &G.acc[(size_t)g * P.glob_words]);
     }
+}
+
+// ahead-of-time instantiations use this kernel; kernels compiled at run time wrap scan_spec_body themselves
+template <class Spec, int R, int BLOCK, bool WIDE>
+__global__ __launch_bounds__(BLOCK) void scan_spec_kernel(const Program P, const FastArgs F, const GlobalTable G,
+                                                         unsigned long long* ngroups) {
+    scan_spec_body<Spec, R, BLOCK, WIDE>(P, F, G, ngroups);
 }
 
 }  // namespace n1k

@@ -5,7 +5,21 @@
 // interpret it with scalar control flow (every lane runs the same op on its
 // own rows), so the interpretive overhead stays on the scalar unit.
 #pragma once
+#ifdef __HIPCC_RTC__
+// hiprtc has no <stdint.h>: same widths and underlying types as the LP64 host headers
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long uint64_t;
+typedef int int32_t;
+typedef long int64_t;
+typedef unsigned long uintptr_t;
+typedef unsigned long size_t;
+#define INT64_MAX 9223372036854775807L
+#define INT64_MIN (-9223372036854775807L - 1)
+#else
 #include <stdint.h>
+#endif
 
 namespace n1k {
 
@@ -107,7 +121,8 @@ struct AggSpec {
 //   AVG          : [isum_lo][isum_hi][fsum][flags][n]
 //   MIN/MAX      : [flags][ival][fval][sval]
 //   * DISTINCT   : [distinct count (filled at finish)][n_int][n_float][n_other][special]
-constexpr uint32_t kLdsWordsDistinct = 3, kGlobWordsDistinct = 5, kMaxDistinct = 4;
+//                  SUM/AVG(DISTINCT) append the SUM words [isum_lo][isum_hi][fsum][flags] of the distinct members
+constexpr uint32_t kLdsWordsDistinct = 3, kGlobWordsDistinct = 5, kGlobWordsDistinctSum = 9, kMaxDistinct = 4;
 constexpr uint32_t kLdsWordsSum = 3, kLdsWordsAvg = 4, kGlobWordsSum = 4, kGlobWordsAvg = 5, kWordsMinMax = 4;
 
 // SUM/AVG flag bits: which kinds of NUMBER operands were met.  intValue.Add keeps an int64 only for same-sign
@@ -176,7 +191,7 @@ struct DistinctArgs {
     uint64_t* set_table;   // concatenated per-(group, class) open-addressed value sets, kEmptyKey when free
     unsigned long long* total_words;  // out: words needed by the regions
     uint32_t glob_off;     // first global word of the aggregate
-    uint32_t pad;
+    uint32_t kind;         // AGG_* of the DISTINCT aggregate
 };
 
 // ---- "fast" scan kernel: bounded plan shapes with every descriptor at a static index ------------------------

@@ -33,7 +33,9 @@ def run_gpu(table: n1o.Table, condition: Optional[str], keys: Sequence[str], agg
             part = [_slice(c, lo, hi) for c in cols]
             if device_resident:
                 import torch
-                op.intern(list(table.dictionary))
+                codes = op.intern(list(table.dictionary))
+                # a caller that interns its dictionary right after n1k_create keeps its own codes
+                assert np.array_equal(codes, np.arange(len(table.dictionary), dtype=np.uint32))
                 dev = []
                 for c in part:
                     if c.kind == n1o.COL_DICT32:

@@ -72,3 +72,17 @@ def test_dictionary_interning_is_stable():
     assert a[0] == a[3] and len({int(a[0]), int(a[1]), int(a[2])}) == 3
     assert op.dict_get(int(a[1])) == b"y" and op.dict_get(int(a[2])) == b""
     op.done()
+
+
+def test_runtime_specialisation_compiles_without_a_gpu():
+    """A plan shape that has no ahead-of-time kernel is instantiated through hiprtc (compile only, gfx950)."""
+    import numpy as np
+    pj = plan.filter_group_plan("((10 < (`d`.`x`)) and ((`d`.`x`) <= 90.5))", ["(`d`.`k`)"],
+                                ["avg((`d`.`x`))", "count(*)", "max((`d`.`y`))"])
+    op = query_amd.GpuFilterGroup(pj)
+    assert op.column_paths == ["(`d`.`x`)", "(`d`.`k`)", "(`d`.`y`)"]
+    kinds = np.array([_ffi.COL_TAGGED64, _ffi.COL_DICT32, _ffi.COL_TAGGED64], dtype=np.uint32)
+    log = C.create_string_buffer(4096)
+    st = _ffi.lib().n1k_jit_check(op._h, kinds.ctypes.data, 3, log, 4096)
+    assert st == _ffi.OK, log.value.decode(errors="replace")
+    op.done()

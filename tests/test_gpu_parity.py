@@ -98,6 +98,33 @@ def test_hashed_spec_kernel_with_more_groups_than_lds_slots():
     pu.assert_same_groups(gpu, ora, aggs=aggs)
 
 
+JIT_SHAPES = [
+    ("((10 < %s) and (%s <= 90.5))" % (D("price"), D("price")), [D("cat")],
+     ["avg(%s)" % D("price"), "count(*)", "max(%s)" % D("user_id")]),
+    ("(%s is not null)" % D("price"), [D("cat")], ["min(%s)" % D("price"), "sum(%s)" % D("region_id")]),
+    ("(%s = \"cat_3\")" % D("cat"), [D("cat")], ["count(%s)" % D("price"), "countn(%s)" % D("price")]),
+    ("(%s < 30)" % D("price"), [D("region_id")], ["count(*)", "min(%s)" % D("price")]),
+    (None, [], ["sum(%s)" % D("price"), "avg(%s)" % D("user_id")]),
+    ("(50 <= %s)" % D("price"), [D("cat"), D("region_id")], ["max(%s)" % D("price")]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(JIT_SHAPES)))
+def test_runtime_specialised_kernels_agree_with_the_oracle(case):
+    """Shapes without an ahead-of-time kernel: the scan template is instantiated at run time (hiprtc) when forced
+    (jit=2; by default only large batches trigger it).  Same semantics, checked against the oracle."""
+    cond, keys, aggs = JIT_SHAPES[case]
+    aggs = sorted(aggs)
+    t = n1o.synth_table(90_001, k_cat=23, zipf=True)
+    ora = n1o.run(t, cond, keys, aggs)
+    gpu, stats = pu.run_gpu(t, cond, keys, aggs, device_resident=True, jit=2)
+    assert stats["spec_kernel"] == 2, "the run-time instantiation did not run"
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert stats["rows_selected"] == ora.rows_passed
+    gpu2, stats2 = pu.run_gpu(t, cond, keys, aggs, device_resident=False, batches=3, jit=2)
+    pu.assert_same_groups(gpu2, ora, aggs=aggs)
+
+
 def test_unaligned_device_columns():
     """Columns that start at an odd row of a larger allocation cannot use 16-byte loads: same results."""
     import torch
@@ -243,7 +270,8 @@ def test_distinct_over_mixed_types_and_edge_values():
     gt = np.full(n, n1o.T_INT, np.uint8)
     t = n1o.Table([n1o.Column(D("g"), n1o.COL_TAGGED64, tags=gt, payload=grp),
                    n1o.Column(D("v"), n1o.COL_TAGGED64, tags=tags, payload=pay)], strs)
-    aggs = sorted(["count(distinct %s)" % D("v"), "countn(distinct %s)" % D("v"), "count(%s)" % D("v")])
+    aggs = sorted(["count(distinct %s)" % D("v"), "countn(distinct %s)" % D("v"), "count(%s)" % D("v"),
+                   "sum(distinct %s)" % D("v"), "avg(distinct %s)" % D("v")])
     for keys in ([D("g")], []):
         ora = n1o.run(t, None, keys, aggs)
         gpu, _ = pu.run_gpu(t, None, keys, aggs, batches=2)

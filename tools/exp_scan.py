@@ -49,6 +49,8 @@ def main():
                                  {"block": block, "grid_blocks": grid, "slabs": slabs}, False))
         variants += [
             ("filter-only", c2[0], [], [], {}, True),
+            ("le+avg,count jit", "(%s <= 50.5)" % D("price"), [D("cat")], ["avg(%s)" % D("price"), "count(*)"], {}, False),
+            ("le+avg,count nojit", "(%s <= 50.5)" % D("price"), [D("cat")], ["avg(%s)" % D("price"), "count(*)"], {"jit": 0}, False),
             ("intkey sum spec", None, [D("region_id")], ["sum(%s)" % D("price")], {}, False),
             ("intkey sum interp", None, [D("region_id")], ["sum(%s)" % D("price")], {"fast": 0}, False),
             ("cat+region sum spec", None, [D("cat"), D("region_id")], ["sum(%s)" % D("price")], {}, False),
