@@ -149,6 +149,7 @@ typedef struct n1k_stats {
     uint64_t bytes_scanned; /* algorithmic column bytes read by the scan kernel */
     uint32_t agg_mode;      /* n1k_agg_mode actually used by the last batch */
     uint32_t spec_kernel;   /* plan-specialised kernel that ran the last batch: 0 none, 1 prebuilt, 2 built at run time */
+    uint64_t wide_key_values; /* distinct key numbers held in the wide-value tables (floats, |int| beyond the field); set by finish/export */
 } n1k_stats;
 
 typedef enum n1k_agg_mode {
@@ -224,7 +225,8 @@ n1k_status n1k_dict_get(const n1k_handle *h, uint32_t code, const char **ptr, si
  *         "grid_blocks" / "block" / "rows_per_lane" / "lds_bytes" (launch tuning, 0 = auto),
  *         "fast" / "spec" / "wide" / "slabs" (0/1: kernel selection switches used by the ablation tests),
  *         "jit" (0 off, 1 = compile a specialised kernel for large batches of unregistered shapes, 2 = always),
- *         "jit_min_rows"} */
+ *         "jit_min_rows", "wide_values" (before the first push: how many distinct float / wide-integer group key
+ *         values the handle can code, default 1<<20; 0 = such keys are N1K_UNSUPPORTED_DATA)} */
 n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);
 
 /* ----------------------------------------------------------------- data ---- */

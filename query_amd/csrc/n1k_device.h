@@ -220,47 +220,96 @@ N1K_DEV int64_t unzigzag(uint64_t z) { return (int64_t)(z >> 1) ^ -(int64_t)(z &
 // key (execution/group_util.go:18-35): MISSING and NULL are distinct, FALSE/TRUE, numbers by value
 // (integral floats fold to the int they equal: value/float.go:31-48 prints 5.0 as "5"), strings /
 // arrays / objects by dictionary code of their (canonical) text.
-N1K_DEV bool pack_key_field(const KeySpec& k, uint32_t tag, uint64_t p, uint64_t& field) {
+// Code of a wide key value: its slot in the handle's value table (find-or-insert, single-word CAS).  The codes
+// are local to the handle (they depend on insertion order), so packed keys holding them never leave the device:
+// finalize_kernel turns them back into values, and the multi-GPU exchange hashes the value itself.
+N1K_DEV bool wide_code(uint64_t* tab, uint32_t bits, unsigned long long* count, uint64_t payload, uint64_t& code) {
+    if (!tab) return false;
+    const uint64_t mask = (1ull << bits) - 1ull;
+    uint64_t h = mix64(payload) & mask;
+    for (uint64_t probe = 0; probe <= mask; probe++) {
+        unsigned long long cur = __hip_atomic_load((unsigned long long*)&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmptyKey) {
+            cur = atomicCAS((unsigned long long*)&tab[h], (unsigned long long)kEmptyKey, (unsigned long long)payload);
+            if (cur == kEmptyKey) {
+                atomicAdd(count, 1ull);
+                cur = payload;
+            }
+        }
+        if (cur == payload) {
+            code = h;
+            return true;
+        }
+        h = (h + 1ull) & mask;
+    }
+    return false;
+}
+
+// field classes of a TAGGED key: 0 MISSING 1 NULL 2 FALSE 3 TRUE 4 INT (zigzag in the field) 5 STRING 6 ARRAY
+// 7 OBJECT (dictionary code) 8 wide INT 9 FLOAT (code of the value table).  `canon` is a handle-independent
+// image of the field (what the multi-GPU row exchange hashes).
+N1K_DEV bool pack_key_field(const Program& P, const KeySpec& k, uint32_t tag, uint64_t p, uint64_t& field, uint64_t& canon) {
     if (k.mode == KEYM_DICT) {
         // DICT32 columns / pure string keys: 0 MISSING, 1 NULL, code+2
         if (tag == T_MISSING) field = 0;
         else if (tag == T_NULL) field = 1;
         else if (tag == T_STRING) field = p + 2;
         else return false;
+        canon = field;
         return k.bits >= 64 || field < (1ull << k.bits);
     }
+    const uint32_t sb = k.bits - 4;
     uint64_t cls, sub = 0;
+    bool num = false;
+    int64_t iv = 0;
     switch (tag) {
         case T_MISSING: cls = 0; break;
         case T_NULL: cls = 1; break;
         case T_FALSE: cls = 2; break;
         case T_TRUE: cls = 3; break;
-        case T_INT: cls = 4; sub = zigzag((int64_t)p); break;
+        case T_INT: cls = 4; num = true; iv = (int64_t)p; break;
         case T_FLOAT: {
             double d = as_f64(p);
-            if (!is_int_f64(d)) return false;  // non-integral float keys need the wide-key path
-            cls = 4;
-            sub = zigzag(go_f2i(d));
+            // 5.0 and 5 are one group: both print "5" (value/float.go:31-48).  From 2^53 up FormatFloat's shortest
+            // digits are no longer the integer's own ("-9223372036854776000" for -2^63), so such floats stay floats.
+            if (is_int_f64(d) && d > -9007199254740992.0 && d < 9007199254740992.0) {
+                cls = 4;
+                num = true;
+                iv = go_f2i(d);
+            } else {
+                cls = 9;
+                uint64_t bits = d != d ? 0x7FF8000000000000ull : p;  // one NaN
+                canon = mix64(bits) ^ 9ull;
+                if (P.wide_bits > sb || !wide_code(P.wide_flt, P.wide_bits, P.wide_count, bits, sub)) return false;
+            }
             break;
         }
         case T_STRING: cls = 5; sub = p; break;
         case T_ARRAY: cls = 6; sub = p; break;
         default: cls = 7; sub = p; break;
     }
-    uint32_t sb = k.bits - 3;
+    if (num) {
+        sub = zigzag(iv);
+        if (sb < 64 && sub >= (1ull << sb)) {
+            cls = 8;
+            canon = mix64((uint64_t)iv) ^ 8ull;
+            if (P.wide_bits > sb || !wide_code(P.wide_int, P.wide_bits, P.wide_count, (uint64_t)iv, sub)) return false;
+        }
+    }
     if (sb < 64 && sub >= (1ull << sb)) return false;
-    field = (sub << 3) | cls;
+    field = (sub << 4) | cls;
+    if (cls < 8) canon = field;
     return true;
 }
 
-N1K_DEV void unpack_key_field(uint32_t mode, uint64_t field, uint32_t& tag, uint64_t& p) {
+N1K_DEV void unpack_key_field(const Program& P, uint32_t mode, uint64_t field, uint32_t& tag, uint64_t& p) {
     if (mode == KEYM_DICT) {
         if (field == 0) { tag = T_MISSING; p = 0; }
         else if (field == 1) { tag = T_NULL; p = 0; }
         else { tag = T_STRING; p = field - 2; }
         return;
     }
-    uint64_t cls = field & 7ull, sub = field >> 3;
+    uint64_t cls = field & 15ull, sub = field >> 4;
     p = 0;
     switch (cls) {
         case 0: tag = T_MISSING; break;
@@ -270,7 +319,9 @@ N1K_DEV void unpack_key_field(uint32_t mode, uint64_t field, uint32_t& tag, uint
         case 4: tag = T_INT; p = (uint64_t)unzigzag(sub); break;
         case 5: tag = T_STRING; p = sub; break;
         case 6: tag = T_ARRAY; p = sub; break;
-        default: tag = T_OBJECT; p = sub; break;
+        case 7: tag = T_OBJECT; p = sub; break;
+        case 8: tag = T_INT; p = P.wide_int[sub]; break;
+        default: tag = T_FLOAT; p = P.wide_flt[sub]; break;
     }
 }
 

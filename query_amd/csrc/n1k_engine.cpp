@@ -82,6 +82,8 @@ struct n1k_handle {
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
     uint64_t opt_jit_min_rows = 4u << 20;
+    uint64_t opt_wide_values = 1u << 20;  // capacity of the wide key value tables (distinct big ints / floats)
+    DevBuf<uint64_t> d_wide_int, d_wide_flt;
     std::string jit_log;
     int device = -1;
     bool device_ready = false;
@@ -461,7 +463,24 @@ n1k_status fix_layout(n1k_handle* h, const n1k_batch* b) {
         ks.bits = ks.mode == KEYM_DICT ? dbits : tbits;
         ks.shift = shift;
         shift += ks.bits;
-        if (ks.bits < 4) return fail(h, N1K_UNSUPPORTED, "group key layout does not fit 63 bits");
+        if (ks.bits < (ks.mode == KEYM_DICT ? 4u : 8u)) return fail(h, N1K_UNSUPPORTED, "group key layout does not fit 63 bits");
+    }
+    // value tables for the numbers a TAGGED field cannot hold itself (n1k_device.h: wide_code)
+    P.wide_int = P.wide_flt = nullptr;
+    P.wide_bits = 0;
+    P.wide_count = h->d_counters.p + 13;
+    if (n_tag && h->opt_wide_values) {
+        uint32_t wb = 4;
+        while ((1ull << wb) < h->opt_wide_values * 2 && wb < 30) wb++;
+        wb = std::min(wb, tbits - 4);
+        const size_t n = (size_t)1 << wb;
+        HIP_TRY(h, h->d_wide_int.ensure(n));
+        HIP_TRY(h, h->d_wide_flt.ensure(n));
+        HIP_TRY(h, hipMemsetAsync(h->d_wide_int.p, 0xFF, n * 8, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_wide_flt.p, 0xFF, n * 8, h->stream));
+        P.wide_int = h->d_wide_int.p;
+        P.wide_flt = h->d_wide_flt.p;
+        P.wide_bits = wb;
     }
     h->layout_fixed = true;
     return N1K_OK;
@@ -1030,6 +1049,8 @@ void n1k_destroy(n1k_handle* h) {
             h->d_log_cls[d].release();
         }
         h->d_counters.release();
+        h->d_wide_int.release();
+        h->d_wide_flt.release();
         for (auto& b : h->st_tags) b.release();
         for (auto& b : h->st_payload) b.release();
         for (auto& b : h->st_codes) b.release();
@@ -1064,6 +1085,11 @@ n1k_status n1k_reset(n1k_handle* h) {
         // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
+        if (h->prog.wide_int) {
+            const size_t n = (size_t)1 << h->prog.wide_bits;
+            HIP_TRY(h, hipMemsetAsync(h->d_wide_int.p, 0xFF, n * 8, h->stream));
+            HIP_TRY(h, hipMemsetAsync(h->d_wide_flt.p, 0xFF, n * 8, h->stream));
+        }
     }
     return N1K_OK;
 }
@@ -1114,6 +1140,10 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "wide") h->opt_wide = value ? 1 : 0;
     else if (n == "jit") h->opt_jit = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
     else if (n == "jit_min_rows") h->opt_jit_min_rows = (uint64_t)std::max<int64_t>(value, 0);
+    else if (n == "wide_values") {
+        if (h->layout_fixed) return fail(h, N1K_INVALID, "wide_values must be set before the first batch");
+        h->opt_wide_values = (uint64_t)std::max<int64_t>(value, 0);
+    }
     else if (n == "slabs") h->opt_slabs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);  // 0 off, 1 auto, 2 always
     else if (n == "block") {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(h, N1K_INVALID, "block must be 0 (auto), 256, 512 or 1024");
@@ -1226,6 +1256,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
         return N1K_OK;
     }
     h->stats.rows_selected = counters[0];
+    h->stats.wide_key_values = counters[13];
     uint64_t ng = counters[1];
     h->r_keys.clear();
     h->r_aggs.clear();
@@ -1296,7 +1327,9 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
                     (unsigned long long)h->opt_max_groups);
     if (err_flags & ERR_UNPACKABLE_KEY)
         return fail(h, N1K_UNSUPPORTED_DATA,
-                    "a group key value does not fit the packed key (non-integral float or very wide integer key)");
+                    "a group key value does not fit the packed key: more than %llu distinct float / wide integer key "
+                    "values (option wide_values), or a key layout too narrow for them",
+                    (unsigned long long)((1ull << h->prog.wide_bits) / 2));
     if (err_flags & ERR_UNSUPPORTED_VALUE)
         return fail(h, N1K_UNSUPPORTED_DATA, "a value outside the device subset was met (ordering of arrays/objects)");
     if (ng == 0 && nk == 0) {
@@ -1422,11 +1455,18 @@ n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t c
         HIP_TRY(h, launch_export_partials(h->prog, h->table, nparts, capacity_groups, (uint64_t*)out, region_words,
                                           h->d_errp, h->stream));
     uint32_t err_flags = 0;
-    unsigned long long sel = 0;
+    unsigned long long sel = 0, wide = 0;
     HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(&sel, h->d_counters.p, sizeof sel, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&wide, h->d_counters.p + 13, sizeof wide, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stats.rows_selected = sel;
+    h->stats.wide_key_values = wide;
+    // codes of the wide-value tables mean nothing on another device: such groups travel as rows instead
+    if (wide) {
+        HIP_TRY(h, hipMemsetAsync(h->d_errp, 0, 4, h->stream));  // a region overflow of the abandoned export is moot
+        return fail(h, N1K_UNSUPPORTED, "group keys hold %llu float / wide integer values: use the row exchange", wide);
+    }
     if (err_flags & ERR_TABLE_FULL) {
         HIP_TRY(h, hipMemsetAsync(h->d_errp, 0, 4, h->stream));
         return fail(h, N1K_OOM, "more than %llu groups for one destination: raise the region capacity",

@@ -420,8 +420,8 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
             load_operand<R>(P, ks.src, row, pass, kt, kp);
 #pragma unroll
             for (int j = 0; j < R; j++) {
-                uint64_t f = 0;
-                bool ok = !pass[j] || pack_key_field(ks, kt[j], kp[j], f);
+                uint64_t f = 0, canon;
+                bool ok = !pass[j] || pack_key_field(P, ks, kt[j], kp[j], f, canon);
                 if (DIRECT) ok = ok && f < (uint64_t)A.direct_radix[k];
                 if (!ok) {
                     unpackable = 1;
@@ -860,6 +860,7 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
             valid[j] = row[j] < A.nrows;
         }
         eval_predicate<R>(P, row, valid, pass, unsupported);
+        // the destination is a function of the key VALUES (wide-value codes are local to a handle)
         uint64_t key[R];
 #pragma unroll
         for (int j = 0; j < R; j++) key[j] = 0;
@@ -870,18 +871,18 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
             load_operand<R>(P, ks.src, row, pass, kt, kp);
 #pragma unroll
             for (int j = 0; j < R; j++) {
-                uint64_t f = 0;
-                if (pass[j] && !pack_key_field(ks, kt[j], kp[j], f)) {
+                uint64_t f = 0, canon = 0;
+                if (pass[j] && !pack_key_field(P, ks, kt[j], kp[j], f, canon)) {
                     unpackable = 1;
                     pass[j] = false;
                 }
-                key[j] |= f << ks.shift;
+                key[j] = mix64(key[j] ^ canon) + k;
             }
         }
         uint64_t pos[R];
 #pragma unroll
         for (int j = 0; j < R; j++) {
-            uint32_t dest = (uint32_t)(((mix64(key[j]) >> 32) * (uint64_t)A.nparts) >> 32);
+            uint32_t dest = (uint32_t)(((key[j] >> 32) * (uint64_t)A.nparts) >> 32);
             pos[j] = 0;
             for (uint32_t d = 0; d < A.nparts; d++) {
                 unsigned long long m = __ballot(pass[j] && dest == d);
@@ -1282,7 +1283,7 @@ __global__ void finalize_kernel(const Program P, const GlobalTable G, OutValue* 
         uint64_t field = ks.bits >= 64 ? key : ((key >> ks.shift) & ((1ull << ks.bits) - 1ull));
         uint32_t tag;
         uint64_t p;
-        unpack_key_field(ks.mode, field, tag, p);
+        unpack_key_field(P, ks.mode, field, tag, p);
         put_value(&out_keys[idx * P.nkeys + k], tag, p);
     }
     const uint64_t* g = &G.acc[(size_t)s * P.glob_words];

@@ -149,8 +149,8 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
         // open-addressed LDS table on the packed key (integer / mixed keys, or a dictionary domain beyond the LDS)
 #pragma unroll
         for (int k = 0; k < Spec::nkeys; k++) {
-            uint64_t f = 0;
-            if (!pack_key_field(P.keys[k], tg[Spec::key_col[k]], pv[Spec::key_col[k]], f)) {
+            uint64_t f = 0, canon;
+            if (!pack_key_field(P, P.keys[k], tg[Spec::key_col[k]], pv[Spec::key_col[k]], f, canon)) {
                 unpackable = 1;
                 return;
             }

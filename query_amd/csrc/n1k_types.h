@@ -148,6 +148,12 @@ struct Program {
     uint32_t dict_size;
     uint32_t empty_str_code, empty_arr_code, empty_obj_code;  // codes of "", "[]", "{}" or 0xFFFFFFFF
     const uint32_t* str_rank;  // rank[code]: bytewise order of the dictionary strings (value/string.go:116-130)
+    // wide key values: numbers that do not fit a key bit field (non-integral floats, big ints) are replaced by
+    // their slot in one of these per-handle open-addressed value tables (2^wide_bits entries, kEmptyKey = free)
+    uint64_t* wide_int;
+    uint64_t* wide_flt;
+    unsigned long long* wide_count;  // distinct wide values met so far
+    uint32_t wide_bits, pad1;
     DevCol cols[kMaxCols];
     Term terms[kMaxTerms];
     LogicOp logic[kMaxLogic];

@@ -154,12 +154,20 @@ class ShardedFilterGroup:
                 # a destination got more groups than a region holds: tell every receiver through the region headers
                 # (word 1), so that all ranks agree to retry with larger regions without an extra collective
                 send.view(torch.int64)[1::region // 8] = 1
+            elif st == _ffi.UNSUPPORTED:
+                # this shard's keys hold float / wide-integer values, coded by device-local value tables: the
+                # groups cannot travel in packed form.  Same header channel: every rank switches to the row exchange.
+                send.view(torch.int64)[1::region // 8] = 2
             else:
                 op._check(st)
             dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
             overflow = int(recv.view(torch.int64)[1::region // 8].max().item())  # also orders the collective before the merge
             if not overflow:
                 break
+            if overflow == 2:
+                raw, info = self.run(nrows, cols_by_path)
+                info["mode"] = "rows (wide key values)"
+                return raw, info
             self.partial_capacity *= 4
         op.sync()  # drains the HIP events: stats now hold this step's scan time
         stats = op.stats()

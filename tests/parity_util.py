@@ -85,10 +85,24 @@ def values_match(g, o, rel=REL_TOL, float_agg=False) -> bool:
     return g[1] == o[1]
 
 
+def _canon_key(k):
+    """Key values as value.NewValue would hold them: an integral float IS the int (value/value.go NewValue folds
+    float64 with no fraction into intValue), so (FLOAT, 5.0) from a raw column and (INT, 5) name the same key
+    (both print "5"; from 2^53 up the float's shortest digits differ from the integer's and the keys stay apart)."""
+    out = []
+    for tag, v in k:
+        if tag == n1o.T_FLOAT and not math.isnan(v) and not math.isinf(v) and v == int(v) and abs(v) < 2.0 ** 53:
+            tag, v = n1o.T_INT, int(v)
+        elif tag == n1o.T_FLOAT and math.isnan(v):
+            v = "NaN"
+        out.append((tag, v))
+    return tuple(out)
+
+
 def assert_same_groups(gpu, ora, rel=REL_TOL, aggs: Optional[Sequence[str]] = None):
     assert gpu.nkeys == ora.nkeys and gpu.naggs == ora.naggs
-    gmap = {tuple(k): a for k, a in zip(gpu.keys, gpu.aggs)}
-    omap = {tuple(k): a for k, a in zip(ora.keys, ora.aggs)}
+    gmap = {_canon_key(k): a for k, a in zip(gpu.keys, gpu.aggs)}
+    omap = {_canon_key(k): a for k, a in zip(ora.keys, ora.aggs)}
     assert len(gmap) == len(gpu.keys), "device emitted a duplicate group (NewDuplicateFinalGroupError)"
     missing = set(omap) - set(gmap)
     extra = set(gmap) - set(omap)

@@ -43,12 +43,13 @@ def _device_cols(t, paths):
     return dev, keep
 
 
+@pytest.mark.parametrize("keys", [KEYS, [D("price")], [D("cat"), D("region_id")]], ids=["dict", "float", "dict+int"])
 @pytest.mark.parametrize("nparts", [1, 3, 8])
-def test_partition_kernel_routes_every_survivor_once(nparts):
+def test_partition_kernel_routes_every_survivor_once(nparts, keys):
     import torch
     n = 90_001
     t = n1o.synth_table(n, k_cat=29, zipf=True)
-    sender = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, KEYS, AGGS))
+    sender = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, keys, AGGS))
     sender.intern(list(t.dictionary))
     paths = sender.column_paths
     dev, keep = _device_cols(t, paths)
@@ -76,11 +77,11 @@ def test_partition_kernel_routes_every_survivor_once(nparts):
     ora_sel = n1o.run(t, COND, [], [], has_group=False).selected
     assert int(cnt.sum()) == len(ora_sel)  # every survivor exactly once
     # a group key lives in exactly one part, and the union of the parts' groups is the oracle's answer
-    ora = n1o.run(t, COND, KEYS, AGGS)
+    ora = n1o.run(t, COND, keys, AGGS)
     seen = {}
     merged_keys, merged_aggs = [], []
     for d in range(nparts):
-        recv = query_amd.GpuFilterGroup(plan.filter_group_plan(None, KEYS, AGGS))
+        recv = query_amd.GpuFilterGroup(plan.filter_group_plan(None, keys, AGGS))
         recv.intern(list(t.dictionary))
         rcols = []
         for p in recv.column_paths:
@@ -99,7 +100,7 @@ def test_partition_kernel_routes_every_survivor_once(nparts):
             merged_aggs.append(a)
     sender.done()
     from query_amd.gpu_operator import GroupRows
-    pu.assert_same_groups(GroupRows(1, len(AGGS), merged_keys, merged_aggs, []), ora, aggs=AGGS)
+    pu.assert_same_groups(GroupRows(len(keys), len(AGGS), merged_keys, merged_aggs, []), ora, aggs=AGGS)
 
 
 def test_partial_groups_export_merge_roundtrip():
@@ -187,5 +188,35 @@ def test_rank_pipeline_world1_rccl():
         aggs = op.receiver._py_values(raw["aggs"], cache)
         from query_amd.gpu_operator import GroupRows
         pu.assert_same_groups(GroupRows(1, len(AGGS), keys, aggs, []), ora, aggs=AGGS)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_pipeline_falls_back_to_rows_for_wide_key_values():
+    """Float group keys are coded by a device-local value table, so partial groups cannot travel in packed form:
+    every rank must agree (through the region headers) to use the row exchange instead."""
+    import torch
+    import torch.distributed as dist
+    from query_amd import distributed as qd
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n = 50_000
+        t = n1o.synth_table(n, k_cat=50)
+        keys, aggs = [D("price")], sorted(["count(*)", "max(%s)" % D("user_id")])
+        op = qd.ShardedFilterGroup(COND, keys, aggs, t.dictionary, 0, 1, 0)
+        dev, keep = _device_cols(t, op.send_paths)
+        raw, info = op.run_partials(n, dev)
+        assert info["mode"].startswith("rows")
+        ora = n1o.run(t, COND, keys, aggs)
+        from query_amd.gpu_operator import GroupRows
+        cache = {}
+        got = GroupRows(1, len(aggs), op.receiver._py_values(raw["keys"], cache), op.receiver._py_values(raw["aggs"], cache), [])
+        pu.assert_same_groups(got, ora, aggs=aggs)
     finally:
         dist.destroy_process_group()

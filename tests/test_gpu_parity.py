@@ -176,10 +176,11 @@ def test_key_shapes(keys):
     n = 60_000
     t = n1o.synth_table(n, k_cat=50)
     if keys == [D("price")]:
-        # non-integral float keys are outside the packed-key subset: must be reported, not mis-grouped
-        with pytest.raises(query_amd.N1kError) as ei:
-            pu.run_gpu(t, None, keys, ["count(*)"])
-        assert ei.value.status == _ffi.UNSUPPORTED_DATA
+        # non-integral float keys: grouped through the wide-value tables (about 10 k distinct prices)
+        ora = n1o.run(t, None, keys, ["count(*)"])
+        gpu, stats = pu.run_gpu(t, None, keys, ["count(*)"])
+        pu.assert_same_groups(gpu, ora)
+        assert stats["wide_key_values"] > 5000
         return
     aggs = sorted(["count(*)", "sum(%s)" % D("price"), "max(%s)" % D("user_id")])
     ora = n1o.run(t, "(%s is not missing)" % D("price"), keys, aggs)
@@ -399,3 +400,70 @@ def test_empty_batches_and_zero_rows():
     op.done()
     ora = n1o.run(t, "(50 < %s)" % D("price"), [D("cat")], aggs)
     pu.assert_same_groups(gpu, ora, aggs=aggs)
+
+
+def _f64(x):
+    return np.array([x], np.float64).view(np.uint64)[0]
+
+
+def _wide_key_table(n, seed=5):
+    """A key column holding every scalar class, numbers a packed field cannot hold (non-integral floats, ints
+    beyond +-2^58, the int64 extremes, +-Inf) and the pairs that must collide (5 / 5.0, 0 / -0.0, -2^63 / -2^63.0)."""
+    rng = np.random.default_rng(seed)
+    pool = [(n1o.T_INT, 5), (n1o.T_FLOAT, _f64(5.0)), (n1o.T_INT, 0), (n1o.T_FLOAT, _f64(-0.0)),
+            (n1o.T_FLOAT, _f64(2.5)), (n1o.T_FLOAT, _f64(-2.5)), (n1o.T_FLOAT, _f64(1e300)), (n1o.T_FLOAT, _f64(1e-300)),
+            (n1o.T_FLOAT, _f64(float("inf"))), (n1o.T_FLOAT, _f64(float("-inf"))),
+            (n1o.T_INT, np.uint64(2 ** 63 - 1)), (n1o.T_INT, np.int64(-2 ** 63).view(np.uint64)),
+            (n1o.T_FLOAT, _f64(-2.0 ** 63)), (n1o.T_FLOAT, _f64(2.0 ** 63)), (n1o.T_INT, np.uint64(2 ** 60)),
+            (n1o.T_INT, np.int64(-2 ** 60).view(np.uint64)), (n1o.T_FLOAT, _f64(2.0 ** 60)),
+            (n1o.T_INT, np.uint64(4617878467915022336)),  # the int whose bits spell 5.5
+            (n1o.T_FLOAT, _f64(5.5)), (n1o.T_NULL, 0), (n1o.T_MISSING, 0), (n1o.T_TRUE, 0), (n1o.T_FALSE, 0),
+            (n1o.T_STRING, 0), (n1o.T_STRING, 1)]
+    pick = rng.integers(0, len(pool), n)
+    tags = np.array([pool[i][0] for i in pick], np.uint8)
+    pay = np.array([int(pool[i][1]) for i in pick], np.uint64)
+    # plus a tail of many distinct floats and wide ints
+    m = n // 4
+    tags[:m] = n1o.T_FLOAT
+    pay[:m] = (rng.integers(0, 3000, m) + 0.25).view(np.uint64)
+    tags[m:2 * m] = n1o.T_INT
+    pay[m:2 * m] = (rng.integers(0, 3000, m).astype(np.int64) * np.int64(-(2 ** 59 + 1))).view(np.uint64)
+    vals = rng.integers(-50, 50, n).astype(np.int64)
+    cat = rng.integers(0, 7, n).astype(np.uint32)
+    return n1o.Table([n1o.Column(D("k"), n1o.COL_TAGGED64, tags=tags, payload=pay),
+                      n1o.Column(D("v"), n1o.COL_TAGGED64, tags=np.full(n, n1o.T_INT, np.uint8), payload=vals.view(np.uint64)),
+                      n1o.Column(D("cat"), n1o.COL_DICT32, codes=cat)],
+                     [b"s%d" % i for i in range(7)])
+
+
+@pytest.mark.parametrize("keys", [[D("k")], [D("cat"), D("k")], [D("k"), D("k")]])
+@pytest.mark.parametrize("opts", [{}, {"spec": 0}, {"fast": 0, "spec": 0}, {"jit": 2}], ids=["auto", "fast", "interp", "jit"])
+def test_wide_key_values_group_like_the_reference(keys, opts):
+    """execution/group_util.go:18-35 groups on the canonical JSON of the key values: floats, huge ints and the
+    int/float pairs that print alike.  On the device such numbers are keyed by their value-table code."""
+    t = _wide_key_table(40_000)
+    aggs = sorted(["count(*)", "sum(%s)" % D("v"), "min(%s)" % D("v")])
+    ora = n1o.run(t, None, keys, aggs, threads=2)
+    gpu, stats = pu.run_gpu(t, None, keys, aggs, batches=3, **opts)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert stats["wide_key_values"] >= 5000
+
+
+def test_wide_key_value_table_overflow_is_reported():
+    t = _wide_key_table(40_000)
+    with pytest.raises(query_amd.N1kError) as ei:
+        pu.run_gpu(t, None, [D("k")], ["count(*)"], wide_values=64)
+    assert ei.value.status == _ffi.UNSUPPORTED_DATA and "wide_values" in ei.value.message
+
+
+def test_wide_key_values_survive_reopen():
+    t = _wide_key_table(20_000)
+    pj = query_amd.plan.filter_group_plan(None, [D("k")], ["count(*)"])
+    op = query_amd.GpuFilterGroup(pj)
+    by = {c.name: c for c in t.columns}
+    ora = n1o.run(t, None, [D("k")], ["count(*)"])
+    for _ in range(2):
+        op.process_items([by[p] for p in op.column_paths], t.dictionary)
+        pu.assert_same_groups(op.after_items(), ora)
+        op.reopen()
+    op.done()
