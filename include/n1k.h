@@ -291,8 +291,14 @@ n1k_status n1k_partition_device_batch(n1k_handle *h, const n1k_batch *batch, uin
  * n1k_export_partials_device: write every group of the handle (packed key + raw accumulators) into `nparts`
  * regions of `out` (device memory) by hash(group key) % nparts — the same hash as
  * n1k_partition_device_batch.  Region d (region_bytes = n1k_partial_region_bytes(h, capacity_groups)) is
- *     [count u64][reserved u64][keys: capacity x u64][accumulators: capacity x n1k_partial_words(h) x u64]
- * so that ONE all-to-all with equal splits moves all regions.  N1K_OOM when a region overflows.
+ *     [count u64][verdict u64][keys: capacity x u64][accumulators: capacity x n1k_partial_words(h) x u64]
+ * so that ONE all-to-all with equal splits moves all regions.  N1K_OOM when a region overflows; N1K_UNSUPPORTED
+ * when the keys hold float / wide-integer values (their codes are local to the handle).
+ *
+ * n1k_export_partials_async: the same, ordered on the handle's stream with no host synchronisation.  The two
+ * failures above are written into the `verdict` word of EVERY region instead (bit 0 overflow, bit 1 wide values),
+ * so that each receiver learns them from the exchange itself: n1k_merge_partials_device then merges nothing and
+ * the receiver's n1k_finish returns N1K_OOM / N1K_UNSUPPORTED — on all ranks alike, which lets them retry in step.
  *
  * n1k_merge_partials_device: ≙ CumulateIntermediate (execution/group_intermediate.go:91-101) over `nregions`
  * regions of that layout (device memory), e.g. what the all-to-all delivered.  The handle must have the same
@@ -305,6 +311,7 @@ n1k_status n1k_partition_device_batch(n1k_handle *h, const n1k_batch *batch, uin
 uint32_t n1k_partial_words(const n1k_handle *h);
 uint64_t n1k_partial_region_bytes(const n1k_handle *h, uint64_t capacity_groups);
 n1k_status n1k_export_partials_device(n1k_handle *h, uint32_t nparts, uint64_t capacity_groups, void *out);
+n1k_status n1k_export_partials_async(n1k_handle *h, uint32_t nparts, uint64_t capacity_groups, void *out);
 n1k_status n1k_merge_partials_device(n1k_handle *h, uint32_t nregions, uint64_t capacity_groups, const void *in);
 n1k_status n1k_export_groups(n1k_handle *h, const void **blob, size_t *len);
 n1k_status n1k_merge_groups(n1k_handle *h, const void *blob, size_t len);

@@ -84,6 +84,8 @@ struct n1k_handle {
     uint64_t opt_jit_min_rows = 4u << 20;
     uint64_t opt_wide_values = 1u << 20;  // capacity of the wide key value tables (distinct big ints / floats)
     DevBuf<uint64_t> d_wide_int, d_wide_flt;
+    char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
+    size_t pin_cap = 0;
     std::string jit_log;
     int device = -1;
     bool device_ready = false;
@@ -1051,6 +1053,7 @@ void n1k_destroy(n1k_handle* h) {
         h->d_counters.release();
         h->d_wide_int.release();
         h->d_wide_flt.release();
+        if (h->pin_out) (void)hipHostFree(h->pin_out);
         for (auto& b : h->st_tags) b.release();
         for (auto& b : h->st_payload) b.release();
         for (auto& b : h->st_codes) b.release();
@@ -1221,8 +1224,12 @@ n1k_status n1k_sync(n1k_handle* h) {
     if (!h) return N1K_INVALID;
     if (!h->device_ready) return N1K_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long counters[16] = {0};
+    HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     drain_events(h);
+    if (h->plan.has_group) h->stats.rows_selected = counters[0];
+    h->stats.wide_key_values = counters[13];
     return N1K_OK;
 }
 
@@ -1236,10 +1243,38 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     out->naggs = na;
     uint32_t err_flags = 0;
     unsigned long long counters[16] = {0};
+    const size_t rec_keys = (size_t)nk * sizeof(OutValue), rec_aggs = (size_t)na * sizeof(OutValue),
+                 rec_parts = (size_t)na * sizeof(OutPartial);
+    // Speculative FinalGroup: when the plan has no DISTINCT step the finalize kernel does not depend on anything the
+    // host has to read first, so it is launched for up to `spec_groups` groups together with the copy of the
+    // counters: ONE host synchronisation per query when the result fits (else the sized pass below runs as well).
+    uint64_t spec_groups = 0;
     if (h->device_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
-        HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (pl.has_group && !h->has_distinct && h->table.capacity) {
+            spec_groups = std::min<uint64_t>(h->table.capacity, 4096);
+            const size_t off_aggs = spec_groups * rec_keys, off_parts = off_aggs + spec_groups * rec_aggs,
+                         off_rep = off_parts + spec_groups * rec_parts, total = off_rep + spec_groups * 8;
+            HIP_TRY(h, h->d_out.ensure(total + 16));
+            if (h->pin_cap < total + sizeof counters) {
+                if (h->pin_out) (void)hipHostFree(h->pin_out);
+                h->pin_out = nullptr;
+                h->pin_cap = 0;
+                HIP_TRY(h, hipHostMalloc((void**)&h->pin_out, total + sizeof counters, hipHostMallocDefault));
+                h->pin_cap = total + sizeof counters;
+            }
+            char* d = h->d_out.p;
+            HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
+            HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
+                                       (uint64_t*)(d + off_rep), h->d_counters.p + 2, spec_groups, h->d_errp, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->pin_out, d, total, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->pin_out + total, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            memcpy(counters, h->pin_out + total, sizeof counters);
+        } else {
+            HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
         err_flags = (uint32_t)counters[12];
         drain_events(h);
     } else if (h->stats.rows_in == 0) {
@@ -1290,20 +1325,23 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
         }
     }
     if (ng > 0) {
-        const size_t rec_keys = (size_t)nk * sizeof(OutValue), rec_aggs = (size_t)na * sizeof(OutValue),
-                     rec_parts = (size_t)na * sizeof(OutPartial);
-        const size_t off_aggs = ng * rec_keys, off_parts = off_aggs + ng * rec_aggs, off_rep = off_parts + ng * rec_parts;
-        const size_t total = off_rep + ng * 8;
-        HIP_TRY(h, h->d_out.ensure(total + 16));
-        char* d = h->d_out.p;
-        HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
-        HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
-                                   (uint64_t*)(d + off_rep), h->d_counters.p + 2, ng, h->d_errp, h->stream));
-        h->out_host.resize(total);
-        HIP_TRY(h, hipMemcpyAsync(h->out_host.data(), d, total, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        const char* hp = h->out_host.data();
+        const bool spec_hit = spec_groups && ng <= spec_groups;
+        const uint64_t lay = spec_hit ? spec_groups : ng;  // the arrays are laid out for `lay` groups
+        const size_t off_aggs = lay * rec_keys, off_parts = off_aggs + lay * rec_aggs, off_rep = off_parts + lay * rec_parts;
+        const size_t total = off_rep + lay * 8;
+        const char* hp = h->pin_out;
+        if (!spec_hit) {
+            HIP_TRY(h, h->d_out.ensure(total + 16));
+            char* d = h->d_out.p;
+            HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
+            HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
+                                       (uint64_t*)(d + off_rep), h->d_counters.p + 2, ng, h->d_errp, h->stream));
+            h->out_host.resize(total);
+            HIP_TRY(h, hipMemcpyAsync(h->out_host.data(), d, total, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            hp = h->out_host.data();
+        }
         h->r_keys.assign((const n1k_value*)hp, (const n1k_value*)hp + ng * nk);
         h->r_aggs.assign((const n1k_value*)(hp + off_aggs), (const n1k_value*)(hp + off_aggs) + ng * na);
         h->r_rep.assign((const uint64_t*)(hp + off_rep), (const uint64_t*)(hp + off_rep) + ng);
@@ -1325,6 +1363,10 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     if (err_flags & ERR_TABLE_FULL)
         return fail(h, N1K_OOM, "group table capacity exceeded: raise the max_groups option (now %llu)",
                     (unsigned long long)h->opt_max_groups);
+    if (err_flags & ERR_EXCHANGE_WIDE)
+        return fail(h, N1K_UNSUPPORTED, "a sender's group keys hold float / wide integer values: use the row exchange");
+    if (err_flags & ERR_EXCHANGE_OVERFLOW)
+        return fail(h, N1K_OOM, "a sender's partial-group region overflowed: raise the region capacity");
     if (err_flags & ERR_UNPACKABLE_KEY)
         return fail(h, N1K_UNSUPPORTED_DATA,
                     "a group key value does not fit the packed key: more than %llu distinct float / wide integer key "
@@ -1379,6 +1421,16 @@ n1k_status n1k_jit_check(n1k_handle* h, const uint32_t* col_kinds, uint32_t ncol
 
 n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
     if (!h || !out) return N1K_INVALID;
+    // account pushes whose events have completed meanwhile (no waiting: hipEventQuery)
+    n1k_handle* m = const_cast<n1k_handle*>(h);
+    while (!m->events.empty() && m->events.front().second && hipEventQuery(m->events.front().second) == hipSuccess) {
+        auto pr = m->events.front();
+        float ms = 0.f;
+        if (pr.first && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) m->stats.device_ms += ms;
+        if (pr.first) m->event_pool.push_back(pr.first);
+        m->event_pool.push_back(pr.second);
+        m->events.erase(m->events.begin());
+    }
     *out = h->stats;
     return N1K_OK;
 }
@@ -1443,7 +1495,7 @@ uint64_t n1k_partial_region_bytes(const n1k_handle* h, uint64_t capacity_groups)
     return 8ull * (2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words));
 }
 
-n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
+n1k_status n1k_export_partials_async(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
     if (!h || !out || nparts == 0 || capacity_groups == 0) return N1K_INVALID;
     if (!h->plan.has_group) return fail(h, N1K_INVALID, "no groups in a Filter-only plan");
     if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
@@ -1454,6 +1506,12 @@ n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t c
     if (h->table.capacity)
         HIP_TRY(h, launch_export_partials(h->prog, h->table, nparts, capacity_groups, (uint64_t*)out, region_words,
                                           h->d_errp, h->stream));
+    return N1K_OK;
+}
+
+n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
+    n1k_status st = n1k_export_partials_async(h, nparts, capacity_groups, out);
+    if (st != N1K_OK) return st;
     uint32_t err_flags = 0;
     unsigned long long sel = 0, wide = 0;
     HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));

@@ -1073,6 +1073,10 @@ __global__ __launch_bounds__(1024) void merge_slabs_kernel(const Program P, cons
 __global__ void export_partials_kernel(const Program P, const GlobalTable G, uint32_t nparts, uint64_t cap,
                                        uint64_t* out, uint64_t region_words, uint32_t* err_flags) {
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // header word 1 of EVERY region carries this sender's verdict to all receivers (so that the ranks agree on a
+    // retry without a second collective): bit 0 = some region overflowed, bit 1 = keys hold device-local wide codes
+    if (s == 0 && P.wide_count && *P.wide_count)
+        for (uint32_t r = 0; r < nparts; r++) atomicOr((unsigned long long*)&out[(size_t)r * region_words + 1], 2ull);
     if (s >= G.capacity) return;
     uint64_t key = G.keys[s];
     if (key == kEmptyKey) return;
@@ -1080,7 +1084,8 @@ __global__ void export_partials_kernel(const Program P, const GlobalTable G, uin
     uint64_t* region = out + (size_t)d * region_words;
     unsigned long long pos = atomicAdd((unsigned long long*)&region[0], 1ull);
     if (pos >= cap) {
-        atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+        if (!(atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL) & ERR_TABLE_FULL))
+            for (uint32_t r = 0; r < nparts; r++) atomicOr((unsigned long long*)&out[(size_t)r * region_words + 1], 1ull);
         return;
     }
     region[2 + pos] = key;
@@ -1096,6 +1101,14 @@ __global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint
     uint32_t r = (uint32_t)(i / cap);
     uint64_t pos = i % cap;
     if (r >= nregions) return;
+    // a sender that could not export (see export_partials_kernel) voids the whole exchange: nothing is merged and
+    // n1k_finish reports it, on every rank alike
+    uint64_t verdict = 0;
+    for (uint32_t q = 0; q < nregions; q++) verdict |= in[(size_t)q * region_words + 1];
+    if (verdict) {
+        if (i == 0) atomicOr(err_flags, (uint32_t)(((verdict & 1ull) ? ERR_EXCHANGE_OVERFLOW : 0u) | ((verdict & 2ull) ? ERR_EXCHANGE_WIDE : 0u)));
+        return;
+    }
     const uint64_t* region = in + (size_t)r * region_words;
     uint64_t count = region[0] < cap ? region[0] : cap;
     if (pos >= count) return;

@@ -136,7 +136,9 @@ enum : uint64_t { MM_FALSE = 1, MM_TRUE = 2, MM_INT = 4, MM_FLOAT = 8, MM_STRING
 enum : uint32_t {
     ERR_UNPACKABLE_KEY = 1,   // a group key value does not fit its bit field (wide ints, non-integral floats)
     ERR_TABLE_FULL = 2,       // global group table capacity exceeded
-    ERR_UNSUPPORTED_VALUE = 4 // e.g. ordering two arrays/objects
+    ERR_UNSUPPORTED_VALUE = 4, // e.g. ordering two arrays/objects
+    ERR_EXCHANGE_OVERFLOW = 16, // a sender's partial-group region overflowed (seen by the merge on every rank)
+    ERR_EXCHANGE_WIDE = 32      // a sender's keys hold wide-value codes: partial groups cannot travel
 };
 
 struct Program {

@@ -118,8 +118,14 @@ class ShardedFilterGroup:
         from query_amd import plan
         self.rank, self.world, self.device = rank, world, device
         # sender: Filter + key evaluation; receiver: the same grouping without the Filter (it was applied already)
-        self.sender = query_amd.GpuFilterGroup(plan.filter_group_plan(condition, keys, aggs), device=device)
-        self.receiver = query_amd.GpuFilterGroup(plan.filter_group_plan(None, keys, aggs), device=device, **options)
+        import torch
+        # one stream for both handles and for torch (RCCL work is ordered against it by c10d's events)
+        self.stream = torch.cuda.Stream(device=torch.device("cuda", device))
+        self.sender = query_amd.GpuFilterGroup(plan.filter_group_plan(condition, keys, aggs), device=device,
+                                               stream=self.stream.cuda_stream)
+        self.receiver = query_amd.GpuFilterGroup(plan.filter_group_plan(None, keys, aggs), device=device,
+                                                 stream=self.stream.cuda_stream, **options)
+        self._recv_ready = False
         self.sender.intern(list(dictionary))
         self.receiver.intern(list(dictionary))
         self.send_paths = self.sender.column_paths
@@ -130,51 +136,58 @@ class ShardedFilterGroup:
         self._pbuf = None
 
     # ------------------------------------------------------------------ exchange of partial groups
-    def run_partials(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
+    def run_partials(self, nrows: int, cols_by_path: Dict[str, tuple], want_rows_selected: bool = True) -> Tuple[dict, dict]:
         """Few groups next to rows: aggregate the local shard first (same kernels as on one GPU), then move only
         the partial groups: ONE all_to_all_single of fixed-size regions, hash-partitioned on the group key, merged
-        by the owner (≙ IntermediateGroup) and finalised there."""
+        by the owner (≙ IntermediateGroup) and finalised there.
+
+        The whole step is stream-ordered — scan, export, all-to-all, merge, finalize — with a single host
+        synchronisation at the end (n1k_finish's copy of the groups).  A sender that cannot export (a region
+        overflowed; keys coded by device-local value tables) says so in every region header, the merge on each
+        receiver then does nothing and n1k_finish reports it: all ranks take the same retry branch without an
+        extra collective."""
         import torch
         import torch.distributed as dist
         from query_amd import _ffi
-        op = self.sender  # Filter + InitialGroup over the local shard
-        lib = op._lib
-        op.reopen()
-        op.process_device_items(nrows, [cols_by_path[p] for p in self.send_paths])
+        from query_amd.gpu_operator import N1kError
+        snd, rcv = self.sender, self.receiver  # Filter + InitialGroup over the shard; owner-side merge + FinalGroup
+        lib = snd._lib
         dev = torch.device("cuda", self.device)
-        while True:
-            cap = self.partial_capacity
-            region = int(lib.n1k_partial_region_bytes(op._h, cap))
-            if self._pbuf is None or self._pbuf[0].numel() != region * self.world:
-                self._pbuf = (torch.empty(region * self.world, dtype=torch.uint8, device=dev),
-                              torch.empty(region * self.world, dtype=torch.uint8, device=dev))
-            send, recv = self._pbuf
-            st = lib.n1k_export_partials_device(op._h, self.world, cap, send.data_ptr())  # synchronises the handle's stream
-            if st == _ffi.OOM:
-                # a destination got more groups than a region holds: tell every receiver through the region headers
-                # (word 1), so that all ranks agree to retry with larger regions without an extra collective
-                send.view(torch.int64)[1::region // 8] = 1
-            elif st == _ffi.UNSUPPORTED:
-                # this shard's keys hold float / wide-integer values, coded by device-local value tables: the
-                # groups cannot travel in packed form.  Same header channel: every rank switches to the row exchange.
-                send.view(torch.int64)[1::region // 8] = 2
-            else:
-                op._check(st)
-            dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
-            overflow = int(recv.view(torch.int64)[1::region // 8].max().item())  # also orders the collective before the merge
-            if not overflow:
+        with torch.cuda.stream(self.stream):
+            if not self._recv_ready:  # the owner handle needs the key layout (column kinds) before it can merge
+                rcv.process_device_items(0, [cols_by_path[p] for p in self.recv_paths])
+                self._recv_ready = True
+            while True:
+                cap = self.partial_capacity
+                region = int(lib.n1k_partial_region_bytes(snd._h, cap))
+                if self._pbuf is None or self._pbuf[0].numel() != region * self.world:
+                    self._pbuf = (torch.empty(region * self.world, dtype=torch.uint8, device=dev),
+                                  torch.empty(region * self.world, dtype=torch.uint8, device=dev))
+                send, recv = self._pbuf
+                snd.reopen()
+                snd.process_device_items(nrows, [cols_by_path[p] for p in self.send_paths])
+                snd._check(lib.n1k_export_partials_async(snd._h, self.world, cap, send.data_ptr()))
+                dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
+                rcv.reopen()
+                rcv._check(lib.n1k_merge_partials_device(rcv._h, self.world, cap, recv.data_ptr()))
+                try:
+                    raw = rcv.after_items_raw()  # the step's one host synchronisation
+                except N1kError as e:
+                    if e.status == _ffi.OOM and "region" in e.message:
+                        self.partial_capacity *= 4
+                        continue
+                    if e.status == _ffi.UNSUPPORTED:
+                        snd.reopen()  # drop the abandoned export's groups and flags
+                        raw, info = self.run(nrows, cols_by_path)
+                        info["mode"] = "rows (wide key values)"
+                        return raw, info
+                    raise
                 break
-            if overflow == 2:
-                raw, info = self.run(nrows, cols_by_path)
-                info["mode"] = "rows (wide key values)"
-                return raw, info
-            self.partial_capacity *= 4
-        op.sync()  # drains the HIP events: stats now hold this step's scan time
-        stats = op.stats()
-        op.reopen()  # the owner starts from an empty table (plan, dictionary, key layout stay)
-        op._check(lib.n1k_merge_partials_device(op._h, self.world, cap, recv.data_ptr()))
-        raw = op.after_items_raw()
-        return raw, {"mode": "partials", "region_bytes": region, "rows_selected": int(stats["rows_selected"]),
+            if want_rows_selected:
+                snd.sync()  # one more small copy: the Filter's survivor count lives in the sender's counters
+            stats = snd.stats()  # scan time from the completed HIP events (no waiting)
+        return raw, {"mode": "partials", "region_bytes": region,
+                     "rows_selected": int(stats["rows_selected"]) if want_rows_selected else None,
                      "scan_ms": float(stats["device_ms"]), "spec_kernel": int(stats["spec_kernel"])}
 
     def _alloc(self, capacity: int, kinds: Sequence[int]):
@@ -194,6 +207,11 @@ class ShardedFilterGroup:
     def run(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
         """cols_by_path: path -> (kind, tags_ptr, payload_ptr, codes_ptr) device addresses of this rank's shard.
         Returns (local final groups as numpy record arrays, timing/volume info)."""
+        import torch
+        with torch.cuda.stream(self.stream):
+            return self._run_rows(nrows, cols_by_path)
+
+    def _run_rows(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
         import torch
         import torch.distributed as dist
         from query_amd import _ffi
@@ -265,10 +283,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     dev = torch.device("cuda", local_rank)
     gather = None
 
-    def step():
+    def step(last=False):
         nonlocal gather
         raw, info = (op.run(args.rows, cols.by_path) if op.has_distinct or args.exchange == "rows"
-                     else op.run_partials(args.rows, cols.by_path))
+                     else op.run_partials(args.rows, cols.by_path, want_rows_selected=last))
         rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
                               raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1) \
             if raw["ngroups"] else np.zeros((0, 16 * (raw["nkeys"] + raw["naggs"])), np.uint8)
@@ -282,8 +300,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        allg, info = step()
+    for i in range(args.steps):
+        allg, info = step(last=(i == args.steps - 1))
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)

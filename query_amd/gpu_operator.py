@@ -188,8 +188,8 @@ class GpuFilterGroup:
         def arr(ptr, count, dt):
             if not count or not ptr:
                 return np.zeros(0, dtype=dt)
-            raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * dt.itemsize,))
-            return raw.view(dt).copy()
+            # one memcpy out of the handle-owned result (valid until the next finish/reset/destroy)
+            return np.frombuffer(bytearray(C.string_at(ptr, count * dt.itemsize)), dtype=dt)
 
         out = {"ngroups": ng, "nkeys": nk, "naggs": na,
                "keys": arr(res.keys, ng * nk, self._VALUE_DT).reshape(ng, nk) if nk else np.zeros((ng, 0), self._VALUE_DT),
