@@ -139,8 +139,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "rows"],
-                    help="multi-GPU: what crosses xGMI (auto = partial groups unless the plan has DISTINCT)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "partials", "rows"],
+                    help="multi-GPU: what crosses xGMI.  auto = per-GPU partial groups, all-gathered while they are few "
+                         "and hash-partitioned (all-to-all) beyond that, rows when the plan has DISTINCT; "
+                         "partials = always the hash-partitioned partial groups; rows = always the filtered rows")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank")
     args = ap.parse_args()
 

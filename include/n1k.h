@@ -273,7 +273,7 @@ n1k_status n1k_jit_check(n1k_handle *h, const uint32_t *col_kinds, uint32_t ncol
  * Hash-partition step of the 8-GPU path (no reference analogue: replaces the
  * Parallel -> IntermediateGroup fan-in, execution/exchange.go:161-251).
  * Evaluates the Filter on a device-resident batch and scatters every surviving
- * row's referenced columns into `nparts` regions by hash(group key) % nparts.
+ * row's referenced columns into `nparts` (<= 64) regions by a hash of the group key VALUES.
  * Each column keeps its own layout, so the receiving rank can hand the received
  * buffers straight to n1k_push_device_batch of a handle built from the same plan
  * without its Filter.
@@ -289,8 +289,7 @@ n1k_status n1k_partition_device_batch(n1k_handle *h, const n1k_batch *batch, uin
  * Partial groups (the reference's Initial -> Intermediate hand-over, algebra/aggregate.go:25-40).
  *
  * n1k_export_partials_device: write every group of the handle (packed key + raw accumulators) into `nparts`
- * regions of `out` (device memory) by hash(group key) % nparts — the same hash as
- * n1k_partition_device_batch.  Region d (region_bytes = n1k_partial_region_bytes(h, capacity_groups)) is
+ * regions of `out` (device memory) by a hash of the packed group key.  Region d (region_bytes = n1k_partial_region_bytes(h, capacity_groups)) is
  *     [count u64][verdict u64][keys: capacity x u64][accumulators: capacity x n1k_partial_words(h) x u64]
  * so that ONE all-to-all with equal splits moves all regions.  N1K_OOM when a region overflows; N1K_UNSUPPORTED
  * when the keys hold float / wide-integer values (their codes are local to the handle).

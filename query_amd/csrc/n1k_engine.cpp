@@ -1438,6 +1438,7 @@ n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
 n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uint32_t nparts, uint64_t capacity_rows,
                                       const n1k_col* out_cols, uint64_t* out_counts) {
     if (!h || !batch || !out_cols || !out_counts || nparts == 0) return N1K_INVALID;
+    if (nparts > kMaxParts) return fail(h, N1K_INVALID, "at most %u destinations per partition call", kMaxParts);
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
     if (!h->plan.has_group) return fail(h, N1K_INVALID, "partitioning needs group keys");
     if (sizeof(Program) + sizeof(PartArgs) + 64 > 4096) return fail(h, N1K_UNSUPPORTED, "kernel arguments exceed 4 KiB");
@@ -1469,8 +1470,8 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
     A.err_flags = h->d_errp;
     HIP_TRY(h, hipMemsetAsync(out_counts, 0, nparts * sizeof(uint64_t), h->stream));
     if (batch->nrows) {
-        uint64_t ntiles = (batch->nrows + 1023) / 1024;
-        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8, ntiles));
+        uint64_t ntiles = (batch->nrows + 2047) / 2048;  // partition_kernel<4, 512>
+        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 4, ntiles));
         hipEvent_t e0 = get_event(h), e1 = get_event(h);
         if (e0) (void)hipEventRecord(e0, h->stream);
         HIP_TRY(h, launch_partition(P, A, grid, h->stream));

@@ -844,11 +844,15 @@ __global__ void init_table_kernel(const Program P, const GlobalTable G, uint64_t
 // No reference analogue (the reference fans in through one in-memory queue, execution/exchange.go:161-251): every
 // surviving row goes to the GPU that owns hash(group key) % nparts, so that each group lives on exactly one GPU
 // and COUNT(DISTINCT) needs no cross-GPU merge.  Region d of every output column receives the rows for rank d;
-// positions come from one wave-aggregated atomic per (wave, destination).
+// positions come from a workgroup-level reservation (LDS counters, one global atomic per tile and destination).
 template <int R, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const PartArgs A) {
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     uint32_t unsupported = 0, unpackable = 0;
+    __shared__ uint32_t s_cnt[kMaxParts];
+    __shared__ unsigned long long s_base[kMaxParts];
+    for (uint32_t d = tid; d < kMaxParts; d += BLOCK) s_cnt[d] = 0;
+    __syncthreads();
     const uint64_t tile_rows = (uint64_t)BLOCK * R;
     const uint64_t ntiles = (A.nrows + tile_rows - 1) / tile_rows;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -879,28 +883,45 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
                 key[j] = mix64(key[j] ^ canon) + k;
             }
         }
+        // Reservation in two levels: every wave adds its per-destination survivor counts to the workgroup's LDS
+        // counters (one ds_add per wave and destination, rank inside the wave from the ballot), then ONE global
+        // atomic per destination and tile reserves the block's run in that destination's region.  (One global atomic
+        // per wave serialises on nparts addresses: 1.5 M same-address atomics per 100 M rows, ~19 ms measured.)
         uint64_t pos[R];
+        uint32_t dest[R];
 #pragma unroll
         for (int j = 0; j < R; j++) {
-            uint32_t dest = (uint32_t)(((key[j] >> 32) * (uint64_t)A.nparts) >> 32);
+            dest[j] = (uint32_t)(((key[j] >> 32) * (uint64_t)A.nparts) >> 32);
             pos[j] = 0;
             for (uint32_t d = 0; d < A.nparts; d++) {
-                unsigned long long m = __ballot(pass[j] && dest == d);
+                unsigned long long m = __ballot(pass[j] && dest[j] == d);
                 if (m == 0ull) continue;
                 int leader = __ffsll((long long)m) - 1;
-                unsigned long long base = 0;
-                if ((int)lane == leader) base = atomicAdd(&A.counts[d], (unsigned long long)__popcll(m));
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
                 base = __shfl(base, leader, 64);
-                if (pass[j] && dest == d) {
-                    uint64_t r = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (r >= A.capacity) {
-                        atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
-                        pass[j] = false;
-                    }
-                    pos[j] = (uint64_t)d * A.capacity + r;
-                }
+                if (pass[j] && dest[j] == d) pos[j] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             }
         }
+        __syncthreads();
+        for (uint32_t d = tid; d < A.nparts; d += BLOCK) {
+            uint32_t n = s_cnt[d];
+            s_base[d] = n ? atomicAdd(&A.counts[d], (unsigned long long)n) : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (!pass[j]) continue;
+            uint64_t r = s_base[dest[j]] + pos[j];
+            if (r >= A.capacity) {
+                atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                pass[j] = false;
+            }
+            pos[j] = (uint64_t)dest[j] * A.capacity + r;
+        }
+        __syncthreads();
+        for (uint32_t d = tid; d < A.nparts; d += BLOCK) s_cnt[d] = 0;
+        // (the next tile's first barrier orders this reset before its counters are read)
         for (uint32_t c = 0; c < A.ncopy; c++) {
             Operand o{};
             o.is_const = 0;
@@ -1577,7 +1598,7 @@ hipError_t launch_arith(const ArithArgs& A, hipStream_t st) {
 }
 
 hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, hipStream_t st) {
-    hipLaunchKernelGGL((partition_kernel<4, 256>), dim3(grid), dim3(256), 0, st, P, A);
+    hipLaunchKernelGGL((partition_kernel<4, 512>), dim3(grid), dim3(512), 0, st, P, A);
     return hipGetLastError();
 }
 

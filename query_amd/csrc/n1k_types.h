@@ -247,6 +247,7 @@ struct ArithArgs {
     uint64_t* out_payload;
 };
 
+constexpr uint32_t kMaxParts = 64;  // destinations of one partition launch (ranks of a node, with room)
 struct PartArgs {
     uint64_t nrows;
     uint64_t capacity;  // rows per destination region

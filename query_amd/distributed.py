@@ -136,7 +136,18 @@ class ShardedFilterGroup:
         self._pbuf = None
 
     # ------------------------------------------------------------------ exchange of partial groups
-    def run_partials(self, nrows: int, cols_by_path: Dict[str, tuple], want_rows_selected: bool = True) -> Tuple[dict, dict]:
+    # partial groups of ALL ranks fit this many bytes per rank -> gather them instead of partitioning them
+    GATHER_LIMIT = 32 << 20
+
+    def run_gathered(self, nrows: int, cols_by_path: Dict[str, tuple], want_rows_selected: bool = True) -> Tuple[dict, dict]:
+        """Few groups: every rank aggregates its shard, ONE all_gather moves the per-GPU partial groups and every
+        rank merges all of them (≙ IntermediateGroup + FinalGroup, replicated): each rank ends with the complete
+        result, so no second collective is needed.  Falls over to the hash-partitioned exchange (run_partials) when
+        world x region outgrows GATHER_LIMIT."""
+        return self.run_partials(nrows, cols_by_path, want_rows_selected, replicate=True)
+
+    def run_partials(self, nrows: int, cols_by_path: Dict[str, tuple], want_rows_selected: bool = True,
+                     replicate: bool = False) -> Tuple[dict, dict]:
         """Few groups next to rows: aggregate the local shard first (same kernels as on one GPU), then move only
         the partial groups: ONE all_to_all_single of fixed-size regions, hash-partitioned on the group key, merged
         by the owner (≙ IntermediateGroup) and finalised there.
@@ -160,14 +171,20 @@ class ShardedFilterGroup:
             while True:
                 cap = self.partial_capacity
                 region = int(lib.n1k_partial_region_bytes(snd._h, cap))
-                if self._pbuf is None or self._pbuf[0].numel() != region * self.world:
-                    self._pbuf = (torch.empty(region * self.world, dtype=torch.uint8, device=dev),
+                # the same on every rank: capacities only change on verdicts that all ranks see
+                gathered = replicate and region * self.world <= self.GATHER_LIMIT
+                nsend = 1 if gathered else self.world
+                if self._pbuf is None or self._pbuf[0].numel() != region * nsend or self._pbuf[1].numel() != region * self.world:
+                    self._pbuf = (torch.empty(region * nsend, dtype=torch.uint8, device=dev),
                                   torch.empty(region * self.world, dtype=torch.uint8, device=dev))
                 send, recv = self._pbuf
                 snd.reopen()
                 snd.process_device_items(nrows, [cols_by_path[p] for p in self.send_paths])
-                snd._check(lib.n1k_export_partials_async(snd._h, self.world, cap, send.data_ptr()))
-                dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
+                snd._check(lib.n1k_export_partials_async(snd._h, nsend, cap, send.data_ptr()))
+                if gathered:
+                    dist.all_gather_into_tensor(recv, send)  # region r = rank r's partial groups, on every rank
+                else:
+                    dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
                 rcv.reopen()
                 rcv._check(lib.n1k_merge_partials_device(rcv._h, self.world, cap, recv.data_ptr()))
                 try:
@@ -186,7 +203,7 @@ class ShardedFilterGroup:
             if want_rows_selected:
                 snd.sync()  # one more small copy: the Filter's survivor count lives in the sender's counters
             stats = snd.stats()  # scan time from the completed HIP events (no waiting)
-        return raw, {"mode": "partials", "region_bytes": region,
+        return raw, {"mode": "gathered partials" if gathered else "partials", "region_bytes": region,
                      "rows_selected": int(stats["rows_selected"]) if want_rows_selected else None,
                      "scan_ms": float(stats["device_ms"]), "spec_kernel": int(stats["spec_kernel"])}
 
@@ -285,11 +302,17 @@ def bench_main(args, rank: int, world: int, local_rank: int):
 
     def step(last=False):
         nonlocal gather
-        raw, info = (op.run(args.rows, cols.by_path) if op.has_distinct or args.exchange == "rows"
-                     else op.run_partials(args.rows, cols.by_path, want_rows_selected=last))
+        if op.has_distinct or args.exchange == "rows":
+            raw, info = op.run(args.rows, cols.by_path)
+        elif args.exchange == "partials":
+            raw, info = op.run_partials(args.rows, cols.by_path, want_rows_selected=last)
+        else:
+            raw, info = op.run_gathered(args.rows, cols.by_path, want_rows_selected=last)
         rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
                               raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1) \
             if raw["ngroups"] else np.zeros((0, 16 * (raw["nkeys"] + raw["naggs"])), np.uint8)
+        if info.get("mode") == "gathered partials":
+            return rec, info  # every rank already merged every rank's partial groups: the result is complete
         if gather is None:
             gather = FixedGather(rec.shape[1], capacity=max(1024, 2 * rec.shape[0]))
         allg = gather(rec, dev)  # every rank holds the result; rank 0 reports it
@@ -308,6 +331,11 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     if rank == 0:
+        mode = info.get("mode", "rows")
+        how = ("per-GPU partial groups merged after ONE RCCL all-gather (every rank holds the result)" if mode == "gathered partials"
+               else "partial groups hash-partitioned on the group key by RCCL all-to-all, final groups gathered on rank 0"
+               if mode == "partials" else
+               "filtered rows hash-partitioned on the group key by RCCL all-to-all, final groups gathered on rank 0")
         out = {
             "metric": "rows/sec filter+group-by on 100M synthetic JSON docs; achieved HBM GB/s",
             "value": total_rows * args.steps / elapsed,
@@ -321,10 +349,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
             "vs_baseline": None,
             "dtype": "int64/f64 tagged scalars (u8 tag + 8 B payload), u32 dictionary codes",
             "data": "synthetic",
-            "config": {"workload": "%s: %s @ %d rows per GPU x %d GPUs, K_cat=%d, %s hash-partitioned on the group "
-                                   "key by RCCL all-to-all, final groups gathered on rank 0" %
-                                   (args.workload, wl["sql"], args.rows, world, args.kcat,
-                                    "partial groups" if info.get("mode") == "partials" else "filtered rows"),
+            "config": {"workload": "%s: %s @ %d rows per GPU x %d GPUs, K_cat=%d, %s" %
+                                   (args.workload, wl["sql"], args.rows, world, args.kcat, how),
                        "rows_per_gpu": args.rows, "groups": int(allg.shape[0]) if allg is not None else None,
                        "exchange_rank0": info},
         }

@@ -132,7 +132,8 @@ def test_partial_groups_export_merge_roundtrip():
     pu.assert_same_groups(merged, ora, aggs=aggs)
 
 
-def test_rank_pipeline_partials_world1_rccl():
+@pytest.mark.parametrize("mode", ["partials", "gathered"])
+def test_rank_pipeline_partials_world1_rccl(mode):
     import torch
     import torch.distributed as dist
     from query_amd import distributed as qd
@@ -148,12 +149,13 @@ def test_rank_pipeline_partials_world1_rccl():
         t = n1o.synth_table(n, k_cat=5000)  # more groups than the initial region capacity: exercises the retry
         op = qd.ShardedFilterGroup(COND, KEYS, AGGS, t.dictionary, 0, 1, 0)
         dev, keep = _device_cols(t, op.send_paths)
-        raw, info = op.run_partials(n, dev)
+        raw, info = op.run_partials(n, dev) if mode == "partials" else op.run_gathered(n, dev)
+        assert info["mode"] == ("partials" if mode == "partials" else "gathered partials")
         ora = n1o.run(t, COND, KEYS, AGGS)
         assert info["rows_selected"] == ora.rows_passed and raw["ngroups"] == len(ora.keys)
         cache = {}
         from query_amd.gpu_operator import GroupRows
-        got = GroupRows(1, len(AGGS), op.sender._py_values(raw["keys"], cache), op.sender._py_values(raw["aggs"], cache), [])
+        got = GroupRows(1, len(AGGS), op.receiver._py_values(raw["keys"], cache), op.receiver._py_values(raw["aggs"], cache), [])
         pu.assert_same_groups(got, ora, aggs=AGGS)
     finally:
         dist.destroy_process_group()
