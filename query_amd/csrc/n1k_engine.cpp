@@ -115,6 +115,15 @@ struct n1k_handle {
     std::vector<DevBuf<uint64_t>> dv_payload;
     DevBuf<uint64_t> d_log_key[kMaxDistinct], d_log_val[kMaxDistinct], d_regions, d_set_table;
     DevBuf<uint8_t> d_log_cls[kMaxDistinct];
+    // COUNT(DISTINCT) member words (ScanArgs::log_word) and the scratch of their partition / de-duplication at finish
+    DevBuf<uint64_t> d_log_word[kMaxDistinct], d_part[2], d_seg[3], d_wtable;
+    DevBuf<unsigned long long> d_hist, d_cursor, d_dcounts;
+    uint32_t opt_distinct_words = 1;      // 0: every pair takes the (key, value, class) log and the global sets
+    uint32_t opt_distinct_set_slots = 8192;  // LDS set size of the de-duplication kernel (power of two)
+    int32_t opt_distinct_levels = -1;        // partition passes before the LDS sets: -1 = by log size, 0..2 forced (tests)
+    uint32_t nw_key_bits = 0, nw_val_bits = 0;
+    bool distinct_words[kMaxDistinct] = {false, false, false, false};
+    uint32_t distinct_path = 0;  // how the last finish built the sets: bit 0 global pair sets, bit 1 LDS word sets, bit 2 global word set
     uint64_t log_capacity = 0;
 
     // device state
@@ -414,9 +423,9 @@ n1k_status ensure_device(n1k_handle* h) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
     }
-    HIP_TRY(h, h->d_counters.ensure(16));
+    HIP_TRY(h, h->d_counters.ensure(kCounters));
     h->d_errp = (uint32_t*)(h->d_counters.p + 12);
-    HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
     h->device_ready = true;
     return N1K_OK;
 }
@@ -483,6 +492,17 @@ n1k_status fix_layout(n1k_handle* h, const n1k_batch* b) {
         P.wide_int = h->d_wide_int.p;
         P.wide_flt = h->d_wide_flt.p;
         P.wide_bits = wb;
+    }
+    // COUNT(DISTINCT) member words: [packed key : K1][class : 3][value : 61 - K1].  A layout of few bits keeps all
+    // of them; wider layouts (integer keys, several keys) only qualify row by row when the packed key is small.
+    {
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < P.nkeys; k++) total += P.keys[k].bits;
+        h->nw_key_bits = P.nkeys == 0 ? 1u : (total <= 34 ? total : 24u);
+        h->nw_val_bits = 61 - h->nw_key_bits;
+        for (uint32_t a = 0; a < P.naggs; a++)
+            if (P.aggs[a].distinct)
+                h->distinct_words[P.aggs[a].log_index] = h->opt_distinct_words && P.aggs[a].kind == AGG_COUNT;
     }
     h->layout_fixed = true;
     return N1K_OK;
@@ -701,22 +721,27 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             uint64_t cap = std::max<uint64_t>(need, h->log_capacity * 2);
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             for (uint32_t d = 0; d < h->n_distinct; d++) {
-                DevBuf<uint64_t> nk, nv;
+                DevBuf<uint64_t> nk, nv, nw;
                 DevBuf<uint8_t> nc;
                 HIP_TRY(h, nk.ensure(cap));
                 HIP_TRY(h, nv.ensure(cap));
                 HIP_TRY(h, nc.ensure(cap));
+                if (h->distinct_words[d]) HIP_TRY(h, nw.ensure(cap));
                 if (h->log_capacity) {
                     HIP_TRY(h, hipMemcpy(nk.p, h->d_log_key[d].p, h->log_capacity * 8, hipMemcpyDeviceToDevice));
                     HIP_TRY(h, hipMemcpy(nv.p, h->d_log_val[d].p, h->log_capacity * 8, hipMemcpyDeviceToDevice));
                     HIP_TRY(h, hipMemcpy(nc.p, h->d_log_cls[d].p, h->log_capacity, hipMemcpyDeviceToDevice));
+                    if (h->distinct_words[d])
+                        HIP_TRY(h, hipMemcpy(nw.p, h->d_log_word[d].p, h->log_capacity * 8, hipMemcpyDeviceToDevice));
                 }
                 h->d_log_key[d].release();
                 h->d_log_val[d].release();
                 h->d_log_cls[d].release();
+                h->d_log_word[d].release();
                 h->d_log_key[d] = nk;
                 h->d_log_val[d] = nv;
                 h->d_log_cls[d] = nc;
+                h->d_log_word[d] = nw;
             }
             h->log_capacity = cap;
         }
@@ -724,9 +749,17 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             A.log_key[d] = h->d_log_key[d].p;
             A.log_val[d] = h->d_log_val[d].p;
             A.log_cls[d] = h->d_log_cls[d].p;
+            A.log_word[d] = h->distinct_words[d] ? h->d_log_word[d].p : nullptr;
         }
         A.log_cursor = h->d_counters.p + 8;
+        A.word_cursor = h->d_counters.p + 16;
         A.log_capacity = h->log_capacity;
+        A.nw_key_bits = h->nw_key_bits;
+        A.nw_val_bits = h->nw_val_bits;
+        bool any_words = false;
+        for (uint32_t d = 0; d < h->n_distinct; d++) any_words |= h->distinct_words[d];
+        A.dcache_aggs = any_words ? h->n_distinct : 0;
+        A.dcache_slots = any_words ? 4096u / (h->n_distinct > 2 ? 4u : h->n_distinct) : 0;  // 32 KB of LDS in all
     }
     uint32_t block = h->opt_block ? h->opt_block : 1024;
     uint32_t rpl = block == 1024 ? h->opt_rows_per_lane : 4;
@@ -965,7 +998,6 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
         st = fix_layout(h, b);
         if (st != N1K_OK) return st;
     }
-    Program& P = h->prog;
     st = bind_columns(h, b);
     if (st != N1K_OK) return st;
     st = ensure_rank(h);
@@ -1051,6 +1083,14 @@ void n1k_destroy(n1k_handle* h) {
             h->d_log_cls[d].release();
         }
         h->d_counters.release();
+        for (uint32_t d = 0; d < kMaxDistinct; d++) h->d_log_word[d].release();
+        h->d_part[0].release();
+        h->d_part[1].release();
+        for (auto& b : h->d_seg) b.release();
+        h->d_wtable.release();
+        h->d_hist.release();
+        h->d_cursor.release();
+        h->d_dcounts.release();
         h->d_wide_int.release();
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -1087,7 +1127,7 @@ n1k_status n1k_reset(n1k_handle* h) {
         h->stats.device_ms = 0;
         // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
-        else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(unsigned long long), h->stream));
+        else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
         if (h->prog.wide_int) {
             const size_t n = (size_t)1 << h->prog.wide_bits;
             HIP_TRY(h, hipMemsetAsync(h->d_wide_int.p, 0xFF, n * 8, h->stream));
@@ -1143,7 +1183,16 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "wide") h->opt_wide = value ? 1 : 0;
     else if (n == "jit") h->opt_jit = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
     else if (n == "jit_min_rows") h->opt_jit_min_rows = (uint64_t)std::max<int64_t>(value, 0);
-    else if (n == "wide_values") {
+    else if (n == "distinct_words") {
+        if (h->layout_fixed) return fail(h, N1K_INVALID, "distinct_words must be set before the first batch");
+        h->opt_distinct_words = value ? 1 : 0;
+    } else if (n == "distinct_set_slots") {
+        uint32_t v = 64;
+        while (v < (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 8192)) v <<= 1;
+        h->opt_distinct_set_slots = v;
+    } else if (n == "distinct_levels") {
+        h->opt_distinct_levels = (int32_t)std::min<int64_t>(std::max<int64_t>(value, -1), 2);
+    } else if (n == "wide_values") {
         if (h->layout_fixed) return fail(h, N1K_INVALID, "wide_values must be set before the first batch");
         h->opt_wide_values = (uint64_t)std::max<int64_t>(value, 0);
     }
@@ -1224,12 +1273,83 @@ n1k_status n1k_sync(n1k_handle* h) {
     if (!h) return N1K_INVALID;
     if (!h->device_ready) return N1K_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    unsigned long long counters[16] = {0};
+    unsigned long long counters[kCounters] = {0};
     HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     drain_events(h);
     if (h->plan.has_group) h->stats.rows_selected = counters[0];
     h->stats.wide_key_values = counters[13];
+    return N1K_OK;
+}
+
+// COUNT(DISTINCT) over the one-word members of one aggregate: radix partition of the word log until a bin's distinct
+// words fit an LDS set, per-bin LDS sets, member counts added to the groups' set sizes (see n1k_kernels.hip).
+static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64_t nwords) {
+    const uint32_t set_slots = h->opt_distinct_set_slots;
+    const uint64_t per_bin = std::max<uint64_t>(set_slots / 4, 16);  // expected distinct words per final bin: load <= 1/4
+    const uint32_t levels = h->opt_distinct_levels >= 0 ? (uint32_t)h->opt_distinct_levels
+                                                        : (nwords <= per_bin ? 0u : (nwords <= 256 * per_bin ? 1u : 2u));
+    const uint64_t* words = h->d_log_word[ag.log_index].p;
+    HIP_TRY(h, h->d_seg[0].ensure(2));
+    HIP_TRY(h, h->d_seg[1].ensure(257));
+    HIP_TRY(h, h->d_seg[2].ensure(65537));
+    HIP_TRY(h, h->d_hist.ensure(65536));
+    HIP_TRY(h, h->d_cursor.ensure(65536));
+    HIP_TRY(h, h->d_dcounts.ensure(h->table.capacity + 2));
+    const uint64_t seg0[2] = {0, nwords};
+    HIP_TRY(h, hipMemcpyAsync(h->d_seg[0].p, seg0, sizeof seg0, hipMemcpyHostToDevice, h->stream));
+    const uint64_t* bin_start = h->d_seg[0].p;
+    uint32_t nbins = 1;
+    for (uint32_t l = 0; l < levels; l++) {
+        HIP_TRY(h, h->d_part[l].ensure(nwords));
+        RadixArgs R{};
+        R.src = words;
+        R.dst = h->d_part[l].p;
+        R.seg_start = h->d_seg[l].p;
+        R.nseg = nbins;
+        R.shift = 56 - 8 * l;
+        R.hist = h->d_hist.p;
+        R.cursor = h->d_cursor.p;
+        R.out_start = h->d_seg[l + 1].p;
+        // slices per segment: enough workgroups to fill the GPU, never less than one tile each on average
+        uint64_t tiles = (nwords + 8191) / 8192;
+        uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / nbins + (nbins > 1 ? 8 : 0), tiles));
+        HIP_TRY(h, launch_radix_pass(R, slices, h->stream));
+        words = R.dst;
+        bin_start = R.out_start;
+        nbins *= 256;
+    }
+    uint32_t* d_overflow = (uint32_t*)(h->d_counters.p + 20);
+    HIP_TRY(h, hipMemsetAsync(h->d_dcounts.p, 0, (h->table.capacity + 2) * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(d_overflow, 0, 8, h->stream));
+    DedupeArgs D{};
+    D.words = words;
+    D.bin_start = bin_start;
+    D.nbins = nbins;
+    D.set_slots = set_slots;
+    D.key_shift = h->nw_val_bits + 3;
+    D.glob_off = ag.glob_off;
+    D.counts = h->d_dcounts.p;
+    D.overflow = d_overflow;
+    D.lds_counters = h->table.capacity <= 8192 ? (uint32_t)h->table.capacity : 0;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nbins, (uint64_t)h->num_cus * (set_slots <= 4096 && D.lds_counters <= 4096 ? 2 : 1));
+    HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, grid, h->stream));
+    uint32_t overflow = 0;
+    HIP_TRY(h, hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->distinct_path |= 2u;
+    if (overflow) {
+        // some bin holds more distinct words than an LDS set takes (more than ~65536 * set_slots / 2 distinct members
+        // in all): one open-addressed set in global memory over the whole word log instead
+        uint64_t cap = next_pow2(std::max<uint64_t>(nwords * 2, 1024));
+        HIP_TRY(h, h->d_wtable.ensure(cap));
+        HIP_TRY(h, hipMemsetAsync(h->d_wtable.p, 0xFF, cap * 8, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_dcounts.p, 0, (h->table.capacity + 2) * sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, launch_distinct_words_global(h->table, h->d_log_word[ag.log_index].p, nwords, h->d_wtable.p, cap - 1,
+                                                h->nw_val_bits + 3, h->d_dcounts.p, h->d_errp, h->num_cus * 8, h->stream));
+        h->distinct_path |= 4u;
+    }
+    HIP_TRY(h, launch_distinct_add_counts(h->prog, h->table, h->d_dcounts.p, ag.glob_off, h->stream));
     return N1K_OK;
 }
 
@@ -1242,7 +1362,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     out->nkeys = nk;
     out->naggs = na;
     uint32_t err_flags = 0;
-    unsigned long long counters[16] = {0};
+    unsigned long long counters[kCounters] = {0};
     const size_t rec_keys = (size_t)nk * sizeof(OutValue), rec_aggs = (size_t)na * sizeof(OutValue),
                  rec_parts = (size_t)na * sizeof(OutPartial);
     // Speculative FinalGroup: when the plan has no DISTINCT step the finalize kernel does not depend on anything the
@@ -1292,6 +1412,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     }
     h->stats.rows_selected = counters[0];
     h->stats.wide_key_values = counters[13];
+    h->stats.distinct_path = 0;
     uint64_t ng = counters[1];
     h->r_keys.clear();
     h->r_aggs.clear();
@@ -1299,10 +1420,12 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     h->r_rep.clear();
     if (ng > 0 && h->has_distinct) {
         // K6: de-duplicate the logged (group, value) pairs of every DISTINCT aggregate (≙ Set.Len(), value/set.go:198-215)
+        h->distinct_path = 0;
         for (uint32_t a = 0; a < na; a++) {
             const AggSpec& ag = h->prog.aggs[a];
             if (!ag.distinct) continue;
-            uint64_t npairs = counters[8 + ag.log_index];
+            const uint64_t npairs = std::min<uint64_t>(counters[8 + ag.log_index], h->log_capacity);
+            const uint64_t nwords = h->distinct_words[ag.log_index] ? std::min<uint64_t>(counters[16 + ag.log_index], h->log_capacity) : 0;
             DistinctArgs D{};
             D.log_key = h->d_log_key[ag.log_index].p;
             D.log_val = h->d_log_val[ag.log_index].p;
@@ -1314,15 +1437,24 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             HIP_TRY(h, h->d_regions.ensure(h->table.capacity * 6));
             D.regions = h->d_regions.p;
             HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 5, 0, sizeof(unsigned long long), h->stream));
-            HIP_TRY(h, launch_distinct_layout(h->prog, h->table, D, h->stream));
-            unsigned long long words = 0;
-            HIP_TRY(h, hipMemcpyAsync(&words, h->d_counters.p + 5, sizeof words, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            HIP_TRY(h, h->d_set_table.ensure(std::max<uint64_t>(words, 1)));
-            D.set_table = h->d_set_table.p;
-            if (words) HIP_TRY(h, hipMemsetAsync(h->d_set_table.p, 0xFF, words * 8, h->stream));
-            HIP_TRY(h, launch_distinct_insert(h->prog, h->table, D, h->d_errp, h->stream));
+            HIP_TRY(h, launch_distinct_layout(h->prog, h->table, D, h->stream));  // also zeroes the set sizes
+            if (npairs) {
+                // pairs of two words (floats, wide values, SUM/AVG DISTINCT): per-(group, class) sets in global memory
+                unsigned long long words = 0;
+                HIP_TRY(h, hipMemcpyAsync(&words, h->d_counters.p + 5, sizeof words, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                HIP_TRY(h, h->d_set_table.ensure(std::max<uint64_t>(words, 1)));
+                D.set_table = h->d_set_table.p;
+                if (words) HIP_TRY(h, hipMemsetAsync(h->d_set_table.p, 0xFF, words * 8, h->stream));
+                HIP_TRY(h, launch_distinct_insert(h->prog, h->table, D, h->d_errp, h->stream));
+                h->distinct_path |= 1u;
+            }
+            if (nwords) {
+                n1k_status st = distinct_words_finish(h, ag, nwords);
+                if (st != N1K_OK) return st;
+            }
         }
+        h->stats.distinct_path = h->distinct_path;
     }
     if (ng > 0) {
         const bool spec_hit = spec_groups && ng <= spec_groups;

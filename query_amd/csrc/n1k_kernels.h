@@ -47,6 +47,15 @@ hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTab
 hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalTable& G, uint32_t nblocks,
                               unsigned long long* ngroups, hipStream_t st);
 hipError_t launch_distinct_layout(const Program& P, const GlobalTable& G, const DistinctArgs& D, hipStream_t st);
+// COUNT(DISTINCT) over one-word members: one 256-bin partition pass (histogram, offsets, LDS-staged scatter) ...
+hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st);
+// ... the per-bin LDS sets, the global-memory fallback, and the hand-over of the member counts to the set sizes
+hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, hipStream_t st);
+hipError_t launch_distinct_words_global(const GlobalTable& G, const uint64_t* words, uint64_t n, uint64_t* table, uint64_t mask,
+                                        uint32_t key_shift, unsigned long long* counts, uint32_t* err_flags, uint32_t grid,
+                                        hipStream_t st);
+hipError_t launch_distinct_add_counts(const Program& P, const GlobalTable& G, const unsigned long long* counts, uint32_t glob_off,
+                                      hipStream_t st);
 hipError_t launch_distinct_insert(const Program& P, const GlobalTable& G, const DistinctArgs& D, uint32_t* err_flags,
                                   hipStream_t st);
 hipError_t launch_export_partials(const Program& P, const GlobalTable& G, uint32_t nparts, uint64_t cap, uint64_t* out,

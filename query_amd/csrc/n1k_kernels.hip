@@ -274,6 +274,41 @@ N1K_DEV bool distinct_classify(uint32_t kind, uint32_t tag, uint64_t p, uint32_t
     return true;
 }
 
+// One-word form of a (group key, class, value) member of a COUNT(DISTINCT) set, when both parts are small enough
+// (ScanArgs::nw_*).  Non-integral floats never are; DC_OTHER values (tag << 40 | code) are re-packed as code << 4 | tag.
+N1K_DEV bool member_word(const ScanArgs& A, uint64_t key, uint32_t cls, uint64_t val, uint64_t& word) {
+    if (cls == DC_FLOAT) return false;
+    uint64_t v = cls == DC_INT ? zigzag((int64_t)val) : (((val & 0xFFFFFFFFFFull) << 4) | (val >> 40));
+    if ((key >> A.nw_key_bits) != 0ull || (v >> A.nw_val_bits) != 0ull) return false;
+    word = (key << (A.nw_val_bits + 3)) | ((uint64_t)cls << A.nw_val_bits) | v;
+    return true;
+}
+
+// Workgroup-wide reservation of `mine` consecutive entries per thread behind *cursor: returns this thread's first
+// position.  All threads of the block call it; the caller synchronises before the scratch words are reused.
+template <int BLOCK>
+N1K_DEV unsigned long long tile_reserve(uint32_t mine, unsigned long long* cursor, uint32_t* wave_cnt,
+                                        unsigned long long* tile_base, uint32_t tid) {
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if ((int)(tid & 63) >= off) incl += t;
+    }
+    if ((tid & 63) == 63) wave_cnt[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < BLOCK / 64; w++) {
+            uint32_t c = wave_cnt[w];
+            wave_cnt[w] = run;
+            run += c;
+        }
+        *tile_base = run ? atomicAdd(cursor, (unsigned long long)run) : 0ull;
+    }
+    __syncthreads();
+    return *tile_base + wave_cnt[tid >> 6] + (incl - mine);
+}
+
 // read-only probe of the global table
 N1K_DEV long long global_find(const GlobalTable& G, uint64_t key) {
     uint64_t mask = G.capacity - 1;
@@ -372,6 +407,193 @@ __global__ __launch_bounds__(BLOCK) void distinct_insert_kernel(const Program P,
         if (cnt[i]) atomicAdd((unsigned long long*)&G.acc[(size_t)i * P.glob_words + D.glob_off], (unsigned long long)cnt[i]);
 }
 
+// ------------------------------------------------------------------ COUNT(DISTINCT) over member words
+//
+// value.Set membership (value/set.go:22-110) for the pairs that fit one 64-bit word.  Random compare-and-swap into a
+// table in HBM tops out near 20 G inserts/s on gfx950 whatever the table size (tools/ubench_cas.hip: 2 GB, 128 MB and
+// 2 MB windows all land at 4.6-5.4 ms per 100 M), so the set is built in LDS instead: the word log is radix
+// partitioned on bits of mix64(word) (one or two passes of 256 bins, LDS-staged so that every bin is written in
+// runs) until a bin's distinct words fit an LDS open-addressed set, then one workgroup de-duplicates each bin and
+// counts the new members per group.  Equal words always meet in the same bin, so the bins are independent.
+constexpr int kRadixBlock = 512, kRadixPer = 16, kRadixTile = kRadixBlock * kRadixPer;  // 8192 words = 64 KB staged
+
+N1K_DEV uint32_t radix_bin(uint64_t w, uint32_t shift) { return (uint32_t)(mix64(w) >> shift) & 255u; }
+
+// slice of segment `s` that workgroup blockIdx.x owns (the same in the histogram and the scatter pass)
+N1K_DEV void radix_slice(const RadixArgs& A, uint32_t s, uint64_t& lo, uint64_t& hi) {
+    const uint64_t s0 = A.seg_start[s], s1 = A.seg_start[s + 1];
+    uint64_t chunk = (s1 - s0 + gridDim.x - 1) / gridDim.x;
+    chunk = (chunk + kRadixTile - 1) / kRadixTile * kRadixTile;
+    lo = s0 + (uint64_t)blockIdx.x * chunk;
+    hi = lo + chunk < s1 ? lo + chunk : s1;
+    if (lo > s1) lo = hi = s1;
+}
+
+__global__ __launch_bounds__(kRadixBlock) void radix_hist_kernel(const RadixArgs A) {
+    __shared__ uint32_t h[256];
+    const uint32_t tid = threadIdx.x, s = blockIdx.y;
+    if (tid < 256) h[tid] = 0;
+    __syncthreads();
+    uint64_t lo, hi;
+    radix_slice(A, s, lo, hi);
+    for (uint64_t i = lo + tid; i < hi; i += kRadixBlock) atomicAdd(&h[radix_bin(A.src[i], A.shift)], 1u);
+    __syncthreads();
+    if (tid < 256 && h[tid]) atomicAdd(&A.hist[(size_t)s * 256 + tid], (unsigned long long)h[tid]);
+}
+
+// one workgroup per segment: exclusive scan of its 256 bin counts -> write cursors and the finer segment starts
+__global__ __launch_bounds__(256) void radix_offsets_kernel(const RadixArgs A) {
+    __shared__ unsigned long long sc[256];
+    const uint32_t s = blockIdx.x, t = threadIdx.x;
+    const unsigned long long v = A.hist[(size_t)s * 256 + t];
+    sc[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        unsigned long long x = t >= off ? sc[t - off] : 0ull;
+        __syncthreads();
+        sc[t] += x;
+        __syncthreads();
+    }
+    const unsigned long long excl = sc[t] - v + A.seg_start[s];
+    A.cursor[(size_t)s * 256 + t] = excl;
+    A.out_start[(size_t)s * 256 + t] = excl;
+    if (s == A.nseg - 1 && t == 255) A.out_start[(size_t)A.nseg * 256] = A.seg_start[A.nseg];
+}
+
+__global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixArgs A) {
+    __shared__ uint64_t stage[kRadixTile];
+    __shared__ uint32_t cnt[256], pre[256];
+    __shared__ unsigned long long gbase[256];
+    const uint32_t tid = threadIdx.x, s = blockIdx.y;
+    uint64_t lo, hi;
+    radix_slice(A, s, lo, hi);
+    for (uint64_t tile = lo; tile < hi; tile += kRadixTile) {
+        const uint32_t n = (uint32_t)(hi - tile < (uint64_t)kRadixTile ? hi - tile : (uint64_t)kRadixTile);
+        if (tid < 256) cnt[tid] = 0;
+        __syncthreads();
+        uint64_t w[kRadixPer];
+        uint32_t rk[kRadixPer];  // bin << 16 | rank of the word inside (tile, bin)
+#pragma unroll
+        for (int j = 0; j < kRadixPer; j++) {
+            const uint32_t p = (uint32_t)j * kRadixBlock + tid;
+            rk[j] = 0xFFFFFFFFu;
+            if (p < n) {
+                w[j] = A.src[tile + p];
+                const uint32_t b = radix_bin(w[j], A.shift);
+                rk[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the 256 counts (threads 0..255) and one global reservation per non-empty bin
+        uint32_t mine = tid < 256 ? cnt[tid] : 0u;
+        if (tid < 256) pre[tid] = mine;
+        __syncthreads();
+        for (uint32_t off = 1; off < 256; off <<= 1) {
+            uint32_t x = (tid < 256 && tid >= off) ? pre[tid - off] : 0u;
+            __syncthreads();
+            if (tid < 256) pre[tid] += x;
+            __syncthreads();
+        }
+        if (tid < 256) {
+            pre[tid] -= mine;
+            gbase[tid] = mine ? atomicAdd(&A.cursor[(size_t)s * 256 + tid], (unsigned long long)mine) : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kRadixPer; j++)
+            if (rk[j] != 0xFFFFFFFFu) stage[pre[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = w[j];
+        __syncthreads();
+        // the staged tile is ordered by bin: consecutive threads write consecutive words of a bin's run
+        for (uint32_t p = tid; p < n; p += kRadixBlock) {
+            const uint64_t x = stage[p];
+            const uint32_t b = radix_bin(x, A.shift);
+            A.dst[gbase[b] + (p - pre[b])] = x;
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per bin (persistent over bins): LDS open-addressed set of the bin's words; every first insertion is
+// one more member of its group's set (Set.Len(), value/set.go:198-215)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P, const GlobalTable G, const DedupeArgs D) {
+    extern __shared__ uint64_t dl[];
+    uint64_t* set = dl;
+    lds_u32* cnt = (lds_u32*)(dl + D.set_slots);
+    const uint32_t tid = threadIdx.x, mask = D.set_slots - 1;
+    for (uint32_t i = tid; i < D.lds_counters; i += BLOCK) cnt[i] = 0;
+    uint32_t overflow = 0;
+    for (uint32_t bin = blockIdx.x; bin < D.nbins; bin += gridDim.x) {
+        const uint64_t lo = D.bin_start[bin], hi = D.bin_start[bin + 1];
+        if (lo == hi) continue;
+        __syncthreads();
+        for (uint32_t i = tid; i < D.set_slots; i += BLOCK) *(volatile lds_u64*)lds_word(set, i) = kEmptyKey;
+        __syncthreads();
+        for (uint64_t i = lo + tid; i < hi; i += BLOCK) {
+            const uint64_t w = D.words[i];
+            uint32_t h = (uint32_t)mix64(w) & mask;  // low bits: the partition consumed the high ones
+            int state = 0;                           // 1 fresh, 2 already a member
+            for (int probe = 0; probe < 64 && !state; probe++) {
+                lds_u64* sp = lds_word(set, h);
+                unsigned long long cur = lds_peek(sp);
+                if (cur == w) state = 2;
+                else if (cur == kEmptyKey) {
+                    unsigned long long expected = kEmptyKey;
+                    if (__hip_atomic_compare_exchange_strong(sp, &expected, (unsigned long long)w, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP))
+                        state = 1;
+                    else if (expected == w) state = 2;
+                }
+                h = (h + 1) & mask;
+            }
+            if (!state) overflow = 1;  // the bin holds more distinct words than the LDS set takes: the caller falls back
+            if (state == 1) {
+                long long g = global_find(G, w >> D.key_shift);
+                if (g < 0) overflow = 1;
+                else if (D.lds_counters) (void)__hip_atomic_fetch_add(cnt + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else atomicAdd(&D.counts[g], 1ull);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < D.lds_counters; i += BLOCK)
+        if (cnt[i]) atomicAdd(&D.counts[i], (unsigned long long)cnt[i]);
+    if (overflow) atomicOr(D.overflow, 1u);
+}
+
+// fallback when a bin overflowed its LDS set: one open-addressed set of words in global memory for the whole log
+__global__ void distinct_words_global_kernel(const GlobalTable G, const uint64_t* words, uint64_t n, uint64_t* table,
+                                             uint64_t mask, uint32_t key_shift, unsigned long long* counts,
+                                             uint32_t* err_flags) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = words[i];
+        uint64_t h = mix64(w) & mask;
+        int state = 0;
+        for (uint64_t probe = 0; probe <= mask && !state; probe++) {
+            unsigned long long cur = __hip_atomic_load((unsigned long long*)&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == w) state = 2;
+            else if (cur == kEmptyKey) {
+                unsigned long long old = atomicCAS((unsigned long long*)&table[h], (unsigned long long)kEmptyKey, (unsigned long long)w);
+                if (old == kEmptyKey) state = 1;
+                else if (old == w) state = 2;
+            }
+            h = (h + 1) & mask;
+        }
+        if (state == 1) {
+            long long g = global_find(G, w >> key_shift);
+            if (g >= 0) atomicAdd(&counts[g], 1ull);
+            else atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+        } else if (!state)
+            atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+    }
+}
+
+__global__ void distinct_add_counts_kernel(const Program P, const GlobalTable G, const unsigned long long* counts, uint32_t glob_off) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.capacity) return;
+    if (counts[s]) G.acc[s * P.glob_words + glob_off] += counts[s];
+}
+
 // ------------------------------------------------------------------ K1+K2+K3(+K4): scan -> filter -> group
 //
 // One persistent workgroup per CU slice walks tiles of BLOCK*R rows.  DIRECT = the group-key domain is small
@@ -391,6 +613,8 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
 
     lds_table_init<BLOCK>(P, lds, S, tid);
     if (tid == 0) lds_fill = 0;
+    uint64_t* dcache = lds + (size_t)S * P.lds_words;  // "already logged" caches of the COUNT(DISTINCT) aggregates
+    for (uint32_t i = tid; i < A.dcache_slots * A.dcache_aggs; i += BLOCK) *(volatile lds_u64*)lds_word(dcache, i) = kEmptyKey;
     __syncthreads();
 
     uint32_t unsupported = 0, unpackable = 0;
@@ -472,41 +696,39 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
                 // per workgroup tile (one atomic on the cursor per BLOCK*R rows, not per wave).
                 uint32_t cls[R];
                 uint64_t val[R];
-                bool q[R];
-                uint32_t mine = 0;
+                bool q[R], nar[R];
+                uint32_t mine = 0, mine_w = 0;
+                const bool words = ag.kind == AGG_COUNT && A.log_word[ag.log_index] != nullptr;
 #pragma unroll
                 for (int j = 0; j < R; j++) {
                     cls[j] = 0;
                     val[j] = 0;
+                    nar[j] = false;
                     q[j] = pass[j] && distinct_classify(ag.kind, vt[j], vp[j], cls[j], val[j]);
-                    if (q[j]) {
+                    if (!q[j]) continue;
+                    uint64_t word;
+                    if (words && member_word(A, key[j], cls[j], val[j], word)) {
+                        // one-word member: skip it when this workgroup logged the very same word already (a
+                        // direct-mapped LDS cache; a racing duplicate only costs a redundant log entry)
+                        nar[j] = true;
+                        val[j] = word;
+                        if (A.dcache_slots) {
+                            lds_u64* c = lds_word(dcache, ag.log_index * A.dcache_slots + ((uint32_t)mix64(word) & (A.dcache_slots - 1)));
+                            if (lds_peek(c) == word) q[j] = false;
+                            else *(volatile lds_u64*)c = word;
+                        }
+                        if (q[j]) mine_w++;
+                    } else {
                         mine++;
                         if (slot[j] >= 0) lds_add_u64(lds_word(lds, (ag.lds_off + cls[j]) * S + (uint32_t)slot[j]), 1ull);
                         else atomicAdd((unsigned long long*)&G.acc[(size_t)grow[j] * P.glob_words + ag.glob_off + 1 + cls[j]], 1ull);
                     }
                 }
-                // exclusive prefix of `mine` over the workgroup: wave scan + per-wave totals in LDS
-                uint32_t incl = mine;
-                for (int off = 1; off < 64; off <<= 1) {
-                    uint32_t t = __shfl_up(incl, off, 64);
-                    if ((int)(tid & 63) >= off) incl += t;
-                }
-                if ((tid & 63) == 63) log_wave_cnt[tid >> 6] = incl;
-                __syncthreads();
-                if (tid == 0) {
-                    uint32_t run = 0;
-                    for (int w = 0; w < BLOCK / 64; w++) {
-                        uint32_t c = log_wave_cnt[w];
-                        log_wave_cnt[w] = run;
-                        run += c;
-                    }
-                    log_tile_base = run ? atomicAdd(&A.log_cursor[ag.log_index], (unsigned long long)run) : 0ull;
-                }
-                __syncthreads();
-                unsigned long long pos = log_tile_base + log_wave_cnt[tid >> 6] + (incl - mine);
+                // log space is reserved once per workgroup tile and log (one atomic on the cursor per BLOCK*R rows)
+                unsigned long long pos = tile_reserve<BLOCK>(mine, &A.log_cursor[ag.log_index], log_wave_cnt, &log_tile_base, tid);
 #pragma unroll
                 for (int j = 0; j < R; j++) {
-                    if (!q[j]) continue;
+                    if (!q[j] || nar[j]) continue;
                     if (pos < A.log_capacity) {
                         A.log_key[ag.log_index][pos] = key[j];
                         A.log_val[ag.log_index][pos] = val[j];
@@ -517,6 +739,17 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
                     pos++;
                 }
                 __syncthreads();
+                if (words) {
+                    pos = tile_reserve<BLOCK>(mine_w, &A.word_cursor[ag.log_index], log_wave_cnt, &log_tile_base, tid);
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        if (!q[j] || !nar[j]) continue;
+                        if (pos < A.log_capacity) A.log_word[ag.log_index][pos] = val[j];
+                        else atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                        pos++;
+                    }
+                    __syncthreads();
+                }
                 continue;
             }
 #pragma unroll
@@ -831,7 +1064,7 @@ const std::vector<SpecEntry>& spec_registry() {
 __global__ void init_table_kernel(const Program P, const GlobalTable G, uint64_t first, uint64_t count,
                                   unsigned long long* counters) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (counters && i < 16) counters[i] = 0;  // reopen(): counters and error flags go back to zero in the same launch
+    if (counters && i < kCounters) counters[i] = 0;  // reopen(): counters and error flags go back to zero in the same launch
     if (i >= count) return;
     uint64_t s = first + i;
     G.keys[s] = kEmptyKey;
@@ -1523,7 +1756,7 @@ static hipError_t launch_scan_variant(const Program& P, const ScanArgs& A, const
 
 hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTable& G, unsigned long long* ngroups,
                              uint32_t grid, uint32_t block, uint32_t rows_per_lane, bool direct, hipStream_t st) {
-    size_t shmem = (size_t)A.lds_slots * P.lds_words * 8;
+    size_t shmem = (size_t)A.lds_slots * P.lds_words * 8 + (size_t)A.dcache_slots * A.dcache_aggs * 8;
     if (block == 256) return launch_scan_variant<4, 256>(P, A, G, ngroups, grid, direct, shmem, st);
     if (block == 512) return launch_scan_variant<4, 512>(P, A, G, ngroups, grid, direct, shmem, st);
     if (rows_per_lane == 2) return launch_scan_variant<2, 1024>(P, A, G, ngroups, grid, direct, shmem, st);
@@ -1555,6 +1788,36 @@ hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalT
     uint32_t blocks = (F.lds_slots + 63) / 64;
     uint32_t ychunks = nblocks >= 512 ? 4 : (nblocks >= 128 ? 2 : 1);  // 16 * ychunks parallel chunks of workgroups
     hipLaunchKernelGGL(merge_slabs_kernel, dim3(blocks, ychunks), dim3(64, 16), 0, st, P, F, G, nblocks, ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st) {
+    (void)hipMemsetAsync(A.hist, 0, (size_t)A.nseg * 256 * sizeof(unsigned long long), st);
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
+    hipLaunchKernelGGL(radix_offsets_kernel, dim3(A.nseg), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, hipStream_t st) {
+    auto k = distinct_dedupe_kernel<1024>;
+    size_t shmem = (size_t)D.set_slots * 8 + (size_t)D.lds_counters * 4;
+    if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(1024), shmem, st, P, G, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_distinct_words_global(const GlobalTable& G, const uint64_t* words, uint64_t n, uint64_t* table, uint64_t mask,
+                                        uint32_t key_shift, unsigned long long* counts, uint32_t* err_flags, uint32_t grid,
+                                        hipStream_t st) {
+    hipLaunchKernelGGL(distinct_words_global_kernel, dim3(grid), dim3(512), 0, st, G, words, n, table, mask, key_shift, counts, err_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_distinct_add_counts(const Program& P, const GlobalTable& G, const unsigned long long* counts, uint32_t glob_off,
+                                      hipStream_t st) {
+    uint32_t blocks = (uint32_t)((G.capacity + 255) / 256);
+    hipLaunchKernelGGL(distinct_add_counts_kernel, dim3(blocks), dim3(256), 0, st, P, G, counts, glob_off);
     return hipGetLastError();
 }
 

@@ -31,6 +31,10 @@ constexpr int kMaxAggs = 8;
 constexpr int kMaxLdsWords = 40;   // 1 key word + accumulators
 
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+// device counters of a handle: [0] rows selected [1] groups [2] out count [3] filter total [4] rehash scratch
+// [5] DISTINCT region words [8..11] pair-log cursors [12] error flags [13] wide key values [16..19] word-log cursors
+// [20] DISTINCT LDS-set overflow flag
+constexpr uint32_t kCounters = 32;
 
 // value tags == n1k_tag (include/n1k.h)
 enum : uint32_t { T_MISSING = 0, T_NULL, T_FALSE, T_TRUE, T_INT, T_FLOAT, T_STRING, T_ARRAY, T_OBJECT };
@@ -185,6 +189,39 @@ struct ScanArgs {
     uint8_t* log_cls[kMaxDistinct];
     unsigned long long* log_cursor;  // kMaxDistinct counters
     uint64_t log_capacity;
+    // COUNT(DISTINCT): pairs whose group key and value fit one 64-bit MEMBER WORD
+    //   [key : nw_key_bits][class : 3][value : nw_val_bits]      (nw_key_bits + 3 + nw_val_bits == 64)
+    // go to a second log of single words (8 B/pair) that n1k_finish radix-partitions and de-duplicates in LDS.
+    uint64_t* log_word[kMaxDistinct];
+    unsigned long long* word_cursor;  // kMaxDistinct counters
+    uint32_t nw_key_bits, nw_val_bits;
+    uint32_t dcache_slots;  // per DISTINCT aggregate: slots (power of two) of the workgroup's "already logged" cache, 0 = none
+    uint32_t dcache_aggs;   // number of such caches (== DISTINCT aggregates of the plan)
+};
+
+// radix partition of a word log by bits of mix64(word) (finish step of COUNT(DISTINCT), see n1k_kernels.hip)
+struct RadixArgs {
+    const uint64_t* src;
+    uint64_t* dst;
+    const uint64_t* seg_start;  // nseg + 1 entries: segment s is src[seg_start[s] .. seg_start[s+1])
+    uint32_t nseg;
+    uint32_t shift;             // bin = (mix64(word) >> shift) & 255
+    unsigned long long* hist;   // nseg * 256 counters
+    unsigned long long* cursor; // nseg * 256 write cursors (absolute positions in dst)
+    uint64_t* out_start;        // nseg * 256 + 1 entries: starts of the finer segments
+};
+
+struct DedupeArgs {
+    const uint64_t* words;
+    const uint64_t* bin_start;  // nbins + 1
+    uint32_t nbins;
+    uint32_t set_slots;         // LDS set size (power of two)
+    uint32_t key_shift;         // word >> key_shift = packed group key
+    uint32_t glob_off;
+    unsigned long long* counts; // per global-table slot: distinct members found (added to the set size afterwards)
+    uint32_t* overflow;         // set when a bin holds more distinct words than the LDS set takes
+    uint32_t lds_counters;      // == table capacity when per-group LDS counters are used, else 0
+    uint32_t pad;
 };
 
 // value classes of the DISTINCT sets (value/set.go:22-35 keeps one map per type; integral floats join the ints)

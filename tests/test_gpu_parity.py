@@ -467,3 +467,74 @@ def test_wide_key_values_survive_reopen():
         pu.assert_same_groups(op.after_items(), ora)
         op.reopen()
     op.done()
+
+
+def _distinct_table(n, nvals, ngroups, seed=3, wide_share=0.1):
+    """(g, v): v mostly small ints (one-word members), plus floats / huge ints / strings (two-word pairs)."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, ngroups, n).astype(np.uint64)
+    tags = np.full(n, n1o.T_INT, np.uint8)
+    pay = (rng.integers(0, nvals, n) - nvals // 3).astype(np.int64).view(np.uint64).copy()
+    w = rng.random(n) < wide_share
+    kind = rng.integers(0, 4, n)
+    fl = w & (kind == 0)
+    tags[fl] = n1o.T_FLOAT
+    pay[fl] = (rng.integers(0, nvals, int(fl.sum())) + 0.5).view(np.uint64)
+    big = w & (kind == 1)
+    pay[big] = (rng.integers(0, 50, int(big.sum())).astype(np.int64) * np.int64(2 ** 55)).view(np.uint64)
+    st = w & (kind == 2)
+    tags[st] = n1o.T_STRING
+    pay[st] = rng.integers(0, 3, int(st.sum())).astype(np.uint64)
+    nul = w & (kind == 3)
+    tags[nul] = n1o.T_NULL
+    pay[nul] = 0
+    return n1o.Table([n1o.Column(D("g"), n1o.COL_TAGGED64, tags=np.full(n, n1o.T_INT, np.uint8), payload=g),
+                      n1o.Column(D("v"), n1o.COL_TAGGED64, tags=tags, payload=pay)], [b"x", b"y", b"z"])
+
+
+@pytest.mark.parametrize("n,nvals,ngroups,opts,path", [
+    (3_000, 50, 4, {}, 3),                                  # one LDS set for the whole log (no partition pass)
+    (120_000, 40_000, 7, {}, 3),                            # one partition pass
+    (900_000, 700_000, 50, {}, 3),                          # two partition passes
+    (400_000, 16, 5, {}, 3),                                # few members, each logged many times (filter cache, hot bins)
+    (300_000, 200_000, 9, {"distinct_set_slots": 64, "distinct_levels": 1}, 7),   # bins overflow their LDS sets: global one-word set
+    (200_000, 90_000, 6, {"distinct_words": 0}, 1),         # everything through the two-word pair sets
+], ids=["direct", "one-pass", "two-pass", "duplicates", "overflow-fallback", "pairs-only"])
+def test_count_distinct_paths(n, nvals, ngroups, opts, path):
+    """COUNT(DISTINCT) through every way the sets are built (value.Set semantics, value/set.go:22-110)."""
+    t = _distinct_table(n, nvals, ngroups)
+    aggs = sorted(["count(distinct %s)" % D("v"), "count(%s)" % D("v")])
+    ora = n1o.run(t, None, [D("g")], aggs, threads=2)
+    gpu, stats = pu.run_gpu(t, None, [D("g")], aggs, batches=2, **opts)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert stats["distinct_path"] == path
+
+
+def test_count_distinct_words_refinish_and_reopen():
+    """The word log survives n1k_finish (more batches may follow) and is dropped by reopen."""
+    t = _distinct_table(150_000, 60_000, 5)
+    aggs = ["count(distinct %s)" % D("v")]
+    pj = query_amd.plan.filter_group_plan(None, [D("g")], aggs)
+    op = query_amd.GpuFilterGroup(pj)
+    by = {c.name: c for c in t.columns}
+    half = t.slice(0, 75_000), t.slice(75_000, 150_000)
+    for _ in range(2):
+        op.process_items([{c.name: c for c in half[0].columns}[p] for p in op.column_paths], t.dictionary)
+        pu.assert_same_groups(op.after_items(), n1o.run(half[0], None, [D("g")], aggs))
+        op.process_items([{c.name: c for c in half[1].columns}[p] for p in op.column_paths], t.dictionary)
+        pu.assert_same_groups(op.after_items(), n1o.run(t, None, [D("g")], aggs))
+        op.reopen()
+    op.done()
+
+
+def test_count_distinct_dictionary_key_and_strings():
+    """config 3's shape with a dictionary-coded key; string operands are one-word members too when codes are small."""
+    t = n1o.synth_table(150_000, k_cat=300, total_rows=40_000)
+    aggs = sorted(["count(distinct %s)" % D("user_id"), "count(distinct %s)" % D("cat"), "count(distinct %s)" % D("price")])
+    ora = n1o.run(t, None, [D("cat")], aggs, threads=2)
+    gpu, stats = pu.run_gpu(t, None, [D("cat")], aggs, batches=2)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert stats["distinct_path"] & 2
+    ora = n1o.run(t, None, [], aggs, threads=2)
+    gpu, stats = pu.run_gpu(t, None, [], aggs)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
