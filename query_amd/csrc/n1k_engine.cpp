@@ -119,7 +119,7 @@ struct n1k_handle {
     DevBuf<uint64_t> d_log_word[kMaxDistinct], d_part[2], d_seg[3], d_wtable;
     DevBuf<unsigned long long> d_hist, d_cursor, d_dcounts;
     uint32_t opt_distinct_words = 1;      // 0: every pair takes the (key, value, class) log and the global sets
-    uint32_t opt_distinct_set_slots = 8192;  // LDS set size of the de-duplication kernel (power of two)
+    uint32_t opt_distinct_set_slots = 4096;  // LDS set size of the de-duplication kernel (power of two)
     int32_t opt_distinct_levels = -1;        // partition passes before the LDS sets: -1 = by log size, 0..2 forced (tests)
     uint32_t nw_key_bits = 0, nw_val_bits = 0;
     bool distinct_words[kMaxDistinct] = {false, false, false, false};
@@ -1331,8 +1331,11 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
     D.glob_off = ag.glob_off;
     D.counts = h->d_dcounts.p;
     D.overflow = d_overflow;
-    D.lds_counters = h->table.capacity <= 8192 ? (uint32_t)h->table.capacity : 0;
-    uint32_t grid = (uint32_t)std::min<uint64_t>(nbins, (uint64_t)h->num_cus * (set_slots <= 4096 && D.lds_counters <= 4096 ? 2 : 1));
+    D.lds_counters = h->table.capacity <= 4096 ? (uint32_t)h->table.capacity : 0;  // LDS table of per-group member counts
+    // 512-thread workgroups, as many per CU as their LDS (set + group counters) allows
+    const size_t shmem = (size_t)set_slots * 8 + (size_t)D.lds_counters * 12 + 512;
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nbins, (uint64_t)h->num_cus * per_cu);
     HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, grid, h->stream));
     uint32_t overflow = 0;
     HIP_TRY(h, hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, h->stream));
