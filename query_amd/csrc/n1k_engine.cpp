@@ -1356,6 +1356,94 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
     return N1K_OK;
 }
 
+// value.Collate for result values (value/value.go:69-79 type order; integer.go:100-118, float.go:106-172,
+// string.go:116-130, boolean.go:99-113).  Arrays / objects collate element-wise in the reference: not ordered here.
+static int host_collate(const n1k_handle* h, const n1k_value& a, const n1k_value& b, bool* unsupported) {
+    auto cls = [](uint8_t t) -> int {
+        switch (t) {
+            case N1K_T_MISSING: return 0;
+            case N1K_T_NULL: return 1;
+            case N1K_T_FALSE: case N1K_T_TRUE: return 2;
+            case N1K_T_INT: case N1K_T_FLOAT: return 3;
+            case N1K_T_STRING: return 4;
+            case N1K_T_ARRAY: return 5;
+            default: return 6;
+        }
+    };
+    const int ca = cls(a.tag), cb = cls(b.tag);
+    if (ca != cb) return ca < cb ? -1 : 1;
+    switch (ca) {
+        case 2: return (int)(a.tag == N1K_T_TRUE) - (int)(b.tag == N1K_T_TRUE);
+        case 3: {
+            if (a.tag == N1K_T_INT && b.tag == N1K_T_INT) return a.v.i < b.v.i ? -1 : (a.v.i > b.v.i ? 1 : 0);
+            const double x = a.tag == N1K_T_INT ? (double)a.v.i : a.v.f, y = b.tag == N1K_T_INT ? (double)b.v.i : b.v.f;
+            if (x != x) return (y != y) ? 0 : -1;  // NaN sorts first
+            if (y != y) return 1;
+            return x < y ? -1 : (x > y ? 1 : 0);
+        }
+        case 4: {
+            const std::string& x = h->dict[a.v.code];
+            const std::string& y = h->dict[b.v.code];
+            const int c = memcmp(x.data(), y.data(), std::min(x.size(), y.size()));
+            if (c) return c < 0 ? -1 : 1;
+            return x.size() < y.size() ? -1 : (x.size() > y.size() ? 1 : 0);
+        }
+        case 5:
+        case 6:
+            if (a.v.code != b.v.code) *unsupported = true;
+            return 0;
+        default: return 0;
+    }
+}
+
+// Order / Offset / Limit over the final groups (execution/order.go:121-169: term by term Collate, DESC flips it;
+// order_limit.go keeps offset + limit rows; offset.go / limit.go then cut).  sort.Sort is not stable, so the order
+// among rows that tie on every term is unspecified in the reference too; here ties keep table order.
+static n1k_status order_groups(n1k_handle* h, uint64_t& ng) {
+    const ParsedPlan& pl = h->plan;
+    const size_t nk = pl.keys.size(), na = pl.aggs.size();
+    std::vector<uint32_t> perm((size_t)ng);
+    for (size_t i = 0; i < perm.size(); i++) perm[i] = (uint32_t)i;
+    bool unsupported = false;
+    if (pl.has_order) {
+        auto less = [&](uint32_t x, uint32_t y) {
+            for (const OrderTerm& t : pl.order) {
+                const n1k_value& a = t.key_index >= 0 ? h->r_keys[x * nk + t.key_index] : h->r_aggs[x * na + t.agg_index];
+                const n1k_value& b = t.key_index >= 0 ? h->r_keys[y * nk + t.key_index] : h->r_aggs[y * na + t.agg_index];
+                const int c = host_collate(h, a, b, &unsupported);
+                if (c) return t.desc ? c > 0 : c < 0;
+            }
+            return false;
+        };
+        const uint64_t keep = pl.limit >= 0 ? std::min<uint64_t>(ng, (uint64_t)pl.offset + (uint64_t)pl.limit) : ng;
+        if (keep < ng) std::partial_sort(perm.begin(), perm.begin() + keep, perm.end(), [&](uint32_t x, uint32_t y) {
+            return less(x, y) || (!less(y, x) && x < y);
+        });
+        else std::stable_sort(perm.begin(), perm.end(), less);
+        if (unsupported) return fail(h, N1K_UNSUPPORTED_DATA, "ORDER BY over array / object values is outside the device subset");
+    }
+    const uint64_t first = std::min<uint64_t>(ng, (uint64_t)pl.offset);
+    const uint64_t last = pl.limit >= 0 ? std::min<uint64_t>(ng, first + (uint64_t)pl.limit) : ng;
+    std::vector<n1k_value> keys((last - first) * nk), aggs((last - first) * na);
+    std::vector<n1k_partial> parts((last - first) * na);
+    std::vector<uint64_t> rep(last - first);
+    for (uint64_t i = first; i < last; i++) {
+        const uint32_t g = perm[i];
+        for (size_t k = 0; k < nk; k++) keys[(i - first) * nk + k] = h->r_keys[g * nk + k];
+        for (size_t a = 0; a < na; a++) {
+            aggs[(i - first) * na + a] = h->r_aggs[g * na + a];
+            if (!h->r_parts.empty()) parts[(i - first) * na + a] = h->r_parts[g * na + a];
+        }
+        rep[i - first] = g < h->r_rep.size() ? h->r_rep[g] : ~0ull;
+    }
+    h->r_keys.swap(keys);
+    h->r_aggs.swap(aggs);
+    h->r_parts.swap(parts);
+    h->r_rep.swap(rep);
+    ng = last - first;
+    return N1K_OK;
+}
+
 n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     if (!h || !out) return N1K_INVALID;
     memset(out, 0, sizeof *out);
@@ -1516,6 +1604,10 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
         h->r_rep.assign(1, ~0ull);
         for (uint32_t a = 0; a < na; a++) default_value(pl.aggs[a], h->r_aggs[a], h->r_parts[a]);
         ng = 1;
+    }
+    if (pl.has_order || pl.limit >= 0 || pl.offset > 0) {
+        n1k_status st = order_groups(h, ng);
+        if (st != N1K_OK) return st;
     }
     out->ngroups = ng;
     out->keys = h->r_keys.data();

@@ -546,6 +546,7 @@ bool plan_node(const JVal& node, ParsedPlan& out, PlanError& err, int depth) {
                 auto e = parse_expression(k.str, err);
                 if (!e) return false;
                 out.keys.push_back(std::move(e));
+                out.key_texts.push_back(k.str);
             }
         if (as && as->type == JVal::Arr)
             for (auto& a : as->arr) {
@@ -556,6 +557,62 @@ bool plan_node(const JVal& node, ParsedPlan& out, PlanError& err, int depth) {
             }
         out.has_group = true;
         return true;
+    }
+    if (name == "IntermediateGroup" || name == "FinalGroup") {  // plan/group.go:106-273: subsumed by the device operator
+        if (!out.has_group) { err.msg = name + " before InitialGroup"; return false; }
+        const JVal* ks = node.get("group_keys");
+        const JVal* as = node.get("aggregates");
+        size_t nk = ks && ks->type == JVal::Arr ? ks->arr.size() : 0, na = as && as->type == JVal::Arr ? as->arr.size() : 0;
+        bool same = nk == out.key_texts.size() && na == out.aggs.size();
+        for (size_t i = 0; same && i < nk; i++) same = ks->arr[i].type == JVal::Str && ks->arr[i].str == out.key_texts[i];
+        for (size_t i = 0; same && i < na; i++) same = as->arr[i].type == JVal::Str && as->arr[i].str == out.aggs[i].text;
+        if (!same) { err.msg = name + " does not match the InitialGroup"; return false; }
+        return true;
+    }
+    auto const_count = [&](const JVal* v, const char* what, int64_t& dst) -> bool {
+        // LIMIT / OFFSET expressions: non-negative integer constants only (anything else needs the evaluator)
+        if (!v || v->type != JVal::Str) { err.msg = std::string(what) + " without expression"; return false; }
+        std::string t = v->str;
+        while (!t.empty() && (t.front() == '(' || t.front() == ' ')) t.erase(t.begin());
+        while (!t.empty() && (t.back() == ')' || t.back() == ' ')) t.pop_back();
+        if (t.empty() || t.size() > 18 || t.find_first_not_of("0123456789") != std::string::npos) {
+            err.unsupported = true;
+            err.msg = std::string(what) + " expression is not an integer constant: " + v->str;
+            return false;
+        }
+        dst = (int64_t)strtoll(t.c_str(), nullptr, 10);
+        return true;
+    };
+    if (name == "Order") {  // plan/order.go:51-79 (the node carries its own offset / limit for the top-k sort)
+        if (!out.has_group || out.has_order) { err.unsupported = true; err.msg = "Order runs on the device only over the groups"; return false; }
+        const JVal* ts = node.get("sort_terms");
+        if (!ts || ts->type != JVal::Arr || ts->arr.empty()) { err.msg = "Order without sort_terms"; return false; }
+        for (auto& t : ts->arr) {
+            const JVal* e = t.type == JVal::Obj ? t.get("expr") : nullptr;
+            if (!e || e->type != JVal::Str) { err.msg = "sort term without expr"; return false; }
+            OrderTerm ot;
+            ot.text = e->str;
+            const JVal* d = t.get("desc");
+            ot.desc = d && d->type == JVal::Bool && d->b;
+            for (size_t i = 0; i < out.key_texts.size() && ot.key_index < 0; i++)
+                if (out.key_texts[i] == ot.text) ot.key_index = (int)i;
+            for (size_t i = 0; i < out.aggs.size() && ot.key_index < 0 && ot.agg_index < 0; i++)
+                if (out.aggs[i].text == ot.text) ot.agg_index = (int)i;
+            if (ot.key_index < 0 && ot.agg_index < 0) {
+                err.unsupported = true;
+                err.msg = "sort term is neither a group key nor an aggregate of the plan: " + ot.text;
+                return false;
+            }
+            out.order.push_back(ot);
+        }
+        out.has_order = true;
+        if (node.get("offset") && !const_count(node.get("offset"), "offset", out.offset)) return false;
+        if (node.get("limit") && !const_count(node.get("limit"), "limit", out.limit)) return false;
+        return true;
+    }
+    if (name == "Limit" || name == "Offset") {  // plan/limit.go:46-53, plan/offset.go
+        if (!out.has_group) { err.unsupported = true; err.msg = name + " runs on the device only over the groups"; return false; }
+        return const_count(node.get("expr"), name == "Limit" ? "limit" : "offset", name == "Limit" ? out.limit : out.offset);
     }
     err.unsupported = true;
     err.msg = "operator " + name + " does not run on the device";

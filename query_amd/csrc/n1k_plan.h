@@ -42,17 +42,33 @@ struct AggDef {
     std::string text;               // agg.String(): key of the reference's "aggregates" attachment map
 };
 
+// one ORDER BY term over the groups (plan/order.go:51-79): its expression must be, text for text, one of the group
+// keys or one of the aggregates (the Go glue resolves projection aliases before handing the plan over)
+struct OrderTerm {
+    std::string text;
+    bool desc = false;
+    int key_index = -1;  // >= 0: group key
+    int agg_index = -1;  // >= 0: aggregate
+};
+
 struct ParsedPlan {
     bool has_filter = false;
     bool has_group = false;
     std::unique_ptr<Expr> condition;
     std::vector<std::unique_ptr<Expr>> keys;
+    std::vector<std::string> key_texts;  // stringer text of every group key
     std::vector<AggDef> aggs;
     std::vector<std::string> paths;  // distinct leaf paths in column order
     int max_parallelism = 0;
+    // Order / Offset / Limit over the final groups (execution/order.go, order_limit.go, offset.go, limit.go)
+    bool has_order = false;
+    std::vector<OrderTerm> order;
+    int64_t limit = -1;  // < 0: none
+    int64_t offset = 0;
 };
 
-// Parse plan JSON (Sequence / Parallel / Filter / InitialGroup nodes).  Returns false and fills err on failure.
+// Parse plan JSON (Sequence / Parallel / Filter / InitialGroup nodes, optionally followed by IntermediateGroup /
+// FinalGroup — which the device operator subsumes — and Order / Offset / Limit over the groups).  Returns false and fills err on failure.
 bool parse_plan_json(const char* json, size_t len, ParsedPlan& out, PlanError& err);
 
 // Parse one stringified expression / aggregate.

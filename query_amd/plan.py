@@ -75,17 +75,71 @@ class Parallel:
         return d
 
 
+@dataclass
+class Order:
+    """plan/order.go:51-79: sort_terms [{expr, desc?}], optional offset / limit expression strings."""
+    sort_terms: Sequence[tuple]  # (expression text, descending)
+    offset: Optional[int] = None
+    limit: Optional[int] = None
+
+    def marshal(self) -> dict:
+        terms = []
+        for expr, desc in self.sort_terms:
+            t = {"expr": expr}
+            if desc:
+                t["desc"] = True
+            terms.append(t)
+        d = {"#operator": "Order", "sort_terms": terms}
+        if self.offset is not None:
+            d["offset"] = str(int(self.offset))
+        if self.limit is not None:
+            d["limit"] = str(int(self.limit))
+        return d
+
+
+@dataclass
+class Limit:
+    expr: int
+
+    def marshal(self) -> dict:
+        return {"#operator": "Limit", "expr": str(int(self.expr))}
+
+
+@dataclass
+class Offset:
+    expr: int
+
+    def marshal(self) -> dict:
+        return {"#operator": "Offset", "expr": str(int(self.expr))}
+
+
 def marshal_json(op) -> str:
     return json.dumps(op.marshal(), sort_keys=True)
 
 
 def filter_group_plan(condition: Optional[str], group_keys: Optional[Sequence[str]],
-                      aggregates: Optional[Sequence[str]], *, filter_only: bool = False) -> str:
+                      aggregates: Optional[Sequence[str]], *, filter_only: bool = False,
+                      order: Optional[Sequence[tuple]] = None, limit: Optional[int] = None,
+                      offset: Optional[int] = None) -> str:
     """Plan JSON of Parallel{Sequence[Filter?, InitialGroup?]} as the planner emits it
-    (planner/build_select_sub.go:209-211, 276-296)."""
+    (planner/build_select_sub.go:209-211, 276-296).  With `order` / `limit` / `offset` the whole grouped tail
+    follows: IntermediateGroup, FinalGroup, Order (which carries offset and limit, plan/order.go:51-79), Offset,
+    Limit (planner/build_select.go) — the sort terms must be group keys or aggregates of the plan."""
     children: List[object] = []
     if condition:
         children.append(Filter(condition))
     if not filter_only:
         children.append(InitialGroup(list(group_keys or []), list(aggregates or [])))
-    return marshal_json(Parallel(Sequence(children)))
+    par = Parallel(Sequence(children))
+    if order is None and limit is None and offset is None:
+        return marshal_json(par)
+    tail: List[object] = [par, IntermediateGroup(list(group_keys or []), list(aggregates or [])),
+                          FinalGroup(list(group_keys or []), list(aggregates or []))]
+    if order:
+        tail.append(Order(list(order), offset, limit))
+    else:
+        if offset is not None:
+            tail.append(Offset(offset))
+        if limit is not None:
+            tail.append(Limit(limit))
+    return marshal_json(Sequence(tail))

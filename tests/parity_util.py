@@ -14,9 +14,10 @@ REL_TOL = 1e-9  # north_star: float SUM/AVG within 1e-9 relative; everything els
 
 
 def run_gpu(table: n1o.Table, condition: Optional[str], keys: Sequence[str], aggs: Sequence[str], *,
-            filter_only: bool = False, batches: int = 1, device_resident: bool = False, **options):
+            filter_only: bool = False, batches: int = 1, device_resident: bool = False, order=None, limit=None,
+            offset=None, **options):
     """Run through libn1k.so.  The table's columns are matched to the plan's leaf paths by name."""
-    pj = qplan.filter_group_plan(condition, keys, aggs, filter_only=filter_only)
+    pj = qplan.filter_group_plan(condition, keys, aggs, filter_only=filter_only, order=order, limit=limit, offset=offset)
     op = query_amd.GpuFilterGroup(pj, **options)
     try:
         by_name = {c.name: c for c in table.columns}
@@ -112,3 +113,66 @@ def assert_same_groups(gpu, ora, rel=REL_TOL, aggs: Optional[Sequence[str]] = No
         for i, (g, o) in enumerate(zip(ga, oa)):
             fl = bool(aggs) and aggs[i].split("(")[0] in ("sum", "avg")
             assert values_match(g, o, rel, fl), ("aggregate %d of group %r: device %r oracle %r" % (i, k, g, o))
+
+
+_CLASS = {n1o.T_MISSING: 0, n1o.T_NULL: 1, n1o.T_FALSE: 2, n1o.T_TRUE: 2, n1o.T_INT: 3, n1o.T_FLOAT: 3, n1o.T_STRING: 4,
+          n1o.T_ARRAY: 5, n1o.T_OBJECT: 6}
+
+
+def collate_values(a, b) -> int:
+    """value.Collate over (tag, python value) pairs: type order, then numbers / bytes / booleans (value/*.go)."""
+    ca, cb = _CLASS[a[0]], _CLASS[b[0]]
+    if ca != cb:
+        return -1 if ca < cb else 1
+    if ca <= 1:
+        return 0
+    if ca == 2:
+        return (a[0] == n1o.T_TRUE) - (b[0] == n1o.T_TRUE)
+    x, y = a[1], b[1]
+    return (x > y) - (x < y)
+
+
+def assert_ordered_groups(gpu, ora, keys, aggs, order, limit=None, offset=None, rel=REL_TOL):
+    """The device's ORDER BY / OFFSET / LIMIT output against the oracle's groups sorted here with the same terms
+    (execution/order.go:121-169).  Rows may trade places only where their sort values tie (sort.Sort is not stable)
+    or, for float SUM/AVG terms, agree within `rel`."""
+    import functools
+    names = list(keys) + list(aggs)
+
+    def term_value(g, text):
+        i = names.index(text)
+        return g[0][i] if i < len(keys) else g[1][i - len(keys)]
+
+    def cmp(g1, g2):
+        for text, desc in order or []:
+            c = collate_values(term_value(g1, text), term_value(g2, text))
+            if c:
+                return -c if desc else c
+        return 0
+
+    exp = sorted(zip(ora.keys, ora.aggs), key=functools.cmp_to_key(cmp))
+    lo = offset or 0
+    hi = len(exp) if limit is None else min(len(exp), lo + limit)
+    got = list(zip(gpu.keys, gpu.aggs))
+    assert len(got) == max(0, hi - lo)
+    omap = {_canon_key(k): a for k, a in zip(ora.keys, ora.aggs)}
+    for (k, a) in got:  # every returned group is a group of the oracle, with the same aggregates
+        oa = omap[_canon_key(k)]
+        for i, (g, o) in enumerate(zip(a, oa)):
+            assert values_match(g, o, rel, aggs[i].split("(")[0] in ("sum", "avg")), (k, i, g, o)
+    if not order:
+        return
+    for i in range(1, len(got)):  # sorted by its own values
+        assert cmp(got[i - 1], got[i]) <= 0 or _near(got[i - 1], got[i], order, term_value, rel), ("not sorted at", i)
+    for i, (e, g) in enumerate(zip(exp[lo:hi], got)):
+        if _canon_key(e[0]) == _canon_key(g[0]):
+            continue
+        assert _near(e, g, order, term_value, rel), ("row %d differs beyond ties" % i, e, g)
+
+
+def _near(g1, g2, order, term_value, rel):
+    for text, _ in order:
+        a, b = term_value(g1, text), term_value(g2, text)
+        if not values_match(a, b, rel, True):
+            return False
+    return True

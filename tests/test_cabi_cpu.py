@@ -86,3 +86,32 @@ def test_runtime_specialisation_compiles_without_a_gpu():
     st = _ffi.lib().n1k_jit_check(op._h, kinds.ctypes.data, 3, log, 4096)
     assert st == _ffi.OK, log.value.decode(errors="replace")
     op.done()
+
+
+def test_order_limit_nodes_are_part_of_the_plan_contract():
+    """plan/order.go:51-79, plan/limit.go:46-53: Order / Offset / Limit after the group operators are accepted when
+    their terms are keys or aggregates of the plan; anything else keeps the reference operators (N1K_UNSUPPORTED)."""
+    import query_amd
+    from query_amd import plan, _ffi
+    D = lambda *n: plan.field_path("default", *n)
+    keys, aggs = [D("cat"), D("region_id")], ["sum(%s)" % D("price")]
+    ok = plan.filter_group_plan("(50 < %s)" % D("price"), keys, aggs, order=[(aggs[0], True), (D("cat"), False)], limit=100, offset=3)
+    op = query_amd.GpuFilterGroup(ok)
+    assert op.column_paths == [D("price"), D("cat"), D("region_id")]
+    op.done()
+    query_amd.GpuFilterGroup(plan.filter_group_plan(None, keys, aggs, limit=10)).done()
+    bad_plans = [
+        plan.filter_group_plan(None, keys, aggs, order=[("avg(%s)" % D("price"), False)]),          # not an aggregate of the plan
+        plan.filter_group_plan(None, keys, aggs, order=[(aggs[0], False)], limit=5).replace('"limit": "5"', '"limit": "(1 + 1)"'),
+        '{"#operator":"Sequence","~children":[{"#operator":"Order","sort_terms":[{"expr":"count(*)"}]}]}',  # nothing to order
+    ]
+    assert "(1 + 1)" in bad_plans[1]
+    for bad in bad_plans:
+        with pytest.raises(query_amd.N1kError) as ei:
+            query_amd.GpuFilterGroup(bad)
+        assert ei.value.status == _ffi.UNSUPPORTED
+    # a FinalGroup that does not repeat the InitialGroup's lists is a malformed plan
+    mism = ok.replace('"#operator": "FinalGroup", "aggregates": ["sum', '"#operator": "FinalGroup", "aggregates": ["max')
+    with pytest.raises(query_amd.N1kError) as ei:
+        query_amd.GpuFilterGroup(mism)
+    assert ei.value.status == _ffi.INVALID

@@ -538,3 +538,32 @@ def test_count_distinct_dictionary_key_and_strings():
     ora = n1o.run(t, None, [], aggs, threads=2)
     gpu, stats = pu.run_gpu(t, None, [], aggs)
     pu.assert_same_groups(gpu, ora, aggs=aggs)
+
+
+ORDER_KEYS = [D("cat"), D("region_id")]
+ORDER_AGGS = sorted(["sum(%s)" % D("price"), "count(*)", "min(%s)" % D("price")])
+
+
+@pytest.mark.parametrize("order,limit,offset", [
+    ([("sum(%s)" % D("price"), True)], 100, None),                                    # config 5's tail
+    ([("count(*)", True), (D("cat"), False), (D("region_id"), False)], None, None),   # a total order: exact sequence
+    ([(D("cat"), False), (D("region_id"), True)], 20, 5),
+    ([("min(%s)" % D("price"), False), ("count(*)", True)], 7, 3),                    # mixed-type term (numbers, "n/a", NULL)
+    (None, 10, 2),                                                                    # Limit / Offset without Order
+    ([("sum(%s)" % D("price"), False)], 0, None),
+    ([("sum(%s)" % D("price"), True)], 100000, 10),                                   # limit beyond the groups
+], ids=["sum-desc-limit", "total-order", "keys-offset-limit", "mixed-types", "limit-only", "limit-0", "limit-beyond"])
+def test_order_by_limit_over_the_groups(order, limit, offset):
+    """BASELINE config 5's tail: ORDER BY <aggregate | key> [DESC] OFFSET o LIMIT k over the final groups
+    (execution/order.go:121-169, order_limit.go, offset.go, limit.go) inside the same handle."""
+    t = n1o.synth_table(90_000, k_cat=60)
+    ora = n1o.run(t, None, ORDER_KEYS, ORDER_AGGS, threads=2)
+    gpu, _ = pu.run_gpu(t, None, ORDER_KEYS, ORDER_AGGS, batches=2, order=order, limit=limit, offset=offset)
+    pu.assert_ordered_groups(gpu, ora, ORDER_KEYS, ORDER_AGGS, order, limit, offset)
+
+
+def test_order_by_rejects_terms_outside_the_groups():
+    pj = query_amd.plan.filter_group_plan(None, ORDER_KEYS, ORDER_AGGS, order=[(D("price"), False)])
+    with pytest.raises(query_amd.N1kError) as ei:
+        query_amd.GpuFilterGroup(pj)
+    assert ei.value.status == _ffi.UNSUPPORTED
