@@ -153,6 +153,7 @@ typedef struct n1k_stats {
     uint32_t distinct_path;  /* how the last finish built the DISTINCT sets: bit 0 per-group sets in global memory (two-word
                                 pairs), bit 1 radix partition + LDS sets (one-word members), bit 2 global one-word set (fallback) */
     uint32_t reserved0;
+    uint64_t topk_candidates; /* ORDER BY ... LIMIT: groups that left the device after the top-k filter (0 = filter not used) */
 } n1k_stats;
 
 typedef enum n1k_agg_mode {
@@ -229,7 +230,8 @@ n1k_status n1k_dict_get(const n1k_handle *h, uint32_t code, const char **ptr, si
  *         "fast" / "spec" / "wide" / "slabs" (0/1: kernel selection switches used by the ablation tests),
  *         "jit" (0 off, 1 = compile a specialised kernel for large batches of unregistered shapes, 2 = always),
  *         "jit_min_rows", "distinct_words" (0/1, before the first push: COUNT(DISTINCT) members that fit one word are
- *         de-duplicated by radix partition + LDS sets), "distinct_set_slots" / "distinct_levels" (LDS set size, forced number of partition passes: tests), "wide_values" (before the first push: how many distinct float / wide-integer group key
+ *         de-duplicated by radix partition + LDS sets), "topk_min_groups" (ORDER BY ... LIMIT: the device top-k filter runs from this many groups on, default 65536),
+ *         "distinct_set_slots" / "distinct_levels" (LDS set size, forced number of partition passes: tests), "wide_values" (before the first push: how many distinct float / wide-integer group key
  *         values the handle can code, default 1<<20; 0 = such keys are N1K_UNSUPPORTED_DATA)} */
 n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);
 

@@ -58,7 +58,8 @@ class Stats(C.Structure):
     _fields_ = [("rows_in", C.c_uint64), ("rows_selected", C.c_uint64), ("groups_out", C.c_uint64),
                 ("batches", C.c_uint64), ("device_ms", C.c_double), ("bytes_scanned", C.c_uint64),
                 ("agg_mode", C.c_uint32), ("spec_kernel", C.c_uint32),
-                ("wide_key_values", C.c_uint64), ("distinct_path", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("wide_key_values", C.c_uint64), ("distinct_path", C.c_uint32), ("reserved0", C.c_uint32),
+                ("topk_candidates", C.c_uint64)]
 
 
 class SynthSpec(C.Structure):

@@ -84,6 +84,10 @@ struct n1k_handle {
     uint64_t opt_jit_min_rows = 4u << 20;
     uint64_t opt_wide_values = 1u << 20;  // capacity of the wide key value tables (distinct big ints / floats)
     DevBuf<uint64_t> d_wide_int, d_wide_flt;
+    DevBuf<uint64_t> d_images;   // ORDER BY ... LIMIT: order images, candidate indices, select state, compacted records
+    DevBuf<uint32_t> d_cand;
+    DevBuf<char> d_topk, d_out2;
+    uint64_t opt_topk_min_groups = 65536;  // device top-k filter from this many groups on
     char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
     size_t pin_cap = 0;
     std::string jit_log;
@@ -394,6 +398,7 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
             lds_w += kWordsMinMax;
             glob_w += kWordsMinMax;
         }
+        if (pl.has_order) h->need_rank = true;  // order images of string values (top-k filter)
     }
     P.lds_words = lds_w;
     P.glob_words = glob_w ? glob_w : 1;
@@ -1094,6 +1099,10 @@ void n1k_destroy(n1k_handle* h) {
         h->d_wide_int.release();
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
+        h->d_images.release();
+        h->d_cand.release();
+        h->d_topk.release();
+        h->d_out2.release();
         for (auto& b : h->st_tags) b.release();
         for (auto& b : h->st_payload) b.release();
         for (auto& b : h->st_codes) b.release();
@@ -1190,6 +1199,8 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         uint32_t v = 64;
         while (v < (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 8192)) v <<= 1;
         h->opt_distinct_set_slots = v;
+    } else if (n == "topk_min_groups") {
+        h->opt_topk_min_groups = (uint64_t)std::max<int64_t>(value, 1);
     } else if (n == "distinct_levels") {
         h->opt_distinct_levels = (int32_t)std::min<int64_t>(std::max<int64_t>(value, -1), 2);
     } else if (n == "wide_values") {
@@ -1462,7 +1473,8 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     uint64_t spec_groups = 0;
     if (h->device_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
-        if (pl.has_group && !h->has_distinct && h->table.capacity) {
+        const bool topk_forced = pl.has_order && pl.limit >= 0 && h->opt_topk_min_groups < 4096;  // tests
+        if (pl.has_group && !h->has_distinct && h->table.capacity && !topk_forced) {
             spec_groups = std::min<uint64_t>(h->table.capacity, 4096);
             const size_t off_aggs = spec_groups * rec_keys, off_parts = off_aggs + spec_groups * rec_aggs,
                          off_rep = off_parts + spec_groups * rec_parts, total = off_rep + spec_groups * 8;
@@ -1553,22 +1565,55 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
         const size_t off_aggs = lay * rec_keys, off_parts = off_aggs + lay * rec_aggs, off_rep = off_parts + lay * rec_parts;
         const size_t total = off_rep + lay * 8;
         const char* hp = h->pin_out;
+        size_t o_aggs = off_aggs, o_parts = off_parts, o_rep = off_rep;  // layout of the host copy
+        h->stats.topk_candidates = 0;
         if (!spec_hit) {
             HIP_TRY(h, h->d_out.ensure(total + 16));
             char* d = h->d_out.p;
             HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
             HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
                                        (uint64_t*)(d + off_rep), h->d_counters.p + 2, ng, h->d_errp, h->stream));
-            h->out_host.resize(total);
-            HIP_TRY(h, hipMemcpyAsync(h->out_host.data(), d, total, hipMemcpyDeviceToHost, h->stream));
+            const uint64_t keep = pl.limit >= 0 ? (uint64_t)pl.offset + (uint64_t)pl.limit : ng;
+            size_t copy_bytes = total;
+            const char* src = d;
+            if (pl.has_order && pl.limit >= 0 && keep > 0 && keep < ng && ng >= h->opt_topk_min_groups && ng < (1ull << 32)) {
+                // ORDER BY ... LIMIT: only the groups that can be among the first offset+limit rows leave the device
+                const OrderTerm& t0 = pl.order[0];
+                HIP_TRY(h, h->d_images.ensure(ng));
+                HIP_TRY(h, h->d_cand.ensure(ng));
+                HIP_TRY(h, h->d_topk.ensure(topk_state_bytes()));
+                n1k_status rst = ensure_rank(h);
+                if (rst != N1K_OK) return rst;
+                const OutValue* vals = t0.key_index >= 0 ? (const OutValue*)d : (const OutValue*)(d + off_aggs);
+                HIP_TRY(h, launch_topk_select(h->prog, vals, t0.key_index >= 0 ? nk : na,
+                                              (uint32_t)(t0.key_index >= 0 ? t0.key_index : t0.agg_index), ng, t0.desc, keep,
+                                              h->d_images.p, h->d_topk.p, h->d_cand.p, h->stream));
+                unsigned long long ncand = 0;
+                HIP_TRY(h, hipMemcpyAsync(&ncand, h->d_topk.p + topk_ncand_offset(), sizeof ncand, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                o_aggs = ncand * rec_keys;
+                o_parts = o_aggs + ncand * rec_aggs;
+                o_rep = o_parts + ncand * rec_parts;
+                copy_bytes = o_rep + ncand * 8;
+                HIP_TRY(h, h->d_out2.ensure(copy_bytes + 16));
+                char* c = h->d_out2.p;
+                HIP_TRY(h, launch_topk_compact(h->d_cand.p, ncand, nk, na, (const OutValue*)d, (const OutValue*)(d + off_aggs),
+                                               (const OutPartial*)(d + off_parts), (const uint64_t*)(d + off_rep), (OutValue*)c,
+                                               (OutValue*)(c + o_aggs), (OutPartial*)(c + o_parts), (uint64_t*)(c + o_rep), h->stream));
+                src = c;
+                h->stats.topk_candidates = ncand;
+                ng = ncand;
+            }
+            h->out_host.resize(copy_bytes);
+            HIP_TRY(h, hipMemcpyAsync(h->out_host.data(), src, copy_bytes, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             hp = h->out_host.data();
         }
         h->r_keys.assign((const n1k_value*)hp, (const n1k_value*)hp + ng * nk);
-        h->r_aggs.assign((const n1k_value*)(hp + off_aggs), (const n1k_value*)(hp + off_aggs) + ng * na);
-        h->r_rep.assign((const uint64_t*)(hp + off_rep), (const uint64_t*)(hp + off_rep) + ng);
-        const OutPartial* parts = (const OutPartial*)(hp + off_parts);
+        h->r_aggs.assign((const n1k_value*)(hp + o_aggs), (const n1k_value*)(hp + o_aggs) + ng * na);
+        h->r_rep.assign((const uint64_t*)(hp + o_rep), (const uint64_t*)(hp + o_rep) + ng);
+        const OutPartial* parts = (const OutPartial*)(hp + o_parts);
         h->r_parts.resize(ng * na);
         for (size_t i = 0; i < ng * na; i++) {
             n1k_partial& p = h->r_parts[i];

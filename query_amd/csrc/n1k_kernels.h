@@ -46,6 +46,15 @@ hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTab
                             uint32_t grid, uint32_t block, uint32_t rows_per_lane, hipStream_t st);
 hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalTable& G, uint32_t nblocks,
                               unsigned long long* ngroups, hipStream_t st);
+// ORDER BY ... LIMIT over the finalised groups: order images of the first sort term, radix select of the keep-th image,
+// candidate indices (image <= threshold) and compaction of their records
+size_t topk_state_bytes();
+size_t topk_ncand_offset();
+hipError_t launch_topk_select(const Program& P, const OutValue* vals, uint32_t stride, uint32_t index, uint64_t n, bool desc,
+                              uint64_t keep, uint64_t* images, void* state, uint32_t* cand, hipStream_t st);
+hipError_t launch_topk_compact(const uint32_t* cand, uint64_t ncand, uint32_t nk, uint32_t na, const OutValue* keys,
+                               const OutValue* aggs, const OutPartial* parts, const uint64_t* rep, OutValue* okeys, OutValue* oaggs,
+                               OutPartial* oparts, uint64_t* orep, hipStream_t st);
 hipError_t launch_distinct_layout(const Program& P, const GlobalTable& G, const DistinctArgs& D, hipStream_t st);
 // COUNT(DISTINCT) over one-word members: one 256-bin partition pass (histogram, offsets, LDS-staged scatter) ...
 hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st);

@@ -567,3 +567,19 @@ def test_order_by_rejects_terms_outside_the_groups():
     with pytest.raises(query_amd.N1kError) as ei:
         query_amd.GpuFilterGroup(pj)
     assert ei.value.status == _ffi.UNSUPPORTED
+
+
+@pytest.mark.parametrize("order,limit,offset", [
+    ([("sum(%s)" % D("price"), True)], 100, None),
+    ([("count(*)", False), (D("cat"), True)], 30, 10),           # many ties on the first term: all of them are candidates
+    ([(D("cat"), True), (D("region_id"), False)], 50, 0),        # string term: images through the bytewise rank
+    ([("min(%s)" % D("price"), True)], 5, 1),                    # strings ("n/a") sort above numbers
+])
+def test_device_topk_filter_feeds_the_exact_order(order, limit, offset):
+    """execution/order_limit.go: with many groups only the candidates for the first offset+limit rows (order image of
+    the first term <= the selected threshold) are copied to the host; the final order is the exact collation."""
+    t = n1o.synth_table(150_000, k_cat=120)
+    ora = n1o.run(t, None, ORDER_KEYS, ORDER_AGGS, threads=2)
+    gpu, stats = pu.run_gpu(t, None, ORDER_KEYS, ORDER_AGGS, order=order, limit=limit, offset=offset, topk_min_groups=1)
+    pu.assert_ordered_groups(gpu, ora, ORDER_KEYS, ORDER_AGGS, order, limit, offset)
+    assert 0 < stats["topk_candidates"] < len(ora.keys)
