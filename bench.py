@@ -55,6 +55,12 @@ def workloads():
             "aggs": sorted(["count(distinct %s)" % D("user_id"), "avg(%s)" % D("price")]),
             "bytes_per_row": 22,
         },
+        "config5": {
+            "sql": "SELECT cat, region_id, SUM(price) s FROM default GROUP BY cat, region_id ORDER BY s DESC LIMIT 100",
+            "cond": None, "keys": [D("cat"), D("region_id")], "aggs": ["sum(%s)" % D("price")],
+            "order": [("sum(%s)" % D("price"), True)], "limit": 100,
+            "bytes_per_row": 22,
+        },
         "config5_keys": {
             "sql": "SELECT cat, region_id, SUM(price) FROM default GROUP BY cat, region_id",
             "cond": None, "keys": [D("cat"), D("region_id")], "aggs": ["sum(%s)" % D("price")],
@@ -165,7 +171,7 @@ def main():
     wl = workloads()[args.workload]
     total_rows = args.rows
     cols = DeviceColumns(args.rows, args.kcat, bool(args.zipf), 0, total_rows, local_rank)
-    pj = query_amd.plan.filter_group_plan(wl["cond"], wl["keys"], wl["aggs"])
+    pj = query_amd.plan.filter_group_plan(wl["cond"], wl["keys"], wl["aggs"], order=wl.get("order"), limit=wl.get("limit"))
     op = query_amd.GpuFilterGroup(pj, device=local_rank)
     for o in args.opt:
         k, v = o.split("=")

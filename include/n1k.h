@@ -160,7 +160,8 @@ typedef enum n1k_agg_mode {
     N1K_MODE_AUTO = 0,
     N1K_MODE_LDS_HASH = 1,  /* open-addressed LDS table per workgroup, global atomic merge */
     N1K_MODE_LDS_DIRECT = 2,/* perfect-hash LDS table (small dictionary-coded key domain), slab merge */
-    N1K_MODE_GLOBAL = 3     /* no LDS stage: global open-addressed table only (high cardinality) */
+    N1K_MODE_GLOBAL = 3,    /* no LDS stage: global open-addressed table only */
+    N1K_MODE_PARTITIONED = 4 /* high cardinality: rows -> records, radix partition on the key hash, per-bin LDS tables */
 } n1k_agg_mode;
 
 typedef struct n1k_handle n1k_handle;
@@ -225,12 +226,14 @@ n1k_status n1k_dict_get(const n1k_handle *h, uint32_t code, const char **ptr, si
 /* ---------------------------------------------------------------- options -- */
 
 /* name ∈ {"device" (ordinal) | "stream" (hipStream_t) | "rep_row" (0/1): before the first push;
- *         "max_groups" (group-table capacity bound, default 1<<22), "agg_mode" (n1k_agg_mode),
+ *         "max_groups" (group-table capacity bound, default 1<<26; the table itself grows with the rows pushed), "agg_mode" (n1k_agg_mode),
  *         "grid_blocks" / "block" / "rows_per_lane" / "lds_bytes" (launch tuning, 0 = auto),
  *         "fast" / "spec" / "wide" / "slabs" (0/1: kernel selection switches used by the ablation tests),
  *         "jit" (0 off, 1 = compile a specialised kernel for large batches of unregistered shapes, 2 = always),
  *         "jit_min_rows", "distinct_words" (0/1, before the first push: COUNT(DISTINCT) members that fit one word are
- *         de-duplicated by radix partition + LDS sets), "topk_min_groups" (ORDER BY ... LIMIT: the device top-k filter runs from this many groups on, default 65536),
+ *         de-duplicated by radix partition + LDS sets), "partition_min_rows" / "partition_probe_rows" / "partition_min_groups" / "partition_levels" (when AUTO takes the
+ *         partitioned high-cardinality path: batches of at least min_rows rows whose first probe_rows rows bring at
+ *         least min_groups new groups; forced number of passes), "topk_min_groups" (ORDER BY ... LIMIT: the device top-k filter runs from this many groups on, default 65536),
  *         "distinct_set_slots" / "distinct_levels" (LDS set size, forced number of partition passes: tests), "wide_values" (before the first push: how many distinct float / wide-integer group key
  *         values the handle can code, default 1<<20; 0 = such keys are N1K_UNSUPPORTED_DATA)} */
 n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);

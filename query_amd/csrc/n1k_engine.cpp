@@ -75,7 +75,7 @@ struct n1k_handle {
 
     // options
     int64_t opt_agg_mode = N1K_MODE_AUTO;
-    uint64_t opt_max_groups = 1ull << 22;
+    uint64_t opt_max_groups = 1ull << 26;
     uint32_t opt_grid_blocks = 0;
     uint32_t opt_rep_row = 0;
     uint32_t opt_lds_bytes = 64 * 1024;   // HASH mode: LDS table bytes per workgroup
@@ -84,6 +84,12 @@ struct n1k_handle {
     uint64_t opt_jit_min_rows = 4u << 20;
     uint64_t opt_wide_values = 1u << 20;  // capacity of the wide key value tables (distinct big ints / floats)
     DevBuf<uint64_t> d_wide_int, d_wide_flt;
+    // high-cardinality GROUP BY: record arrays (ping-pong per partition pass) and its tuning
+    DevBuf<uint64_t> d_rec_key[3], d_rec_pay[3][kRecOperands];
+    DevBuf<uint8_t> d_rec_tag[3][kRecOperands];
+    uint64_t opt_partition_min_rows = 8u << 20, opt_partition_probe_rows = 2u << 20, opt_partition_min_groups = 65536;
+    int32_t opt_partition_levels = -1;
+    uint64_t groups_seen = 0;
     DevBuf<uint64_t> d_images;   // ORDER BY ... LIMIT: order images, candidate indices, select state, compacted records
     DevBuf<uint32_t> d_cand;
     DevBuf<char> d_topk, d_out2;
@@ -993,6 +999,153 @@ n1k_status bind_columns(n1k_handle* h, const n1k_batch* b) {
     return N1K_OK;
 }
 
+// ---- high-cardinality GROUP BY: records -> radix partition -> per-bin LDS aggregation (n1k_kernels.hip) ---------
+
+struct PartitionPlan {
+    Operand src[kRecOperands];
+    uint32_t nsrc = 0;
+    uint32_t agg_src[kMaxAggs];
+};
+
+// the partitioned path carries up to kRecOperands distinct aggregate operands per record; no DISTINCT sets, no
+// representative rows
+bool partition_eligible(n1k_handle* h, PartitionPlan& pp) {
+    const Program& P = h->prog;
+    if (!h->plan.has_group || P.nkeys == 0 || h->has_distinct || P.want_rep_row) return false;
+    pp.nsrc = 0;
+    for (uint32_t a = 0; a < P.naggs; a++) {
+        pp.agg_src[a] = 0xFFFFFFFFu;
+        if (!P.aggs[a].has_operand) continue;
+        uint32_t e = 0;
+        for (; e < pp.nsrc; e++)
+            if (!memcmp(&pp.src[e], &P.aggs[a].src, sizeof(Operand))) break;
+        if (e == pp.nsrc) {
+            if (pp.nsrc == kRecOperands) return false;
+            pp.src[pp.nsrc++] = P.aggs[a].src;
+        }
+        pp.agg_src[a] = e;
+    }
+    return true;
+}
+
+// all keys dictionary coded and the key domain within reach of the workgroup tables: the scan kernels are at home
+bool small_key_domain(const n1k_handle* h) {
+    long double dom = 1;
+    for (uint32_t k = 0; k < h->prog.nkeys; k++) {
+        if (h->prog.keys[k].mode != KEYM_DICT) return false;
+        dom *= (long double)h->dict.size() + 2;
+    }
+    return dom <= 65536;
+}
+
+n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const PartitionPlan& pp, uint64_t groups_est) {
+    Program& P = h->prog;
+    const uint64_t n = b->nrows;
+    n1k_status st = ensure_table(h, n);
+    if (st != N1K_OK) return st;
+    // LDS table of the per-bin aggregation, and from it the number of partition passes
+    uint32_t slots = (uint32_t)std::min<uint64_t>((64u * 1024u) / (P.lds_words * 8), 1u << 13);
+    if (slots < 64) return run_group_batch(h, b);
+    const uint64_t per_bin = slots / 4;  // groups a bin should hold on average
+    const uint32_t levels = h->opt_partition_levels >= 0 ? (uint32_t)h->opt_partition_levels
+                                                         : (groups_est <= per_bin ? 0u : (groups_est <= 256 * per_bin ? 1u : 2u));
+    for (uint32_t i = 0; i <= std::min(levels, 2u); i++) {  // one set of record arrays per pass, plus the projection's
+        HIP_TRY(h, h->d_rec_key[i].ensure(n));
+        for (uint32_t e = 0; e < pp.nsrc; e++) {
+            HIP_TRY(h, h->d_rec_pay[i][e].ensure(n));
+            HIP_TRY(h, h->d_rec_tag[i][e].ensure(n));
+        }
+    }
+    HIP_TRY(h, h->d_seg[0].ensure(2));
+    HIP_TRY(h, h->d_seg[1].ensure(257));
+    HIP_TRY(h, h->d_seg[2].ensure(65537));
+    HIP_TRY(h, h->d_hist.ensure(65536));
+    HIP_TRY(h, h->d_cursor.ensure(65536));
+    auto rec = [&](int i) {
+        RecArrays r{};
+        r.key = h->d_rec_key[i].p;
+        for (uint32_t e = 0; e < pp.nsrc; e++) {
+            r.pay[e] = h->d_rec_pay[i][e].p;
+            r.tag[e] = h->d_rec_tag[i][e].p;
+        }
+        return r;
+    };
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    if (e0) (void)hipEventRecord(e0, h->stream);
+    // (1) Filter + key + operands -> records
+    unsigned long long* d_nrec = h->d_counters.p + 21;
+    HIP_TRY(h, hipMemsetAsync(d_nrec, 0, sizeof(unsigned long long), h->stream));
+    ProjectArgs A{};
+    A.nrows = n;
+    A.capacity = n;
+    A.out = rec(0);
+    A.cursor = d_nrec;
+    for (uint32_t e = 0; e < pp.nsrc; e++) A.src[e] = pp.src[e];
+    A.nsrc = pp.nsrc;
+    A.err_flags = h->d_errp;
+    {
+        uint64_t tiles = (n + 2047) / 2048;
+        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 4, tiles));
+        HIP_TRY(h, launch_project_records(P, A, grid, h->stream));
+    }
+    // the number of records (rows that passed the Filter) sizes the passes: one small read-back
+    unsigned long long nrec = 0;
+    HIP_TRY(h, hipMemcpyAsync(&nrec, d_nrec, sizeof nrec, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    nrec = std::min<unsigned long long>(nrec, n);
+    HIP_TRY(h, launch_add_counter(h->d_counters.p + 0, nrec, h->stream));  // rows_selected
+    if (nrec) {
+        const uint64_t seg0[2] = {0, nrec};
+        HIP_TRY(h, hipMemcpyAsync(h->d_seg[0].p, seg0, sizeof seg0, hipMemcpyHostToDevice, h->stream));
+        const uint64_t* bin_start = h->d_seg[0].p;
+        uint32_t nbins = 1;
+        int cur = 0;
+        for (uint32_t l = 0; l < levels; l++) {
+            RadixArgs R{};
+            RecArrays src = rec(cur), dst = rec(cur + 1);
+            R.src = src.key;
+            R.dst = dst.key;
+            R.nextra = pp.nsrc;
+            for (uint32_t e = 0; e < pp.nsrc; e++) {
+                R.src_pay[e] = src.pay[e];
+                R.dst_pay[e] = dst.pay[e];
+                R.src_tag[e] = src.tag[e];
+                R.dst_tag[e] = dst.tag[e];
+            }
+            R.seg_start = h->d_seg[l].p;
+            R.nseg = nbins;
+            R.shift = 56 - 8 * l;
+            R.hist = h->d_hist.p;
+            R.cursor = h->d_cursor.p;
+            R.out_start = h->d_seg[l + 1].p;
+            uint64_t tiles = (nrec + 8191) / 8192;
+            uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / nbins + (nbins > 1 ? 8 : 0), tiles));
+            HIP_TRY(h, launch_radix_pass(R, slices, h->stream));
+            bin_start = R.out_start;
+            nbins *= 256;
+            cur++;
+        }
+        BinAggArgs B{};
+        B.in = rec(cur);
+        B.bin_start = bin_start;
+        B.nbins = nbins;
+        B.nsrc = pp.nsrc;
+        B.lds_slots = slots;
+        B.lds_max_fill = std::max(1u, slots * 5 / 8);
+        for (uint32_t a = 0; a < kMaxAggs; a++) B.agg_src[a] = a < P.naggs ? pp.agg_src[a] : 0xFFFFFFFFu;
+        B.err_flags = h->d_errp;
+        const size_t shmem = (size_t)slots * P.lds_words * 8 + 1024;
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
+        uint32_t grid = (uint32_t)std::min<uint64_t>(nbins, (uint64_t)h->num_cus * per_cu);
+        HIP_TRY(h, launch_agg_bins(P, B, h->table, h->d_counters.p + 1, grid, h->stream));
+    }
+    if (e1) (void)hipEventRecord(e1, h->stream);
+    h->events.emplace_back(e0, e1);
+    h->stats.agg_mode = N1K_MODE_PARTITIONED;
+    h->stats.spec_kernel = 0;
+    return N1K_OK;
+}
+
 n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
     n1k_status st = ensure_device(h);
@@ -1003,15 +1156,64 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
         st = fix_layout(h, b);
         if (st != N1K_OK) return st;
     }
-    st = bind_columns(h, b);
-    if (st != N1K_OK) return st;
-    st = ensure_rank(h);
-    if (st != N1K_OK) return st;
-    if (b->nrows) {
-        st = h->plan.has_group ? run_group_batch(h, b) : run_filter_batch(h, b);
-        if (st != N1K_OK) return st;
+    // High-cardinality GROUP BY: beyond a few ten thousand groups the scan's LDS stage absorbs nothing and every row
+    // costs atomics on a table in HBM.  Whether a batch is like that is learnt from the data: the first rows of a
+    // large batch run through the scan kernels; if they bring many new groups, the rest is partitioned (below).
+    PartitionPlan pp;
+    const bool can_partition = h->plan.has_group && partition_eligible(h, pp);
+    uint64_t head = b->nrows;
+    bool decide = false;
+    if (can_partition && h->opt_agg_mode == N1K_MODE_PARTITIONED) head = 0;
+    else if (can_partition && h->opt_agg_mode == N1K_MODE_AUTO && b->nrows >= h->opt_partition_min_rows && !small_key_domain(h)) {
+        head = std::min<uint64_t>(b->nrows, h->opt_partition_probe_rows);
+        decide = true;
     }
-    h->row_base += b->nrows;
+    auto view = [&](uint64_t off, uint64_t n, std::vector<n1k_col>& cols, n1k_batch& v) {
+        cols.assign(b->cols, b->cols + b->ncols);
+        for (auto& c : cols) {
+            if (c.tags) c.tags += off;
+            if (c.payload) c.payload += off;
+            if (c.codes) c.codes += off;
+        }
+        v.nrows = n;
+        v.ncols = b->ncols;
+        v.cols = cols.data();
+    };
+    std::vector<n1k_col> cols;
+    n1k_batch v{};
+    if (head || !b->nrows) {
+        view(0, head, cols, v);
+        st = bind_columns(h, &v);
+        if (st != N1K_OK) return st;
+        st = ensure_rank(h);
+        if (st != N1K_OK) return st;
+        if (v.nrows) {
+            st = h->plan.has_group ? run_group_batch(h, &v) : run_filter_batch(h, &v);
+            if (st != N1K_OK) return st;
+        }
+        h->row_base += v.nrows;
+    }
+    if (head < b->nrows) {
+        uint64_t groups_est = b->nrows - head;
+        bool partition = !decide;
+        if (decide) {
+            unsigned long long ng = 0;
+            HIP_TRY(h, hipMemcpyAsync(&ng, h->d_counters.p + 1, sizeof ng, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            const uint64_t fresh = ng > h->groups_seen ? ng - h->groups_seen : 0;
+            h->groups_seen = ng;
+            partition = fresh >= h->opt_partition_min_groups;
+            groups_est = std::min<uint64_t>(groups_est, std::max<uint64_t>(1, fresh) * ((b->nrows - head + head - 1) / head));
+        }
+        view(head, b->nrows - head, cols, v);
+        st = bind_columns(h, &v);
+        if (st != N1K_OK) return st;
+        st = ensure_rank(h);
+        if (st != N1K_OK) return st;
+        st = partition ? run_group_partitioned(h, &v, pp, groups_est) : run_group_batch(h, &v);
+        if (st != N1K_OK) return st;
+        h->row_base += v.nrows;
+    }
     h->stats.rows_in += b->nrows;
     h->stats.batches += 1;
     h->stats.bytes_scanned += b->nrows * batch_bytes_per_row(h);
@@ -1099,6 +1301,13 @@ void n1k_destroy(n1k_handle* h) {
         h->d_wide_int.release();
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
+        for (int i = 0; i < 3; i++) {
+            h->d_rec_key[i].release();
+            for (uint32_t e = 0; e < kRecOperands; e++) {
+                h->d_rec_pay[i][e].release();
+                h->d_rec_tag[i][e].release();
+            }
+        }
         h->d_images.release();
         h->d_cand.release();
         h->d_topk.release();
@@ -1134,6 +1343,7 @@ n1k_status n1k_reset(n1k_handle* h) {
             drain_events(h);
         }
         h->stats.device_ms = 0;
+        h->groups_seen = 0;
         // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
@@ -1199,6 +1409,14 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         uint32_t v = 64;
         while (v < (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 8192)) v <<= 1;
         h->opt_distinct_set_slots = v;
+    } else if (n == "partition_min_rows") {
+        h->opt_partition_min_rows = (uint64_t)std::max<int64_t>(value, 1);
+    } else if (n == "partition_probe_rows") {
+        h->opt_partition_probe_rows = (uint64_t)std::max<int64_t>(value, 1);
+    } else if (n == "partition_min_groups") {
+        h->opt_partition_min_groups = (uint64_t)std::max<int64_t>(value, 1);
+    } else if (n == "partition_levels") {
+        h->opt_partition_levels = (int32_t)std::min<int64_t>(std::max<int64_t>(value, -1), 2);
     } else if (n == "topk_min_groups") {
         h->opt_topk_min_groups = (uint64_t)std::max<int64_t>(value, 1);
     } else if (n == "distinct_levels") {
@@ -1474,7 +1692,8 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     if (h->device_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
         const bool topk_forced = pl.has_order && pl.limit >= 0 && h->opt_topk_min_groups < 4096;  // tests
-        if (pl.has_group && !h->has_distinct && h->table.capacity && !topk_forced) {
+        // (a table of millions of slots is not worth scanning twice: the sized pass alone then)
+        if (pl.has_group && !h->has_distinct && h->table.capacity && h->table.capacity <= (1u << 20) && !topk_forced) {
             spec_groups = std::min<uint64_t>(h->table.capacity, 4096);
             const size_t off_aggs = spec_groups * rec_keys, off_parts = off_aggs + spec_groups * rec_aggs,
                          off_rep = off_parts + spec_groups * rec_parts, total = off_rep + spec_groups * 8;

@@ -48,6 +48,11 @@ hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalT
                               unsigned long long* ngroups, hipStream_t st);
 // ORDER BY ... LIMIT over the finalised groups: order images of the first sort term, radix select of the keep-th image,
 // candidate indices (image <= threshold) and compaction of their records
+// high-cardinality GROUP BY: rows -> records (key + operands), [radix passes], per-bin LDS aggregation
+hipError_t launch_add_counter(unsigned long long* p, unsigned long long v, hipStream_t st);
+hipError_t launch_project_records(const Program& P, const ProjectArgs& A, uint32_t grid, hipStream_t st);
+hipError_t launch_agg_bins(const Program& P, const BinAggArgs& A, const GlobalTable& G, unsigned long long* ngroups, uint32_t grid,
+                           hipStream_t st);
 size_t topk_state_bytes();
 size_t topk_ncand_offset();
 hipError_t launch_topk_select(const Program& P, const OutValue* vals, uint32_t stride, uint32_t index, uint64_t n, bool desc,

@@ -462,6 +462,7 @@ __global__ __launch_bounds__(256) void radix_offsets_kernel(const RadixArgs A) {
 
 __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixArgs A) {
     __shared__ uint64_t stage[kRadixTile];
+    __shared__ uint8_t sbin[kRadixTile];  // bin of every staged position (records only)
     __shared__ uint32_t cnt[256], pre[256];
     __shared__ unsigned long long gbase[256];
     const uint32_t tid = threadIdx.x, s = blockIdx.y;
@@ -508,8 +509,31 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
             const uint64_t x = stage[p];
             const uint32_t b = radix_bin(x, A.shift);
             A.dst[gbase[b] + (p - pre[b])] = x;
+            if (A.nextra) sbin[p] = (uint8_t)b;
         }
         __syncthreads();
+        // records: the other arrays follow the same permutation, one at a time through the same staging buffer
+        for (uint32_t e = 0; e < A.nextra; e++) {
+#pragma unroll
+            for (int j = 0; j < kRadixPer; j++)
+                if (rk[j] != 0xFFFFFFFFu) stage[pre[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = A.src_pay[e][tile + (uint32_t)j * kRadixBlock + tid];
+            __syncthreads();
+            for (uint32_t p = tid; p < n; p += kRadixBlock) {
+                const uint32_t b = sbin[p];
+                A.dst_pay[e][gbase[b] + (p - pre[b])] = stage[p];
+            }
+            __syncthreads();
+            uint8_t* stage8 = (uint8_t*)stage;
+#pragma unroll
+            for (int j = 0; j < kRadixPer; j++)
+                if (rk[j] != 0xFFFFFFFFu) stage8[pre[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = A.src_tag[e][tile + (uint32_t)j * kRadixBlock + tid];
+            __syncthreads();
+            for (uint32_t p = tid; p < n; p += kRadixBlock) {
+                const uint32_t b = sbin[p];
+                A.dst_tag[e][gbase[b] + (p - pre[b])] = stage8[p];
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1580,27 +1604,194 @@ N1K_DEV void finalize_agg(const Program& P, const AggSpec& ag, const uint64_t* g
     *part = pt;
 }
 
-__global__ void finalize_kernel(const Program P, const GlobalTable G, OutValue* out_keys, OutValue* out_aggs,
-                                OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count,
-                                uint64_t max_out, uint32_t* err_flags) {
-    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= G.capacity) return;
-    uint64_t key = G.keys[s];
-    if (key == kEmptyKey) return;
-    unsigned long long idx = atomicAdd(out_count, 1ull);
-    if (idx >= max_out) return;
-    for (uint32_t k = 0; k < P.nkeys; k++) {
-        const KeySpec& ks = P.keys[k];
-        uint64_t field = ks.bits >= 64 ? key : ((key >> ks.shift) & ((1ull << ks.bits) - 1ull));
-        uint32_t tag;
-        uint64_t p;
-        unpack_key_field(P, ks.mode, field, tag, p);
-        put_value(&out_keys[idx * P.nkeys + k], tag, p);
+// Output positions are handed out per workgroup CHUNK (count the chunk's groups, one atomic, then ranks inside the
+// chunk): one same-address atomic per group cost 24 ms for 6.4 M groups.
+constexpr uint32_t kFinalizeChunk = 16384;  // table slots per workgroup
+__global__ __launch_bounds__(256) void finalize_kernel(const Program P, const GlobalTable G, OutValue* out_keys, OutValue* out_aggs,
+                                                       OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count,
+                                                       uint64_t max_out, uint32_t* err_flags) {
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ unsigned long long chunk_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * kFinalizeChunk;
+    const uint64_t hi = lo + kFinalizeChunk < G.capacity ? lo + kFinalizeChunk : G.capacity;
+    // pass 1: groups in the chunk
+    uint32_t mine = 0;
+    for (uint64_t s = lo + tid; s < hi; s += 256) mine += G.keys[s] != kEmptyKey ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if (lane == 0) wave_cnt[wave] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        chunk_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;
     }
-    const uint64_t* g = &G.acc[(size_t)s * P.glob_words];
-    for (uint32_t a = 0; a < P.naggs; a++)
-        finalize_agg(P, P.aggs[a], g, &out_aggs[idx * P.naggs + a], &out_parts[idx * P.naggs + a], err_flags);
-    if (out_rep) out_rep[idx] = G.rep_row ? G.rep_row[s] : ~0ull;
+    __syncthreads();
+    unsigned long long next = chunk_base;
+    // pass 2: the same slots in the same order; positions from ballots over each step of 256 slots
+    for (uint64_t s0 = lo; s0 < hi; s0 += 256) {
+        const uint64_t s = s0 + tid;
+        const uint64_t key = s < hi ? G.keys[s] : kEmptyKey;
+        const bool used = key != kEmptyKey;
+        const unsigned long long m = __ballot(used);
+        __syncthreads();
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++) before += wave_cnt[w];
+        const uint32_t step_total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        const unsigned long long idx = next + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        next += step_total;
+        if (!used || idx >= max_out) continue;
+        for (uint32_t k = 0; k < P.nkeys; k++) {
+            const KeySpec& ks = P.keys[k];
+            uint64_t field = ks.bits >= 64 ? key : ((key >> ks.shift) & ((1ull << ks.bits) - 1ull));
+            uint32_t tag;
+            uint64_t p;
+            unpack_key_field(P, ks.mode, field, tag, p);
+            put_value(&out_keys[idx * P.nkeys + k], tag, p);
+        }
+        const uint64_t* g = &G.acc[(size_t)s * P.glob_words];
+        for (uint32_t a = 0; a < P.naggs; a++)
+            finalize_agg(P, P.aggs[a], g, &out_aggs[idx * P.naggs + a], &out_parts[idx * P.naggs + a], err_flags);
+        if (out_rep) out_rep[idx] = G.rep_row ? G.rep_row[s] : ~0ull;
+    }
+}
+
+// ------------------------------------------------------------------ high-cardinality GROUP BY: partition, then LDS
+//
+// With millions of groups the workgroup tables stop absorbing anything and every row costs 3-5 atomics on a table in
+// HBM (≈ 20 G/s: config 5's keys ran at 28 ms per 100 M rows).  Instead: (1) Filter + group key + the aggregates'
+// operands are projected to records; (2) the records are radix partitioned on bits of mix64(key) (radix_*_kernel,
+// the record arrays follow the key) until a bin holds about a thousand groups; (3) one workgroup per bin runs
+// InitialGroup in an LDS table and hands the bin's groups to the global table once (≙ IntermediateGroup).  All rows
+// of a key meet in one bin, so a group costs a handful of global atomics instead of its rows.
+template <int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void project_records_kernel(const Program P, const ProjectArgs A) {
+    __shared__ uint32_t wave_cnt[BLOCK / 64];
+    __shared__ unsigned long long tile_base;
+    const uint32_t tid = threadIdx.x;
+    uint32_t unsupported = 0, unpackable = 0;
+    const uint64_t tile_rows = (uint64_t)BLOCK * R;
+    const uint64_t ntiles = (A.nrows + tile_rows - 1) / tile_rows;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t row[R];
+        bool valid[R], pass[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            row[j] = tile * tile_rows + (uint64_t)j * BLOCK + tid;
+            valid[j] = row[j] < A.nrows;
+        }
+        eval_predicate<R>(P, row, valid, pass, unsupported);
+        uint64_t key[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) key[j] = 0;
+        for (uint32_t k = 0; k < P.nkeys; k++) {
+            const KeySpec& ks = P.keys[k];
+            uint32_t kt[R];
+            uint64_t kp[R];
+            load_operand<R>(P, ks.src, row, pass, kt, kp);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                uint64_t f = 0, canon = 0;
+                if (pass[j] && !pack_key_field(P, ks, kt[j], kp[j], f, canon)) {
+                    unpackable = 1;
+                    pass[j] = false;
+                }
+                key[j] |= f << ks.shift;
+            }
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++) mine += pass[j] ? 1u : 0u;
+        unsigned long long pos = tile_reserve<BLOCK>(mine, A.cursor, wave_cnt, &tile_base, tid);
+        unsigned long long q = pos;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (pass[j] && q < A.capacity) A.out.key[q++] = key[j];
+        for (uint32_t e = 0; e < A.nsrc; e++) {
+            uint32_t vt[R];
+            uint64_t vp[R];
+            load_operand<R>(P, A.src[e], row, pass, vt, vp);
+            q = pos;
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                if (pass[j] && q < A.capacity) {
+                    A.out.pay[e][q] = vp[j];
+                    A.out.tag[e][q] = (uint8_t)vt[j];
+                    q++;
+                }
+        }
+        if (pos + mine > A.capacity) atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+        __syncthreads();
+    }
+    if (unsupported) atomicOr(A.err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
+    if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const BinAggArgs A, const GlobalTable G,
+                                                        unsigned long long* ngroups) {
+    extern __shared__ uint64_t lds[];
+    __shared__ uint32_t lds_fill;
+    const uint32_t S = A.lds_slots, tid = threadIdx.x;
+    uint32_t new_groups = 0;
+    for (uint32_t bin = blockIdx.x; bin < A.nbins; bin += gridDim.x) {
+        const uint64_t lo = A.bin_start[bin], hi = A.bin_start[bin + 1];
+        if (lo == hi) continue;
+        __syncthreads();
+        lds_table_init<BLOCK>(P, lds, S, tid);
+        if (tid == 0) lds_fill = 0;
+        __syncthreads();
+        // InitialGroup over the bin's records (execution/group_initial.go:56-100)
+        for (uint64_t i = lo + tid; i < hi; i += BLOCK) {
+            const uint64_t key = A.in.key[i];
+            uint32_t vt[kRecOperands];
+            uint64_t vp[kRecOperands];
+            for (uint32_t e = 0; e < A.nsrc; e++) {
+                vt[e] = A.in.tag[e][i];
+                vp[e] = A.in.pay[e][i];
+            }
+            const int slot = lds_find_or_insert(lds, S, key, &lds_fill, A.lds_max_fill);
+            long long grow = -1;
+            if (slot < 0) {  // more groups in the bin than the LDS table takes: straight to the global table
+                grow = global_find_or_insert(G, key, A.err_flags, ngroups);
+                if (grow < 0) continue;
+            }
+            for (uint32_t a = 0; a < P.naggs; a++) {
+                const AggSpec& ag = P.aggs[a];
+                const uint32_t e = A.agg_src[a];
+                const uint32_t t = e < kRecOperands ? vt[e] : (uint32_t)T_NULL;
+                const uint64_t p = e < kRecOperands ? vp[e] : 0ull;
+                if (slot >= 0) {
+                    if (!acc_lds(P, ag, lds, S, (uint32_t)slot, t, p)) {
+                        if (grow < 0) grow = global_find_or_insert(G, key, A.err_flags, ngroups);
+                        if (grow >= 0) acc_global(P, ag, &G.acc[(size_t)grow * P.glob_words], t, p);
+                    }
+                } else
+                    acc_global(P, ag, &G.acc[(size_t)grow * P.glob_words], t, p);
+            }
+        }
+        __syncthreads();
+        // the bin's groups go to the global table once (≙ IntermediateGroup, execution/group_intermediate.go:56-104)
+        for (uint32_t s = tid; s < S; s += BLOCK) {
+            const uint64_t key = lds[s];
+            if (key == kEmptyKey) continue;
+            bool fresh = false;
+            long long g = global_find_or_insert_quiet(G, key, A.err_flags, fresh);
+            if (g < 0) continue;
+            new_groups += fresh ? 1u : 0u;
+            merge_slot(P, lds, S, s, &G.acc[(size_t)g * P.glob_words]);
+        }
+    }
+    // new groups: one atomic on the counter per workgroup (millions of same-address atomics cost ~4 ns each)
+    __shared__ uint32_t block_new;
+    __syncthreads();
+    if (tid == 0) block_new = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) new_groups += __shfl_down(new_groups, off, 64);
+    if ((tid & 63) == 0 && new_groups) atomicAdd(&block_new, new_groups);
+    __syncthreads();
+    if (tid == 0 && block_new) atomicAdd(ngroups, (unsigned long long)block_new);
 }
 
 // ------------------------------------------------------------------ ORDER BY ... LIMIT k over the groups: top-k filter
@@ -1930,6 +2121,27 @@ hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalT
     return hipGetLastError();
 }
 
+__global__ void add_counter_kernel(unsigned long long* p, unsigned long long v) { *p += v; }
+
+hipError_t launch_add_counter(unsigned long long* p, unsigned long long v, hipStream_t st) {
+    hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, st, p, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_records(const Program& P, const ProjectArgs& A, uint32_t grid, hipStream_t st) {
+    hipLaunchKernelGGL((project_records_kernel<4, 512>), dim3(grid), dim3(512), 0, st, P, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_agg_bins(const Program& P, const BinAggArgs& A, const GlobalTable& G, unsigned long long* ngroups, uint32_t grid,
+                           hipStream_t st) {
+    auto k = agg_bins_kernel<512>;
+    size_t shmem = (size_t)A.lds_slots * P.lds_words * 8;
+    if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), shmem, st, P, A, G, ngroups);
+    return hipGetLastError();
+}
+
 size_t topk_state_bytes() { return sizeof(TopkState); }
 
 hipError_t launch_topk_select(const Program& P, const OutValue* vals, uint32_t stride, uint32_t index, uint64_t n, bool desc,
@@ -2035,7 +2247,7 @@ hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, 
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,
                            OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count, uint64_t max_out,
                            uint32_t* err_flags, hipStream_t st) {
-    uint32_t blocks = (uint32_t)((G.capacity + 255) / 256);
+    uint32_t blocks = (uint32_t)((G.capacity + kFinalizeChunk - 1) / kFinalizeChunk);
     hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, P, G, out_keys, out_aggs, out_parts, out_rep,
                        out_count, max_out, err_flags);
     return hipGetLastError();

@@ -70,7 +70,32 @@ N1K_DEV long long global_find_or_insert(const GlobalTable& G, uint64_t key, uint
         if (cur == kEmptyKey) {
             unsigned long long old = atomicCAS((unsigned long long*)&G.keys[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
             if (old == kEmptyKey) {
-                atomicAdd(ngroups, 1ull);
+                // one atomic on the group counter per wave, not per new group: the lanes that are here together count
+                // themselves (millions of same-address atomics cost ~10 ns each: 6.4 M new groups were 40+ ms)
+                const unsigned long long active = __ballot(1);
+                if (__builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u)) == 0u)
+                    atomicAdd(ngroups, (unsigned long long)__popcll(active));
+                return (long long)h;
+            }
+            if (old == key) return (long long)h;
+        }
+        h = (h + 1) & mask;
+    }
+    atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+    return -1;
+}
+
+// the same without touching the group counter: the caller adds up `fresh` and reports once per workgroup
+N1K_DEV long long global_find_or_insert_quiet(const GlobalTable& G, uint64_t key, uint32_t* err_flags, bool& fresh) {
+    uint64_t mask = G.capacity - 1;
+    uint64_t h = mix64(key) & mask;
+    for (int probe = 0; probe < 8192; probe++) {
+        unsigned long long cur = __hip_atomic_load((unsigned long long*)&G.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return (long long)h;
+        if (cur == kEmptyKey) {
+            unsigned long long old = atomicCAS((unsigned long long*)&G.keys[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
+            if (old == kEmptyKey) {
+                fresh = true;
                 return (long long)h;
             }
             if (old == key) return (long long)h;

@@ -209,6 +209,39 @@ struct RadixArgs {
     unsigned long long* hist;   // nseg * 256 counters
     unsigned long long* cursor; // nseg * 256 write cursors (absolute positions in dst)
     uint64_t* out_start;        // nseg * 256 + 1 entries: starts of the finer segments
+    // records: arrays that travel with the word (same permutation), see RecArrays
+    uint32_t nextra, pad;
+    const uint64_t* src_pay[2];
+    uint64_t* dst_pay[2];
+    const uint8_t* src_tag[2];
+    uint8_t* dst_tag[2];
+};
+
+// High-cardinality GROUP BY: rows are projected to records (packed key + the aggregates' operands), radix
+// partitioned by mix64(key) with the same passes as the COUNT(DISTINCT) words, and aggregated bin by bin in LDS.
+constexpr uint32_t kRecOperands = 2;  // distinct operand sources a record carries
+struct RecArrays {
+    uint64_t* key;
+    uint64_t* pay[kRecOperands];
+    uint8_t* tag[kRecOperands];
+};
+struct ProjectArgs {
+    uint64_t nrows;
+    uint64_t capacity;             // records the output arrays take
+    RecArrays out;
+    unsigned long long* cursor;    // records written
+    Operand src[kRecOperands];
+    uint32_t nsrc, pad;
+    uint32_t* err_flags;
+};
+struct BinAggArgs {
+    RecArrays in;
+    const uint64_t* bin_start;  // nbins + 1
+    uint32_t nbins;
+    uint32_t nsrc;
+    uint32_t lds_slots, lds_max_fill;
+    uint32_t agg_src[kMaxAggs];  // operand slot of every aggregate, 0xFFFFFFFF = none (count(*))
+    uint32_t* err_flags;
 };
 
 struct DedupeArgs {

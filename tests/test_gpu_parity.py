@@ -583,3 +583,40 @@ def test_device_topk_filter_feeds_the_exact_order(order, limit, offset):
     gpu, stats = pu.run_gpu(t, None, ORDER_KEYS, ORDER_AGGS, order=order, limit=limit, offset=offset, topk_min_groups=1)
     pu.assert_ordered_groups(gpu, ora, ORDER_KEYS, ORDER_AGGS, order, limit, offset)
     assert 0 < stats["topk_candidates"] < len(ora.keys)
+
+
+PART_AGGS = sorted(["sum(%s)" % D("price"), "count(*)", "min(%s)" % D("price"), "avg(%s)" % D("price"),
+                    "max(%s)" % D("region_id"), "countn(%s)" % D("price")])
+
+
+@pytest.mark.parametrize("keys,cond,levels", [
+    ([D("user_id")], None, -1),                                     # ~18 k groups of 200 k rows
+    ([D("user_id")], "(50 < %s)" % D("price"), 0),                  # no partition pass: one bin, LDS overflow -> global rows
+    ([D("cat"), D("region_id")], None, 1),
+    ([D("user_id"), D("region_id")], "(%s is valued)" % D("price"), 2),  # two passes, 65 536 bins
+    ([D("price")], None, 1),                                        # float keys: wide-value codes inside the records
+], ids=["auto-levels", "no-pass", "one-pass", "two-pass", "float-keys"])
+def test_partitioned_high_cardinality_group_by(keys, cond, levels):
+    """agg_mode 4: rows -> records -> radix partition on the key hash -> per-bin LDS tables; same groups and
+    aggregates as the reference whatever the number of passes (execution/group_initial.go, group_intermediate.go)."""
+    t = n1o.synth_table(200_000, k_cat=700, total_rows=200_000)
+    ora = n1o.run(t, cond, keys, PART_AGGS, threads=2)
+    gpu, stats = pu.run_gpu(t, cond, keys, PART_AGGS, batches=2, agg_mode=4, partition_levels=levels)
+    pu.assert_same_groups(gpu, ora, aggs=PART_AGGS)
+    assert stats["agg_mode"] == 4 and stats["rows_selected"] == ora.rows_passed
+
+
+def test_partitioned_path_is_chosen_from_the_data():
+    """AUTO: the first rows of a large batch run through the scan kernels; many new groups there send the rest of
+    the batch through the partitioned path, few keep the scan kernels."""
+    t = n1o.synth_table(300_000, k_cat=50, total_rows=3_000_000)
+    aggs = sorted(["sum(%s)" % D("price"), "count(*)"])
+    opts = dict(partition_min_rows=100_000, partition_probe_rows=50_000, partition_min_groups=10_000)
+    ora = n1o.run(t, None, [D("user_id")], aggs, threads=2)          # ~190 k groups
+    gpu, stats = pu.run_gpu(t, None, [D("user_id")], aggs, **opts)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert stats["agg_mode"] == 4
+    ora = n1o.run(t, None, [D("region_id")], aggs, threads=2)        # 64 groups
+    gpu, stats = pu.run_gpu(t, None, [D("region_id")], aggs, **opts)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert stats["agg_mode"] != 4
