@@ -189,7 +189,11 @@ class GpuFilterGroup:
             if not count or not ptr:
                 return np.zeros(0, dtype=dt)
             # one memcpy out of the handle-owned result (valid until the next finish/reset/destroy)
-            return np.frombuffer(bytearray(C.string_at(ptr, count * dt.itemsize)), dtype=dt)
+            nbytes = count * dt.itemsize
+            if nbytes > (1 << 20):  # big results (Filter-only ordinals): view + a single copy
+                raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                return raw.view(dt).copy()
+            return np.frombuffer(bytearray(C.string_at(ptr, nbytes)), dtype=dt)
 
         out = {"ngroups": ng, "nkeys": nk, "naggs": na,
                "keys": arr(res.keys, ng * nk, self._VALUE_DT).reshape(ng, nk) if nk else np.zeros((ng, 0), self._VALUE_DT),
