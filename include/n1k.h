@@ -241,6 +241,24 @@ n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);
 /* ----------------------------------------------------------------- data ---- */
 
 /*
+ * Raw documents -> the plan's leaf columns.
+ * Replaces: the per-row, per-field leaf accesses of the operators over a parsedValue — Field.Apply
+ *           (expression/nav_field.go:134-160) -> parsedValue.Field (value/parsed.go:159-207: go_json FirstFind of the
+ *           field in the raw bytes) -> value.NewValue typing (value/value.go:367-430: integer literals that fit
+ *           int64 are INT, a float64 with no fraction folds to INT) — done once per batch.
+ * Document d is bytes[offsets[d] .. offsets[d+1]) (one UTF-8 JSON value, the file datastore's <key>.json content,
+ * datastore/file/file.go:732-749).  Leaf paths must be chains of field names; the first field of a name counts;
+ * a field of a non-object is MISSING; strings and the canonical text of arrays / objects (sorted names, compact:
+ * value/object.go:30-78) are interned in the handle's dictionary.  The columns (TAGGED64) belong to the handle
+ * until the next extract / destroy.  Parsing is multi-threaded ("json_threads" option, default = the cores, <= 16).
+ * N1K_INVALID names the first malformed document.  Needs no device.
+ */
+n1k_status n1k_extract_json(n1k_handle *h, uint64_t ndocs, const uint64_t *offsets, const char *bytes, n1k_batch *out);
+
+/* n1k_extract_json + n1k_push_batch */
+n1k_status n1k_push_json(n1k_handle *h, uint64_t ndocs, const uint64_t *offsets, const char *bytes);
+
+/*
  * ≙ processItem() over a batch (execution/filter.go:49-61 +
  * execution/group_initial.go:56-100).  Host pointers; the call copies them to
  * the device before returning (cgo rule: no Go pointer is retained).

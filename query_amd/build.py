@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libn1k.so")
-SOURCES = ["n1k_kernels.hip", "n1k_plan.cpp", "n1k_engine.cpp", "n1k_jit.cpp"]
+SOURCES = ["n1k_kernels.hip", "n1k_plan.cpp", "n1k_engine.cpp", "n1k_jit.cpp", "n1k_json.cpp"]
 HEADERS = ["n1k_types.h", "n1k_device.h", "n1k_tables.h", "n1k_spec.h", "n1k_jit.h", "n1k_kernels.h", "n1k_plan.h", os.path.join("..", "..", "include", "n1k.h")]
 ARCH = "gfx950"
 
@@ -40,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
            "-Wall", "-Wno-unused-function", "-o", LIB]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-lhiprtc", "-ldl"]  # run-time instantiation of the plan-specialised kernel (n1k_jit.cpp)
+    cmd += ["-lhiprtc", "-ldl", "-pthread"]  # run-time instantiation of the plan-specialised kernel (n1k_jit.cpp)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

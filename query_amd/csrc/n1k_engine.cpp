@@ -16,11 +16,13 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/n1k.h"
 #include "n1k_jit.h"
+#include "n1k_json.h"
 #include "n1k_kernels.h"
 #include "n1k_plan.h"
 
@@ -94,6 +96,13 @@ struct n1k_handle {
     DevBuf<uint32_t> d_cand;
     DevBuf<char> d_topk, d_out2;
     uint64_t opt_topk_min_groups = 65536;  // device top-k filter from this many groups on
+    // raw documents -> columns (n1k_extract_json): leaf paths as field chains, the extracted batch
+    std::vector<JsonPath> json_paths;
+    int json_paths_state = 0;  // 0 not parsed, 1 ok, -1 some path is not a field chain
+    std::vector<std::vector<uint8_t>> js_tags;
+    std::vector<std::vector<uint64_t>> js_payload;
+    std::vector<n1k_col> js_cols;
+    uint32_t opt_json_threads = 0;  // 0 = hardware concurrency (at most 16)
     char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
     size_t pin_cap = 0;
     std::string jit_log;
@@ -1409,6 +1418,8 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         uint32_t v = 64;
         while (v < (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 8192)) v <<= 1;
         h->opt_distinct_set_slots = v;
+    } else if (n == "json_threads") {
+        h->opt_json_threads = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64);
     } else if (n == "partition_min_rows") {
         h->opt_partition_min_rows = (uint64_t)std::max<int64_t>(value, 1);
     } else if (n == "partition_probe_rows") {
@@ -1456,6 +1467,75 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
 n1k_status n1k_push_device_batch(n1k_handle* h, const n1k_batch* batch) {
     if (!h) return N1K_INVALID;
     return push_device(h, batch);
+}
+
+n1k_status n1k_extract_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offsets, const char* bytes, n1k_batch* out) {
+    if (!h || !out || (ndocs && (!offsets || !bytes))) return N1K_INVALID;
+    if (h->json_paths_state == 0) {
+        h->json_paths.resize(h->plan.paths.size());
+        h->json_paths_state = 1;
+        for (size_t c = 0; c < h->plan.paths.size(); c++)
+            if (!parse_leaf_path(h->plan.paths[c], h->json_paths[c])) h->json_paths_state = -1;
+    }
+    if (h->json_paths_state < 0)
+        return fail(h, N1K_UNSUPPORTED, "a leaf path of the plan is not a chain of field names: extract the columns yourself");
+    const size_t np = h->json_paths.size();
+    uint32_t nthreads = h->opt_json_threads ? h->opt_json_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nthreads = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nthreads, ndocs / 2048 + 1));
+    std::vector<JsonColumns> part(nthreads);
+    std::vector<std::string> errs(nthreads);
+    std::vector<long long> bad(nthreads, -1);
+    std::vector<std::thread> workers;
+    auto range = [&](uint32_t t) { return std::make_pair(ndocs * t / nthreads, ndocs * (t + 1) / nthreads); };
+    for (uint32_t t = 1; t < nthreads; t++)
+        workers.emplace_back([&, t] {
+            auto r = range(t);
+            bad[t] = extract_json_range(h->json_paths, offsets, bytes, r.first, r.second, part[t], errs[t]);
+        });
+    {
+        auto r = range(0);
+        bad[0] = extract_json_range(h->json_paths, offsets, bytes, r.first, r.second, part[0], errs[0]);
+    }
+    for (auto& w : workers) w.join();
+    for (uint32_t t = 0; t < nthreads; t++)
+        if (bad[t] >= 0) return fail(h, N1K_INVALID, "document %lld is not valid JSON: %s", bad[t], errs[t].c_str());
+    // one dictionary: the threads' local strings get the handle's codes
+    h->js_tags.assign(np, std::vector<uint8_t>());
+    h->js_payload.assign(np, std::vector<uint64_t>());
+    for (size_t c = 0; c < np; c++) {
+        h->js_tags[c].resize(ndocs);
+        h->js_payload[c].resize(ndocs);
+    }
+    for (uint32_t t = 0; t < nthreads; t++) {
+        auto r = range(t);
+        std::vector<uint64_t> code(part[t].strings.size());
+        for (size_t i = 0; i < code.size(); i++) code[i] = intern(h, part[t].strings[i]);
+        for (size_t c = 0; c < np; c++) {
+            const size_t n = (size_t)(r.second - r.first);
+            memcpy(h->js_tags[c].data() + r.first, part[t].tags[c].data(), n);
+            uint64_t* dst = h->js_payload[c].data() + r.first;
+            const uint64_t* src = part[t].payload[c].data();
+            const uint8_t* tg = part[t].tags[c].data();
+            for (size_t i = 0; i < n; i++) dst[i] = tg[i] >= N1K_T_STRING ? code[src[i]] : src[i];
+        }
+    }
+    h->js_cols.assign(np, n1k_col{});
+    for (size_t c = 0; c < np; c++) {
+        h->js_cols[c].kind = N1K_COL_TAGGED64;
+        h->js_cols[c].tags = h->js_tags[c].data();
+        h->js_cols[c].payload = h->js_payload[c].data();
+    }
+    out->nrows = ndocs;
+    out->ncols = (uint32_t)np;
+    out->cols = h->js_cols.data();
+    return N1K_OK;
+}
+
+n1k_status n1k_push_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offsets, const char* bytes) {
+    n1k_batch b{};
+    n1k_status st = n1k_extract_json(h, ndocs, offsets, bytes, &b);
+    if (st != N1K_OK) return st;
+    return n1k_push_batch(h, &b);
 }
 
 n1k_status n1k_push_batch(n1k_handle* h, const n1k_batch* batch) {

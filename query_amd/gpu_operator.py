@@ -165,6 +165,38 @@ class GpuFilterGroup:
     def process_device_batch(self, batch):
         self._check(self._lib.n1k_push_device_batch(self._h, C.byref(batch[0])))
 
+    # ------------------------------------------------------------ raw documents
+    @staticmethod
+    def _pack_docs(docs: Sequence[bytes]):
+        offsets = np.zeros(len(docs) + 1, dtype=np.uint64)
+        np.cumsum([len(d) for d in docs], out=offsets[1:])
+        return offsets, b"".join(docs)
+
+    def extract_json(self, docs: Sequence[bytes]) -> List[dict]:
+        """n1k_extract_json: the plan's leaf columns of raw JSON documents, as {"tags", "payload"} numpy copies in
+        column_paths order (string payloads are codes of the handle's dictionary).  Needs no GPU."""
+        offsets, blob = self._pack_docs(docs)
+        b = _ffi.Batch()
+        self._check(self._lib.n1k_extract_json(self._h, len(docs), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), blob, C.byref(b)))
+        out = []
+        for c in range(b.ncols):
+            col = b.cols[c]
+            n = int(b.nrows)
+            tags = np.ctypeslib.as_array(C.cast(col.tags, C.POINTER(C.c_uint8)), shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+            pay = np.ctypeslib.as_array(C.cast(col.payload, C.POINTER(C.c_uint64)), shape=(n,)).copy() if n else np.zeros(0, np.uint64)
+            out.append({"tags": tags, "payload": pay})
+        return out
+
+    def process_json(self, docs: Sequence[bytes]):
+        """n1k_push_json: ≙ processItem over raw documents (the file datastore's <key>.json contents)."""
+        offsets, blob = self._pack_docs(docs)
+        self._check(self._lib.n1k_push_json(self._h, len(docs), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), blob))
+
+    def dict_get(self, code: int) -> bytes:
+        ptr, ln = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.n1k_dict_get(self._h, int(code), C.byref(ptr), C.byref(ln)))
+        return C.string_at(ptr.value, ln.value) if ln.value else b""
+
     def sync(self):
         self._check(self._lib.n1k_sync(self._h))
 

@@ -620,3 +620,48 @@ def test_partitioned_path_is_chosen_from_the_data():
     gpu, stats = pu.run_gpu(t, None, [D("region_id")], aggs, **opts)
     pu.assert_same_groups(gpu, ora, aggs=aggs)
     assert stats["agg_mode"] != 4
+
+
+def _docs_of(table, n):
+    """The synthetic table as raw JSON documents ({"id","cat","price","user_id","region_id","pad"})."""
+    import json
+    by = {c.name: c for c in table.columns}
+    docs = []
+    for i in range(n):
+        d = {"id": "d%d" % i, "pad": "x" * (i % 40)}
+        c = int(by[D("cat")].codes[i])
+        if c == 0xFFFFFFFE:
+            d["cat"] = None
+        elif c != 0xFFFFFFFF:
+            d["cat"] = table.dictionary[c].decode()
+        for name in ("price", "user_id", "region_id"):
+            col = by[D(name)]
+            t, p = int(col.tags[i]), col.payload[i]
+            if t == n1o.T_INT:
+                d[name] = int(np.uint64(p).astype(np.int64))
+            elif t == n1o.T_FLOAT:
+                d[name] = float(np.array([p], np.uint64).view(np.float64)[0])
+            elif t == n1o.T_STRING:
+                d[name] = table.dictionary[int(p)].decode()
+            elif t == n1o.T_NULL:
+                d[name] = None
+        docs.append(json.dumps(d).encode())
+    return docs
+
+
+@pytest.mark.parametrize("cond,keys,aggs", [CONFIG2, CONFIG3,
+                                            (None, [D("cat"), D("region_id")], ["sum(%s)" % D("price")])],
+                         ids=["config2", "config3", "config5-keys"])
+def test_raw_json_documents_end_to_end(cond, keys, aggs):
+    """n1k_push_json: documents in, groups out — the same answers as the oracle over the columns the documents were
+    made from (leaf access + typing: value/parsed.go:159-207, value/value.go:367-430)."""
+    n = 30_000
+    t = n1o.synth_table(n, k_cat=40, total_rows=20_000)
+    docs = _docs_of(t, n)
+    ora = n1o.run(t, cond, keys, aggs, threads=2)
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(cond, keys, aggs))
+    op.process_json(docs[:n // 2])
+    op.process_json(docs[n // 2:])
+    gpu = op.after_items()
+    op.done()
+    pu.assert_same_groups(gpu, ora, aggs=aggs)

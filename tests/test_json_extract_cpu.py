@@ -1,0 +1,146 @@
+"""n1k_extract_json (host C++, no GPU): raw JSON documents -> the plan's leaf columns, against the Python extraction
+the golden tests use (golden_util.build_table) on the reference's own data sets, plus the scanner's edge cases."""
+import json
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import query_amd
+from oracle import n1o
+from query_amd import _ffi, plan
+
+
+def D(*names):
+    return plan.field_path("default", *names)
+
+
+def _decode(op, col):
+    """(tag, value) per row with dictionary codes resolved to bytes."""
+    out = []
+    for t, p in zip(col["tags"], col["payload"]):
+        t = int(t)
+        if t == n1o.T_INT:
+            out.append((t, int(np.uint64(p).astype(np.int64))))
+        elif t == n1o.T_FLOAT:
+            out.append((t, float(np.array([p], np.uint64).view(np.float64)[0])))
+        elif t >= n1o.T_STRING:
+            out.append((t, op.dict_get(int(p))))
+        else:
+            out.append((t, None))
+    return out
+
+
+def _expected(table):
+    out = []
+    for c in table.columns:
+        rows = []
+        for t, p in zip(c.tags, c.payload):
+            t = int(t)
+            if t == n1o.T_INT:
+                rows.append((t, int(np.uint64(p).astype(np.int64))))
+            elif t == n1o.T_FLOAT:
+                rows.append((t, float(np.array([p], np.uint64).view(np.float64)[0])))
+            elif t >= n1o.T_STRING:
+                rows.append((t, bytes(table.dictionary[int(p)])))
+            else:
+                rows.append((t, None))
+        out.append(rows)
+    return out
+
+
+CASES = [c for c in gu.load_cases() if not c["plan"].get("filter_only")]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_extraction_matches_the_golden_tables(case):
+    """Every golden case's documents (the reference's test data), serialised as JSON text, give the same columns as
+    the Python extraction of the golden tests: types per value.NewValue, canonical texts of arrays / objects."""
+    docs = gu.load_docs(case["keyspace"])
+    p = case["plan"]
+    try:
+        op = query_amd.GpuFilterGroup(plan.filter_group_plan(p["condition"], p["group_keys"], p["aggregates"]))
+    except query_amd.N1kError as e:
+        pytest.skip("plan outside the device subset: " + e.message)
+    paths = op.column_paths
+    table = gu.build_table(docs, paths)
+    raw = [json.dumps(d["doc"], ensure_ascii=False).encode() for d in docs]
+    try:
+        cols = op.extract_json(raw)
+    except query_amd.N1kError as e:
+        if e.status == _ffi.UNSUPPORTED:
+            pytest.skip(e.message)
+        raise
+    got = [_decode(op, c) for c in cols]
+    exp = _expected(table)[:len(paths)]
+    assert got == exp
+    op.done()
+
+
+def _one(doc: bytes, *fields, threads=None):
+    paths = [D(*f) if isinstance(f, tuple) else D(f) for f in fields]
+    # up to 4 group keys and 8 aggregates per plan: the leaf columns come out in exactly this order
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(None, paths[:4], ["count(%s)" % p for p in paths[4:]] or ["count(*)"]))
+    assert op.column_paths == paths
+    if threads:
+        op.set_option("json_threads", threads)
+    cols = op.extract_json([doc])
+    r = [_decode(op, c)[0] for c in cols]
+    op.done()
+    return r
+
+
+def test_number_typing_follows_newvalue():
+    """value/value.go:375-382 + integer.go:354-356: integer literals that fit int64 are INT, floats with no fraction
+    fold to INT, everything else FLOAT (G6: 2^53+1 stays exact as an int literal)."""
+    doc = b'{"a": 9007199254740993, "b": 1e3, "c": 1.5, "d": -0.0, "e": 9223372036854775808, "f": -9223372036854775808, "g": 12.0, "h": 1E-2}'
+    a, b, c, d, e, f, g, h = _one(doc, "a", "b", "c", "d", "e", "f", "g", "h")
+    assert a == (n1o.T_INT, 9007199254740993)
+    assert b == (n1o.T_INT, 1000)
+    assert c == (n1o.T_FLOAT, 1.5)
+    assert d == (n1o.T_INT, 0)
+    assert e == (n1o.T_FLOAT, 9223372036854775808.0)
+    assert f == (n1o.T_INT, -9223372036854775808)
+    assert g == (n1o.T_INT, 12)
+    assert h == (n1o.T_FLOAT, 0.01)
+
+
+def test_fields_strings_and_structure():
+    doc = ('{"s": "a\\"b\\\\c\\u00e9\\ud83d\\ude00\\n", "t": true, "f": false, "n": null, "dup": 1, "dup": 2, '
+           '"o": {"z": [1, 2.50, {"k": "v", "a": null}], "a": 1.0, "e": {}}, "arr": [ ], "nested": {"x": {"y": 7}}, "sc": 5}').encode()
+    s, t, f, n, dup, o, arr, y, miss, below_scalar = _one(doc, "s", "t", "f", "n", "dup", "o", "arr", ("nested", "x", "y"), "nope", ("sc", "x"))
+    assert s == (n1o.T_STRING, 'a"b\\cé\U0001F600\n'.encode())
+    assert t == (n1o.T_TRUE, None) and f == (n1o.T_FALSE, None) and n == (n1o.T_NULL, None)
+    assert dup == (n1o.T_INT, 1)  # FirstFind: the first field of a name counts (value/parsed.go:189-193)
+    assert o == (n1o.T_OBJECT, b'{"a":1,"e":{},"z":[1,2.5,{"a":null,"k":"v"}]}')  # sorted names, compact, folded numbers
+    assert arr == (n1o.T_ARRAY, b"[]")
+    assert y == (n1o.T_INT, 7)
+    assert miss == (n1o.T_MISSING, None)
+    assert below_scalar == (n1o.T_MISSING, None)  # a field of a non-object is MISSING
+
+
+def test_malformed_documents_are_named():
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(None, [D("a")], ["count(*)"]))
+    good = b'{"a": 1}'
+    for bad in (b'{"a": 1', b'{"a": tru}', b'{"a": 1} x', b'{"a": "\\q"}', b'{a: 1}', b''):
+        with pytest.raises(query_amd.N1kError) as ei:
+            op.extract_json([good, good, bad, good])
+        assert ei.value.status == _ffi.INVALID and "document 2" in ei.value.message
+    assert _decode(op, op.extract_json([b'[1, 2]', b'7', good])[0]) == [(n1o.T_MISSING, None), (n1o.T_MISSING, None), (n1o.T_INT, 1)]
+    op.done()
+
+
+def test_threads_agree_and_share_one_dictionary():
+    rng = np.random.default_rng(2)
+    docs = [json.dumps({"cat": "c%d" % rng.integers(0, 50), "price": float(rng.integers(0, 10000)) / 100,
+                        "tags": [int(x) for x in rng.integers(0, 3, 2)]}).encode() for _ in range(20_000)]
+    pj = plan.filter_group_plan(None, [D("cat"), D("tags")], ["sum(%s)" % D("price")])
+    a, b = query_amd.GpuFilterGroup(pj), query_amd.GpuFilterGroup(pj)
+    a.set_option("json_threads", 1)
+    b.set_option("json_threads", 7)
+    ca, cb = a.extract_json(docs), b.extract_json(docs)
+    for x, y in zip(ca, cb):
+        assert np.array_equal(x["tags"], y["tags"])
+    assert [_decode(a, c) for c in ca] == [_decode(b, c) for c in cb]
+    a.done()
+    b.done()
