@@ -96,6 +96,10 @@ struct n1k_handle {
     DevBuf<uint32_t> d_cand;
     DevBuf<char> d_topk, d_out2;
     uint64_t opt_topk_min_groups = 65536;  // device top-k filter from this many groups on
+    // HAVING: an inner Filter-only operator over the final groups (its columns are group keys / aggregates)
+    n1k_handle* having = nullptr;
+    std::vector<int> having_cols;        // per inner column: key index k (>= 0) or -(aggregate index) - 1
+    std::vector<uint32_t> having_codes;  // dictionary code of this handle -> code of the inner handle (lazy)
     // raw documents -> columns (n1k_extract_json): leaf paths as field chains, the extracted batch
     std::vector<JsonPath> json_paths;
     int json_paths_state = 0;  // 0 not parsed, 1 ok, -1 some path is not a field chain
@@ -1271,6 +1275,50 @@ n1k_status n1k_create(const char* plan_json, size_t len, n1k_handle** out) {
         delete h;
         return st;
     }
+    if (h->plan.has_having) {
+        // The HAVING condition speaks of group keys and aggregates: replace each (longest text first) by a synthetic
+        // leaf path and hand the result to an inner Filter-only operator, so that the device's predicate evaluator —
+        // comparisons, arithmetic, 4-valued logic — is the one that decides, as it does for WHERE.
+        std::string cond = h->plan.having_text;
+        std::vector<std::pair<std::string, std::string>> subst;
+        for (size_t a = 0; a < h->plan.aggs.size(); a++) subst.emplace_back(h->plan.aggs[a].text, "(`$g`.`a" + std::to_string(a) + "`)");
+        for (size_t k = 0; k < h->plan.key_texts.size(); k++) subst.emplace_back(h->plan.key_texts[k], "(`$g`.`k" + std::to_string(k) + "`)");
+        std::stable_sort(subst.begin(), subst.end(), [](const auto& x, const auto& y) { return x.first.size() > y.first.size(); });
+        for (auto& sb : subst) {
+            if (sb.first.empty()) continue;
+            for (size_t pos = 0; (pos = cond.find(sb.first, pos)) != std::string::npos; pos += sb.second.size())
+                cond.replace(pos, sb.first.size(), sb.second);
+        }
+        std::string js = "{\"#operator\":\"Filter\",\"condition\":\"";
+        for (char c : cond) {
+            if (c == '"' || c == '\\') js.push_back('\\');
+            if ((unsigned char)c < 0x20) {
+                char b[8];
+                snprintf(b, sizeof b, "\\u%04x", (unsigned)c);
+                js += b;
+            } else
+                js.push_back(c);
+        }
+        js += "\"}";
+        n1k_status hst = n1k_create(js.c_str(), js.size(), &h->having);
+        if (hst != N1K_OK) {
+            g_create_error = "HAVING: " + g_create_error;
+            delete h;
+            return hst;
+        }
+        for (const std::string& p : h->having->plan.paths) {
+            int idx = -1;
+            char kind = 0;
+            if (sscanf(p.c_str(), "(`$g`.`%c%d`)", &kind, &idx) != 2 || (kind != 'k' && kind != 'a') || idx < 0 ||
+                (size_t)idx >= (kind == 'k' ? h->plan.key_texts.size() : h->plan.aggs.size())) {
+                g_create_error = "HAVING refers to " + p + ", which is neither a group key nor an aggregate of the plan";
+                n1k_destroy(h->having);
+                delete h;
+                return N1K_UNSUPPORTED;
+            }
+            h->having_cols.push_back(kind == 'k' ? idx : -idx - 1);
+        }
+    }
     g_create_error.clear();
     *out = h;
     return N1K_OK;
@@ -1278,6 +1326,8 @@ n1k_status n1k_create(const char* plan_json, size_t len, n1k_handle** out) {
 
 void n1k_destroy(n1k_handle* h) {
     if (!h) return;
+    if (h->having) n1k_destroy(h->having);
+    h->having = nullptr;
     if (h->device_ready) {
         (void)hipSetDevice(h->device);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -1705,6 +1755,67 @@ static int host_collate(const n1k_handle* h, const n1k_value& a, const n1k_value
     }
 }
 
+// HAVING (the Filter after FinalGroup, planner/build_select_sub.go:295; execution/filter.go:49-61 over rows whose
+// aggregates are read from the "aggregates" attachment, algebra/aggregate.go:97-118): the final groups become a batch
+// of the inner Filter-only operator — one column per key / aggregate its condition names — and its survivors stay.
+static n1k_status having_groups(n1k_handle* h, uint64_t& ng) {
+    n1k_handle* f = h->having;
+    const size_t nk = h->plan.keys.size(), na = h->plan.aggs.size(), nc = h->having_cols.size();
+    if (ng == 0) return N1K_OK;
+    if (f->device < 0 && !f->device_ready) f->device = h->device;
+    std::vector<std::vector<uint8_t>> tags(nc, std::vector<uint8_t>((size_t)ng));
+    std::vector<std::vector<uint64_t>> pay(nc, std::vector<uint64_t>((size_t)ng));
+    h->having_codes.resize(h->dict.size(), 0xFFFFFFFFu);
+    for (size_t c = 0; c < nc; c++) {
+        const int src = h->having_cols[c];
+        for (uint64_t g = 0; g < ng; g++) {
+            const n1k_value& v = src >= 0 ? h->r_keys[g * nk + (size_t)src] : h->r_aggs[g * na + (size_t)(-src - 1)];
+            tags[c][g] = v.tag;
+            uint64_t p = v.v.code;
+            if (v.tag >= N1K_T_STRING) {  // the inner operator has its own dictionary
+                uint32_t& m = h->having_codes[(size_t)p];
+                if (m == 0xFFFFFFFFu) m = intern(f, h->dict[(size_t)p]);
+                p = m;
+            }
+            pay[c][g] = p;
+        }
+    }
+    std::vector<n1k_col> cols(nc ? nc : 1);
+    for (size_t c = 0; c < nc; c++) {
+        cols[c].kind = N1K_COL_TAGGED64;
+        cols[c].tags = tags[c].data();
+        cols[c].payload = pay[c].data();
+    }
+    n1k_batch b{};
+    b.nrows = ng;
+    b.ncols = (uint32_t)nc;
+    b.cols = cols.data();
+    n1k_result res{};
+    n1k_status st = n1k_reset(f);
+    if (st == N1K_OK) st = n1k_push_batch(f, &b);
+    if (st == N1K_OK) st = n1k_finish(f, &res);
+    if (st != N1K_OK) return fail(h, st, "HAVING: %s", n1k_last_error(f));
+    const uint64_t keep = res.nselected;
+    std::vector<n1k_value> keys(keep * nk), aggs(keep * na);
+    std::vector<n1k_partial> parts(h->r_parts.empty() ? 0 : keep * na);
+    std::vector<uint64_t> rep(keep);
+    for (uint64_t i = 0; i < keep; i++) {
+        const uint64_t g = res.selected[i];
+        for (size_t k = 0; k < nk; k++) keys[i * nk + k] = h->r_keys[g * nk + k];
+        for (size_t a = 0; a < na; a++) {
+            aggs[i * na + a] = h->r_aggs[g * na + a];
+            if (!parts.empty()) parts[i * na + a] = h->r_parts[g * na + a];
+        }
+        rep[i] = g < h->r_rep.size() ? h->r_rep[g] : ~0ull;
+    }
+    h->r_keys.swap(keys);
+    h->r_aggs.swap(aggs);
+    h->r_parts.swap(parts);
+    h->r_rep.swap(rep);
+    ng = keep;
+    return N1K_OK;
+}
+
 // Order / Offset / Limit over the final groups (execution/order.go:121-169: term by term Collate, DESC flips it;
 // order_limit.go keeps offset + limit rows; offset.go / limit.go then cut).  sort.Sort is not stable, so the order
 // among rows that tie on every term is unspecified in the reference too; here ties keep table order.
@@ -1771,7 +1882,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     uint64_t spec_groups = 0;
     if (h->device_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
-        const bool topk_forced = pl.has_order && pl.limit >= 0 && h->opt_topk_min_groups < 4096;  // tests
+        const bool topk_forced = pl.has_order && pl.limit >= 0 && !pl.has_having && h->opt_topk_min_groups < 4096;  // tests
         // (a table of millions of slots is not worth scanning twice: the sized pass alone then)
         if (pl.has_group && !h->has_distinct && h->table.capacity && h->table.capacity <= (1u << 20) && !topk_forced) {
             spec_groups = std::min<uint64_t>(h->table.capacity, 4096);
@@ -1875,7 +1986,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             const uint64_t keep = pl.limit >= 0 ? (uint64_t)pl.offset + (uint64_t)pl.limit : ng;
             size_t copy_bytes = total;
             const char* src = d;
-            if (pl.has_order && pl.limit >= 0 && keep > 0 && keep < ng && ng >= h->opt_topk_min_groups && ng < (1ull << 32)) {
+            if (pl.has_order && pl.limit >= 0 && !pl.has_having && keep > 0 && keep < ng && ng >= h->opt_topk_min_groups && ng < (1ull << 32)) {
                 // ORDER BY ... LIMIT: only the groups that can be among the first offset+limit rows leave the device
                 const OrderTerm& t0 = pl.order[0];
                 HIP_TRY(h, h->d_images.ensure(ng));
@@ -1948,6 +2059,10 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
         h->r_rep.assign(1, ~0ull);
         for (uint32_t a = 0; a < na; a++) default_value(pl.aggs[a], h->r_aggs[a], h->r_parts[a]);
         ng = 1;
+    }
+    if (pl.has_having) {
+        n1k_status st = having_groups(h, ng);
+        if (st != N1K_OK) return st;
     }
     if (pl.has_order || pl.limit >= 0 || pl.offset > 0) {
         n1k_status st = order_groups(h, ng);

@@ -523,8 +523,20 @@ bool plan_node(const JVal& node, ParsedPlan& out, PlanError& err, int depth) {
             if (!plan_node(c, out, err, depth + 1)) return false;
         return true;
     }
+    if (name == "Filter" && out.has_group) {  // HAVING: the Filter that follows FinalGroup
+        if (out.has_having || out.has_order || out.limit >= 0 || out.offset > 0) {
+            err.unsupported = true;
+            err.msg = "only one HAVING Filter, before Order / Offset / Limit, runs on the device";
+            return false;
+        }
+        const JVal* c = node.get("condition");
+        if (!c || c->type != JVal::Str) { err.msg = "Filter without condition"; return false; }
+        out.having_text = c->str;
+        out.has_having = true;
+        return true;
+    }
     if (name == "Filter") {  // plan/filter.go:46-53
-        if (out.has_filter || out.has_group) {
+        if (out.has_filter) {
             err.unsupported = true;
             err.msg = "only [Filter?, InitialGroup] sequences run on the device";
             return false;

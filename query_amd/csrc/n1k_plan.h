@@ -65,6 +65,9 @@ struct ParsedPlan {
     std::vector<OrderTerm> order;
     int64_t limit = -1;  // < 0: none
     int64_t offset = 0;
+    // HAVING: a Filter after the group operators (planner/build_select_sub.go:295), over group keys and aggregates
+    bool has_having = false;
+    std::string having_text;
 };
 
 // Parse plan JSON (Sequence / Parallel / Filter / InitialGroup nodes, optionally followed by IntermediateGroup /

@@ -120,7 +120,7 @@ def marshal_json(op) -> str:
 def filter_group_plan(condition: Optional[str], group_keys: Optional[Sequence[str]],
                       aggregates: Optional[Sequence[str]], *, filter_only: bool = False,
                       order: Optional[Sequence[tuple]] = None, limit: Optional[int] = None,
-                      offset: Optional[int] = None) -> str:
+                      offset: Optional[int] = None, having: Optional[str] = None) -> str:
     """Plan JSON of Parallel{Sequence[Filter?, InitialGroup?]} as the planner emits it
     (planner/build_select_sub.go:209-211, 276-296).  With `order` / `limit` / `offset` the whole grouped tail
     follows: IntermediateGroup, FinalGroup, Order (which carries offset and limit, plan/order.go:51-79), Offset,
@@ -131,10 +131,12 @@ def filter_group_plan(condition: Optional[str], group_keys: Optional[Sequence[st
     if not filter_only:
         children.append(InitialGroup(list(group_keys or []), list(aggregates or [])))
     par = Parallel(Sequence(children))
-    if order is None and limit is None and offset is None:
+    if order is None and limit is None and offset is None and having is None:
         return marshal_json(par)
     tail: List[object] = [par, IntermediateGroup(list(group_keys or []), list(aggregates or [])),
                           FinalGroup(list(group_keys or []), list(aggregates or []))]
+    if having is not None:  # HAVING is a Filter over the final groups (planner/build_select_sub.go:295)
+        tail.append(Filter(having))
     if order:
         tail.append(Order(list(order), offset, limit))
     else:

@@ -14,7 +14,7 @@ import math
 import os
 import re
 import sys
-from typing import Any, Dict, List, Sequence
+from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
@@ -349,10 +349,27 @@ def _having(h, keys, aggs) -> bool:
     return {">": c > 0, "<": c < 0, "=": c == 0, ">=": c >= 0, "<=": c <= 0}[op]
 
 
-def replay_post(case: dict, groups: Sequence[tuple]) -> List[dict]:
+def having_text(case: dict) -> Optional[str]:
+    """The case's HAVING clause as expression.Stringer text over the plan's keys / aggregates (what the Filter node
+    after FinalGroup carries): `x > c` prints as (c < x) (expression/comp_gt.go:15-17)."""
+    h = case.get("post", {}).get("having")
+    if not h:
+        return None
+    p = case["plan"]
+    lhs = p["aggregates"][h[0]["agg"]] if "agg" in h[0] else p["group_keys"][h[0]["key"]]
+    lit = lambda v: json.dumps(v)
+    op, rhs = h[1], h[2]
+    if op == "between":
+        return "(%s between %s and %s)" % (lhs, lit(rhs[0]), lit(rhs[1]))
+    if op in (">", ">="):
+        return "(%s %s %s)" % (lit(rhs), "<" if op == ">" else "<=", lhs)
+    return "(%s %s %s)" % (lhs, op, lit(rhs))
+
+
+def replay_post(case: dict, groups: Sequence[tuple], having_done: bool = False) -> List[dict]:
     """groups: list of (keys[], aggs[]) python values.  Returns result rows like the reference's."""
     post = case["post"]
-    rows = [g for g in groups if "having" not in post or _having(post["having"], g[0], g[1])]
+    rows = [g for g in groups if having_done or "having" not in post or _having(post["having"], g[0], g[1])]
     if "order" in post:
         def cmp(g1, g2):
             for spec, direction in post["order"]:

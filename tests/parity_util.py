@@ -15,9 +15,10 @@ REL_TOL = 1e-9  # north_star: float SUM/AVG within 1e-9 relative; everything els
 
 def run_gpu(table: n1o.Table, condition: Optional[str], keys: Sequence[str], aggs: Sequence[str], *,
             filter_only: bool = False, batches: int = 1, device_resident: bool = False, order=None, limit=None,
-            offset=None, **options):
+            offset=None, having=None, **options):
     """Run through libn1k.so.  The table's columns are matched to the plan's leaf paths by name."""
-    pj = qplan.filter_group_plan(condition, keys, aggs, filter_only=filter_only, order=order, limit=limit, offset=offset)
+    pj = qplan.filter_group_plan(condition, keys, aggs, filter_only=filter_only, order=order, limit=limit, offset=offset,
+                                 having=having)
     op = query_amd.GpuFilterGroup(pj, **options)
     try:
         by_name = {c.name: c for c in table.columns}

@@ -28,8 +28,9 @@ def test_golden_cases_on_device(case):
             rows, _ = pu.run_gpu(table, plan["condition"], [], [], filter_only=True)
             got = gu.replay_filter_post(case, docs, rows.selected)
         else:
-            rows, _ = pu.run_gpu(table, plan["condition"], plan["group_keys"], plan["aggregates"])
-            got = gu.replay_post(case, gu.groups_from_result(rows))
+            # HAVING (where the case has one) runs inside the handle, through the device's predicate evaluator
+            rows, _ = pu.run_gpu(table, plan["condition"], plan["group_keys"], plan["aggregates"], having=gu.having_text(case))
+            got = gu.replay_post(case, gu.groups_from_result(rows), having_done=True)
     except query_amd.N1kError as e:
         if e.status == _ffi.UNSUPPORTED:
             pytest.skip("outside the device subset: " + e.message)
@@ -665,3 +666,31 @@ def test_raw_json_documents_end_to_end(cond, keys, aggs):
     gpu = op.after_items()
     op.done()
     pu.assert_same_groups(gpu, ora, aggs=aggs)
+
+
+@pytest.mark.parametrize("having,check", [
+    ("(33000 < sum(%s))" % D("price"), lambda k, a: a["sum"][1] is not None and a["sum"][1] > 33000),
+    ("((count(*) < 700) and (%s is not null))" % D("cat"), lambda k, a: a["count"][1] < 700 and k[0][0] > n1o.T_NULL),
+    ("((sum(%s) / count(*)) between 40 and 52)" % D("price"), lambda k, a: 40 <= a["sum"][1] / a["count"][1] <= 52),
+    ("(%s = \"cat_3\")" % D("cat"), lambda k, a: k[0][1] == b"cat_3"),
+    ("(max(%s) = \"n/a\")" % D("price"), lambda k, a: a["max"][1] == b"n/a"),
+])
+def test_having_over_the_groups(having, check):
+    """planner/build_select_sub.go:295: HAVING is a Filter over the final groups; here its condition (group keys,
+    aggregates, arithmetic, logic) is evaluated by the same device predicate code as WHERE."""
+    t = n1o.synth_table(60_000, k_cat=90)
+    aggs = sorted(["sum(%s)" % D("price"), "count(*)", "max(%s)" % D("price")])
+    ora = n1o.run(t, None, [D("cat")], aggs, threads=2)
+    gpu, _ = pu.run_gpu(t, None, [D("cat")], aggs, having=having, order=[(D("cat"), False)])
+    names = [a.split("(")[0] for a in aggs]
+    keep = [(k, a) for k, a in zip(ora.keys, ora.aggs) if check(k, dict(zip(names, a)))]
+    assert 0 < len(keep) <= len(ora.keys)
+    assert len(gpu.keys) == len(keep)
+    assert {pu._canon_key(k) for k in gpu.keys} == {pu._canon_key(k) for k, _ in keep}
+
+
+def test_having_outside_the_groups_is_unsupported():
+    pj = query_amd.plan.filter_group_plan(None, [D("cat")], ["count(*)"], having="(%s < 5)" % D("price"))
+    with pytest.raises(query_amd.N1kError) as ei:
+        query_amd.GpuFilterGroup(pj)
+    assert ei.value.status == _ffi.UNSUPPORTED and "HAVING" in ei.value.message
