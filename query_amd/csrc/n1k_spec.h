@@ -95,9 +95,7 @@ N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32
     if (kind == AGG_SUM || kind == AGG_AVG) {
         if (tag == T_INT) {
             int64_t x = (int64_t)p;
-#ifndef N1K_ABLATE_BIGINT
             if (x >= (1ll << 40) || x <= -(1ll << 40)) return false;
-#endif
             lds_add_u64(w, (unsigned long long)x);
             SPEC_FLAG(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
@@ -167,12 +165,10 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
         for (int k = 0; k < Spec::nkeys; k++) {
             const uint32_t t = tg[Spec::key_col[k]];
             uint32_t f = t == T_MISSING ? 0u : (t == T_NULL ? 1u : (uint32_t)pv[Spec::key_col[k]] + 2u);
-#ifndef N1K_ABLATE_KEYCHECK
             if ((t > T_NULL && t != T_STRING) || f >= F.keys[k].radix) {
                 unpackable = 1;
                 return;
             }
-#endif
             slot += f * F.keys[k].stride;
         }
         *(volatile lds_u64*)lds_word(lds, slot) = 1ull;  // "touched": every writer stores the same value, nobody reads it here

@@ -132,3 +132,55 @@ def test_full_size_count_distinct_properties(columns):
     di, ci = aggs.index("count(distinct %s)" % D("user_id")), aggs.index("count(%s)" % D("user_id"))
     assert sum(v[ci][1] for v in a.values()) == ROWS
     assert all(0 < v[di][1] <= v[ci][1] for v in a.values())
+
+
+def test_full_size_count_distinct_paths_agree(columns):
+    """The two independent ways the sets are built — radix partition + LDS sets over one-word members, and the
+    per-group global sets over (key, value, class) pairs — give the same COUNT(DISTINCT) at 100 M rows; the oracle
+    pins both on a prefix."""
+    aggs = sorted(["count(distinct %s)" % D("user_id"), "avg(%s)" % D("price")])  # BASELINE config 3
+    words, ws = run(columns, None, KEYS, aggs, [(0, ROWS)])
+    pairs, ps = run(columns, None, KEYS, aggs, [(0, ROWS)], distinct_words=0)
+    assert ws["distinct_path"] == 2 and ps["distinct_path"] == 1
+    a, b = as_dict(words), as_dict(pairs)
+    assert a.keys() == b.keys() and len(a) == K_CAT
+    for k in a:
+        for x, y in zip(a[k], b[k]):
+            assert close(x, y), (k, x, y)
+    n = 1_000_000
+    t = n1o.synth_table(n, k_cat=K_CAT, total_rows=ROWS)
+    ora = n1o.run(t, None, KEYS, aggs, threads=4)
+    raw, _ = run(columns, None, KEYS, aggs, [(0, n)])
+    import bench
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(None, KEYS, aggs))
+    op.intern(bench.synth_dictionary(K_CAT))
+    cache = {}
+    from query_amd.gpu_operator import GroupRows
+    got = GroupRows(1, len(aggs), op._py_values(raw["keys"], cache), op._py_values(raw["aggs"], cache), [])
+    op.done()
+    pu.assert_same_groups(got, ora, aggs=aggs)
+
+
+def test_full_size_high_cardinality_paths_agree(columns):
+    """GROUP BY user_id (10 M groups in 100 M rows): the partitioned path (records -> radix passes -> per-bin LDS
+    tables) against the scan kernel with global atomics, group by group; COUNT(*) adds up to the rows."""
+    keys = [D("user_id")]
+    aggs = sorted(["count(*)", "sum(%s)" % D("region_id"), "max(%s)" % D("price")])
+    part, pst = run(columns, None, keys, aggs, [(0, ROWS)])
+    assert pst["agg_mode"] == 4  # chosen from the data: the first rows bring far more than 65 536 groups
+    scan, sst = run(columns, None, keys, aggs, [(0, ROWS)], agg_mode=_ffi.MODE_LDS_HASH)
+    assert sst["agg_mode"] != 4
+    # 100 M uniform draws over 10 M ids leave about 10 M * e^-10 = 454 ids unseen
+    assert part["ngroups"] == scan["ngroups"] and ROWS // 10 - 1000 < part["ngroups"] <= ROWS // 10
+
+    def table(raw):
+        order = np.argsort(raw["keys"][:, 0]["v"], kind="stable")
+        return raw["keys"][order], raw["aggs"][order]
+
+    pk, pa = table(part)
+    sk, sa = table(scan)
+    assert np.array_equal(pk["v"], sk["v"]) and np.array_equal(pk["tag"], sk["tag"])
+    assert np.array_equal(pa["tag"], sa["tag"])
+    assert np.array_equal(pa["v"], sa["v"])  # COUNT, integer SUM and MAX are bit-exact whatever the order of the rows
+    ci = aggs.index("count(*)")
+    assert int(pa[:, ci]["v"].astype(np.int64).sum()) == ROWS
