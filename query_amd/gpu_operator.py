@@ -116,11 +116,12 @@ class GpuFilterGroup:
         return b, arr
 
     def process_items(self, columns: Sequence[object], dictionary: Optional[Sequence[bytes]] = None,
-                      remap: bool = True):
+                      remap: bool = True, rows: Optional[int] = None):
         """Push one host batch.  `columns` follow self.column_paths order and expose .kind plus numpy
         .tags/.payload or .codes; string payloads/codes index `dictionary`, which is interned into the
-        handle's dictionary first (codes are remapped when the handle already holds other strings)."""
-        nrows = 0
+        handle's dictionary first (codes are remapped when the handle already holds other strings).  A plan that
+        names no leaf path (SELECT COUNT(*) ...) has no columns: `rows` is then the batch."""
+        nrows = int(rows or 0)
         code_map = None
         if dictionary is not None and len(dictionary):
             code_map = self.intern(list(dictionary))

@@ -24,8 +24,6 @@ def run_gpu(table: n1o.Table, condition: Optional[str], keys: Sequence[str], agg
         by_name = {c.name: c for c in table.columns}
         cols = [by_name[p] for p in op.column_paths]
         n = table.nrows
-        if not cols:  # count(*) over no referenced path: the engine still needs the row count
-            raise AssertionError("plan references no column")
         step = max(1, (n + batches - 1) // batches)
         lo = 0
         first = True
@@ -52,7 +50,7 @@ def run_gpu(table: n1o.Table, condition: Optional[str], keys: Sequence[str], agg
                 torch.cuda.synchronize()
                 op.process_device_items(hi - lo, dev)
             else:
-                op.process_items(part, table.dictionary)
+                op.process_items(part, table.dictionary, rows=hi - lo)  # (rows: the batch of a plan that names no column)
             lo = hi
             first = False
         rows = op.after_items()
@@ -68,15 +66,24 @@ def _slice(c, lo, hi):
     return n1o.Column(c.name, c.kind, tags=c.tags[lo:hi], payload=c.payload[lo:hi])
 
 
-def values_match(g, o, rel=REL_TOL, float_agg=False) -> bool:
+def values_match(g, o, rel=REL_TOL, float_agg=False, tie_ok=False, folded=False) -> bool:
     """(tag, value) from the device vs the oracle: tags must agree; ints/strings/bools exact; floats within rel.
     For SUM/AVG (float_agg) a float result within rel of an integral one may print as INT on one side and FLOAT on
     the other (value.NewValue folds 74.0 but not 73.99999999999999): compared numerically."""
     if g[0] != o[0]:
+        if tie_ok and {g[0], o[0]} == {n1o.T_INT, n1o.T_FLOAT}:
+            # MIN / MAX keep the first of two values that collate equal (algebra/agg_min.go:83-94): an int and the
+            # float equal to it (0 and 0.0) tie, and which one arrived first depends on the row order — in the
+            # reference's Parallel copies as much as here
+            return float(g[1]) == float(o[1])
         if float_agg and {g[0], o[0]} == {n1o.T_INT, n1o.T_FLOAT}:
             a, b = float(g[1]), float(o[1])
             return a == b or abs(a - b) <= rel * max(abs(a), abs(b))
         return False
+    if folded and g[0] == n1o.T_INT and g[1] != o[1] and min(abs(g[1]), abs(o[1])) > 2 ** 53:
+        # AVG is float64(sum) / float64(count) folded to INT when integral (algebra/agg_avg.go:136-157): beyond 2^53
+        # every float64 is integral, so this INT is a float result and carries the float tolerance
+        return abs(g[1] - o[1]) <= rel * max(abs(g[1]), abs(o[1]))
     if g[0] == n1o.T_FLOAT:
         a, b = g[1], o[1]
         if math.isnan(a) or math.isnan(b):
@@ -113,7 +120,9 @@ def assert_same_groups(gpu, ora, rel=REL_TOL, aggs: Optional[Sequence[str]] = No
         ga = gmap[k]
         for i, (g, o) in enumerate(zip(ga, oa)):
             fl = bool(aggs) and aggs[i].split("(")[0] in ("sum", "avg")
-            assert values_match(g, o, rel, fl), ("aggregate %d of group %r: device %r oracle %r" % (i, k, g, o))
+            mm = bool(aggs) and aggs[i].split("(")[0] in ("min", "max")
+            av = bool(aggs) and aggs[i].split("(")[0] == "avg"
+            assert values_match(g, o, rel, fl, mm, av), ("aggregate %d of group %r: device %r oracle %r" % (i, k, g, o))
 
 
 _CLASS = {n1o.T_MISSING: 0, n1o.T_NULL: 1, n1o.T_FALSE: 2, n1o.T_TRUE: 2, n1o.T_INT: 3, n1o.T_FLOAT: 3, n1o.T_STRING: 4,
