@@ -169,7 +169,8 @@ def assert_ordered_groups(gpu, ora, keys, aggs, order, limit=None, offset=None, 
     for (k, a) in got:  # every returned group is a group of the oracle, with the same aggregates
         oa = omap[_canon_key(k)]
         for i, (g, o) in enumerate(zip(a, oa)):
-            assert values_match(g, o, rel, aggs[i].split("(")[0] in ("sum", "avg")), (k, i, g, o)
+            f = aggs[i].split("(")[0]
+            assert values_match(g, o, rel, f in ("sum", "avg"), f in ("min", "max"), f == "avg"), (k, i, g, o)
     if not order:
         return
     for i in range(1, len(got)):  # sorted by its own values
@@ -183,6 +184,6 @@ def assert_ordered_groups(gpu, ora, keys, aggs, order, limit=None, offset=None, 
 def _near(g1, g2, order, term_value, rel):
     for text, _ in order:
         a, b = term_value(g1, text), term_value(g2, text)
-        if not values_match(a, b, rel, True):
+        if not values_match(a, b, rel, True, True, True):
             return False
     return True

@@ -135,3 +135,48 @@ def test_random_plans_agree_with_the_oracle(seed):
         pu.assert_same_groups(gpu, ora, aggs=aggs)
     except AssertionError as e:
         raise AssertionError("%s | plan: %r %r %r opts %r batches %d" % (e, cond, keys, aggs, opts, batches))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("N1K_RANDOM_SEEDS", "300")) // 3))
+def test_random_order_having_limit_agree_with_the_oracle(seed):
+    """The grouped tail on top of random plans: HAVING over an aggregate or key, ORDER BY 1-3 terms (keys / aggregates,
+    ASC / DESC), OFFSET / LIMIT — against the oracle's groups filtered and sorted here with the reference's collation."""
+    rng = np.random.default_rng(77_000 + seed)
+    t = make_table(rng, int(rng.integers(50, 4000)))
+    cond, keys, aggs = rand_plan(rng)
+    aggs = [a for a in aggs if "distinct" not in a or rng.random() < 0.5] or ["count(*)"]
+    if not keys:
+        keys = [D("b")]
+    terms = keys + aggs
+    order = [(terms[i], bool(rng.integers(0, 2))) for i in rng.choice(len(terms), int(rng.integers(1, min(3, len(terms)) + 1)), replace=False)]
+    limit = int(rng.integers(0, 30)) if rng.random() < 0.7 else None
+    offset = int(rng.integers(0, 5)) if rng.random() < 0.4 else None
+    having = None
+    hv = None
+    if rng.random() < 0.5:
+        i = int(rng.integers(0, len(terms)))
+        c = ["0", "2", "5.5", "\"a\""][rng.integers(0, 4)]
+        having = "(%s < %s)" % (c, terms[i])
+        hv = (i, c)
+    opts = {"topk_min_groups": 1} if (limit and having is None and rng.random() < 0.5) else {}
+    try:
+        gpu, _ = pu.run_gpu(t, cond, keys, aggs, batches=int(rng.integers(1, 3)), order=order, limit=limit, offset=offset,
+                            having=having, **opts)
+    except query_amd.N1kError as e:
+        if e.status in (_ffi.UNSUPPORTED, _ffi.UNSUPPORTED_DATA):
+            pytest.skip(e.message)
+        raise AssertionError("%s | %r %r %r order %r having %r" % (e, cond, keys, aggs, order, having))
+    try:
+        ora = n1o.run(t, cond, keys, aggs, threads=2)
+    except n1o.OracleError as e:
+        pytest.skip("outside the oracle's restated subset: %s" % e)
+    if hv is not None:  # c < term, with Compare's NULL / MISSING propagation: only TRUE keeps the group
+        i, c = hv
+        cv = {"0": (n1o.T_INT, 0), "2": (n1o.T_INT, 2), "5.5": (n1o.T_FLOAT, 5.5), "\"a\"": (n1o.T_STRING, b"a")}[c]
+        kept = [(k, a) for k, a in zip(ora.keys, ora.aggs)
+                if (k + a)[i][0] > n1o.T_NULL and pu.collate_values(cv, (k + a)[i]) < 0]
+        ora.keys, ora.aggs = [k for k, _ in kept], [a for _, a in kept]
+    try:
+        pu.assert_ordered_groups(gpu, ora, keys, aggs, order, limit, offset)
+    except AssertionError as e:
+        raise AssertionError("%s | %r %r %r order %r limit %r offset %r having %r opts %r" % (e, cond, keys, aggs, order, limit, offset, having, opts))
