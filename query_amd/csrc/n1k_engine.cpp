@@ -89,6 +89,7 @@ struct n1k_handle {
     // high-cardinality GROUP BY: record arrays (ping-pong per partition pass) and its tuning
     DevBuf<uint64_t> d_rec_key[3], d_rec_pay[3][kRecOperands];
     DevBuf<uint8_t> d_rec_tag[3][kRecOperands];
+    DevBuf<uint64_t> d_emit;  // the bins' partial groups before they are merged into the table
     // (measured, 100 M rows, GROUP BY cat, region_id: 6 400 groups 11.3 ms scan kernels vs 6.6 ms partitioned; 64 000 groups
     //  14.4 vs 9.8 ms: the LDS hash stage holds about a thousand groups, beyond that rows turn into global atomics)
     uint64_t opt_partition_min_rows = 8u << 20, opt_partition_probe_rows = 512u << 10, opt_partition_min_groups = 4096;
@@ -588,6 +589,29 @@ n1k_status ensure_table(n1k_handle* h, uint64_t incoming_rows) {
     return N1K_OK;
 }
 
+// the same for a known number of groups (the partitioned path counts its groups before it inserts them)
+n1k_status ensure_table_groups(n1k_handle* h, uint64_t groups) {
+    if (groups > h->opt_max_groups)
+        return fail(h, N1K_OOM, "group table capacity exceeded: raise the max_groups option (now %llu)", (unsigned long long)h->opt_max_groups);
+    uint64_t cap = next_pow2(std::max<uint64_t>(groups * 2, 1024));
+    if (cap <= h->table.capacity) return N1K_OK;
+    if (!h->table.capacity) return alloc_table(h, cap, h->table, h->d_keys, h->d_acc, h->d_rep);
+    GlobalTable nt{};
+    DevBuf<uint64_t> nk, na, nr;
+    n1k_status st = alloc_table(h, cap, nt, nk, na, nr);
+    if (st != N1K_OK) return st;
+    HIP_TRY(h, launch_rehash(h->prog, h->table, nt, h->d_errp, h->d_counters.p + 4, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->d_keys.release();
+    h->d_acc.release();
+    h->d_rep.release();
+    h->d_keys = nk;
+    h->d_acc = na;
+    h->d_rep = nr;
+    h->table = nt;
+    return N1K_OK;
+}
+
 hipEvent_t get_event(n1k_handle* h) {
     if (!h->event_pool.empty()) {
         hipEvent_t e = h->event_pool.back();
@@ -1056,7 +1080,9 @@ bool small_key_domain(const n1k_handle* h) {
 n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const PartitionPlan& pp, uint64_t groups_est) {
     Program& P = h->prog;
     const uint64_t n = b->nrows;
-    n1k_status st = ensure_table(h, n);
+    // the table is NOT sized by this batch's rows: the bins' groups are counted first (below) and the table grows to
+    // what they need — 2^24 slots instead of 2^28 for config 5, which reset and finalize then scan
+    n1k_status st = ensure_table(h, 0);
     if (st != N1K_OK) return st;
     // LDS table of the per-bin aggregation, and from it the number of partition passes
     uint32_t slots = (uint32_t)std::min<uint64_t>((64u * 1024u) / (P.lds_words * 8), 1u << 13);
@@ -1149,10 +1175,30 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
         B.lds_max_fill = std::max(1u, slots * 5 / 8);
         for (uint32_t a = 0; a < kMaxAggs; a++) B.agg_src[a] = a < P.naggs ? pp.agg_src[a] : 0xFFFFFFFFu;
         B.err_flags = h->d_errp;
+        // partial groups of the bins: at most one per record, plus one per record and SUM/AVG for the values the
+        // narrow LDS sums do not take
+        uint32_t nsum = 0;
+        for (uint32_t a = 0; a < P.naggs; a++) nsum += (P.aggs[a].kind == AGG_SUM || P.aggs[a].kind == AGG_AVG) ? 1u : 0u;
+        const uint64_t ecap = nrec * (1 + nsum) + 1024;
+        const uint64_t region_words = 2 + ecap * (1 + (uint64_t)P.glob_words);
+        HIP_TRY(h, h->d_emit.ensure(region_words));
+        HIP_TRY(h, hipMemsetAsync(h->d_emit.p, 0, 16, h->stream));
+        B.emit = h->d_emit.p;
+        B.emit_cap = ecap;
         const size_t shmem = (size_t)slots * P.lds_words * 8 + 1024;
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
         uint32_t grid = (uint32_t)std::min<uint64_t>(nbins, (uint64_t)h->num_cus * per_cu);
         HIP_TRY(h, launch_agg_bins(P, B, h->table, h->d_counters.p + 1, grid, h->stream));
+        // how many partial groups, how many groups already: the table grows to hold both, then the merge
+        unsigned long long emitted = 0, have = 0;
+        HIP_TRY(h, hipMemcpyAsync(&emitted, h->d_emit.p, sizeof emitted, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(&have, h->d_counters.p + 1, sizeof have, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        emitted = std::min<unsigned long long>(emitted, ecap);
+        st = ensure_table_groups(h, have + emitted);
+        if (st != N1K_OK) return st;
+        HIP_TRY(h, launch_merge_partials(P, h->table, 1, ecap, h->d_emit.p, region_words, h->d_errp, h->d_counters.p + 1,
+                                         h->stream, emitted));
     }
     if (e1) (void)hipEventRecord(e1, h->stream);
     h->events.emplace_back(e0, e1);
@@ -1362,6 +1408,7 @@ void n1k_destroy(n1k_handle* h) {
         h->d_wide_int.release();
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
+        h->d_emit.release();
         for (int i = 0; i < 3; i++) {
             h->d_rec_key[i].release();
             for (uint32_t e = 0; e < kRecOperands; e++) {

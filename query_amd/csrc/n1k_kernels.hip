@@ -1415,28 +1415,10 @@ __global__ void export_partials_kernel(const Program P, const GlobalTable G, uin
     for (uint32_t w = 0; w < P.glob_words; w++) acc[w] = G.acc[(size_t)s * P.glob_words + w];
 }
 
-// merge received partial groups into this GPU's table (one thread per record)
-__global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint32_t nregions, uint64_t cap,
-                                      const uint64_t* in, uint64_t region_words, uint32_t* err_flags,
-                                      unsigned long long* ngroups) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t r = (uint32_t)(i / cap);
-    uint64_t pos = i % cap;
-    if (r >= nregions) return;
-    // a sender that could not export (see export_partials_kernel) voids the whole exchange: nothing is merged and
-    // n1k_finish reports it, on every rank alike
-    uint64_t verdict = 0;
-    for (uint32_t q = 0; q < nregions; q++) verdict |= in[(size_t)q * region_words + 1];
-    if (verdict) {
-        if (i == 0) atomicOr(err_flags, (uint32_t)(((verdict & 1ull) ? ERR_EXCHANGE_OVERFLOW : 0u) | ((verdict & 2ull) ? ERR_EXCHANGE_WIDE : 0u)));
-        return;
-    }
-    const uint64_t* region = in + (size_t)r * region_words;
-    uint64_t count = region[0] < cap ? region[0] : cap;
-    if (pos >= count) return;
-    uint64_t key = region[2 + pos];
-    const uint64_t* l = region + 2 + cap + pos * P.glob_words;
-    long long g = global_find_or_insert(G, key, err_flags, ngroups);
+// CumulateIntermediate of one partial group (packed key + raw global accumulators) into the table
+N1K_DEV void merge_partial_record(const Program& P, const GlobalTable& G, uint64_t key, const uint64_t* l, uint32_t* err_flags,
+                                  bool& fresh) {
+    long long g = global_find_or_insert_quiet(G, key, err_flags, fresh);
     if (g < 0) return;
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
@@ -1473,6 +1455,31 @@ __global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint
     }
 }
 
+// merge received partial groups into this GPU's table (one thread per record)
+__global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint32_t nregions, uint64_t cap,
+                                      const uint64_t* in, uint64_t region_words, uint32_t* err_flags,
+                                      unsigned long long* ngroups) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = (uint32_t)(i / cap);
+    uint64_t pos = i % cap;
+    if (r >= nregions) return;
+    // a sender that could not export (see export_partials_kernel) voids the whole exchange: nothing is merged and
+    // n1k_finish reports it, on every rank alike
+    uint64_t verdict = 0;
+    for (uint32_t q = 0; q < nregions; q++) verdict |= in[(size_t)q * region_words + 1];
+    if (verdict) {
+        if (i == 0) atomicOr(err_flags, (uint32_t)(((verdict & 1ull) ? ERR_EXCHANGE_OVERFLOW : 0u) | ((verdict & 2ull) ? ERR_EXCHANGE_WIDE : 0u)));
+        return;
+    }
+    const uint64_t* region = in + (size_t)r * region_words;
+    uint64_t count = region[0] < cap ? region[0] : cap;
+    bool fresh = false;
+    if (pos < count) merge_partial_record(P, G, region[2 + pos], region + 2 + cap + pos * P.glob_words, err_flags, fresh);
+    // new groups: one atomic on the counter per wave (per new group they serialise on one address: 4 ns each)
+    const unsigned long long m = __ballot(fresh);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(ngroups, (unsigned long long)__popcll(m));
+}
+
 // grow the global table: re-insert every occupied slot (keys keep their packed form)
 __global__ void rehash_kernel(const Program P, const GlobalTable oldt, const GlobalTable newt, uint32_t* err_flags,
                               unsigned long long* scratch) {
@@ -1480,7 +1487,8 @@ __global__ void rehash_kernel(const Program P, const GlobalTable oldt, const Glo
     if (s >= oldt.capacity) return;
     uint64_t key = oldt.keys[s];
     if (key == kEmptyKey) return;
-    long long g = global_find_or_insert(newt, key, err_flags, scratch);
+    bool fresh = false;  // (the group count does not change: no counter)
+    long long g = global_find_or_insert_quiet(newt, key, err_flags, fresh);
     if (g < 0) return;
     for (uint32_t w = 0; w < P.glob_words; w++) newt.acc[(size_t)g * P.glob_words + w] = oldt.acc[(size_t)s * P.glob_words + w];
     if (newt.rep_row && oldt.rep_row) newt.rep_row[g] = oldt.rep_row[s];
@@ -1733,6 +1741,8 @@ __global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const 
                                                         unsigned long long* ngroups) {
     extern __shared__ uint64_t lds[];
     __shared__ uint32_t lds_fill;
+    __shared__ uint32_t emit_wave_cnt[BLOCK / 64];
+    __shared__ unsigned long long emit_base;
     const uint32_t S = A.lds_slots, tid = threadIdx.x;
     uint32_t new_groups = 0;
     for (uint32_t bin = blockIdx.x; bin < A.nbins; bin += gridDim.x) {
@@ -1753,7 +1763,23 @@ __global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const 
             }
             const int slot = lds_find_or_insert(lds, S, key, &lds_fill, A.lds_max_fill);
             long long grow = -1;
-            if (slot < 0) {  // more groups in the bin than the LDS table takes: straight to the global table
+            if (slot < 0 && A.emit) {
+                // more groups in the bin than the LDS table takes: the row leaves as a group of its own
+                const unsigned long long q = atomicAdd((unsigned long long*)&A.emit[0], 1ull);
+                if (q >= A.emit_cap) {
+                    atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                    continue;
+                }
+                A.emit[2 + q] = key;
+                uint64_t* row = A.emit + 2 + A.emit_cap + q * P.glob_words;
+                glob_row_init(P, row);
+                for (uint32_t a = 0; a < P.naggs; a++) {
+                    const uint32_t e = A.agg_src[a];
+                    acc_global(P, P.aggs[a], row, e < kRecOperands ? vt[e] : (uint32_t)T_NULL, e < kRecOperands ? vp[e] : 0ull);
+                }
+                continue;
+            }
+            if (slot < 0) {  // the same, straight to the global table
                 grow = global_find_or_insert(G, key, A.err_flags, ngroups);
                 if (grow < 0) continue;
             }
@@ -1764,14 +1790,46 @@ __global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const 
                 const uint64_t p = e < kRecOperands ? vp[e] : 0ull;
                 if (slot >= 0) {
                     if (!acc_lds(P, ag, lds, S, (uint32_t)slot, t, p)) {
-                        if (grow < 0) grow = global_find_or_insert(G, key, A.err_flags, ngroups);
-                        if (grow >= 0) acc_global(P, ag, &G.acc[(size_t)grow * P.glob_words], t, p);
+                        // a value the narrow LDS accumulators do not take (|int| >= 2^40)
+                        if (A.emit) {  // leaves as a partial group of its own that holds just this contribution
+                            const unsigned long long q = atomicAdd((unsigned long long*)&A.emit[0], 1ull);
+                            if (q < A.emit_cap) {
+                                A.emit[2 + q] = key;
+                                uint64_t* row = A.emit + 2 + A.emit_cap + q * P.glob_words;
+                                glob_row_init(P, row);
+                                acc_global(P, ag, row, t, p);
+                            } else
+                                atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                        } else {
+                            if (grow < 0) grow = global_find_or_insert(G, key, A.err_flags, ngroups);
+                            if (grow >= 0) acc_global(P, ag, &G.acc[(size_t)grow * P.glob_words], t, p);
+                        }
                     }
                 } else
                     acc_global(P, ag, &G.acc[(size_t)grow * P.glob_words], t, p);
             }
         }
         __syncthreads();
+        if (A.emit) {
+            // the bin's groups leave as partial groups [key][raw accumulators] in one compact region: their exact number
+            // sizes the global table before they are merged into it (merge_partials_kernel)
+            uint32_t mine = 0;
+            for (uint32_t s = tid; s < S; s += BLOCK) mine += lds[s] != kEmptyKey ? 1u : 0u;
+            unsigned long long q = tile_reserve<BLOCK>(mine, (unsigned long long*)&A.emit[0], emit_wave_cnt, &emit_base, tid);
+            for (uint32_t s = tid; s < S; s += BLOCK) {
+                const uint64_t key = lds[s];
+                if (key == kEmptyKey) continue;
+                if (q < A.emit_cap) {
+                    A.emit[2 + q] = key;
+                    uint64_t* row = A.emit + 2 + A.emit_cap + q * P.glob_words;
+                    glob_row_init(P, row);
+                    merge_slot(P, lds, S, s, row);
+                } else
+                    atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                q++;
+            }
+            continue;
+        }
         // the bin's groups go to the global table once (≙ IntermediateGroup, execution/group_intermediate.go:56-104)
         for (uint32_t s = tid; s < S; s += BLOCK) {
             const uint64_t key = lds[s];
@@ -2224,8 +2282,10 @@ hipError_t launch_export_partials(const Program& P, const GlobalTable& G, uint32
 }
 
 hipError_t launch_merge_partials(const Program& P, const GlobalTable& G, uint32_t nregions, uint64_t cap, const uint64_t* in,
-                                 uint64_t region_words, uint32_t* err_flags, unsigned long long* ngroups, hipStream_t st) {
+                                 uint64_t region_words, uint32_t* err_flags, unsigned long long* ngroups, hipStream_t st,
+                                 uint64_t limit) {
     uint64_t total = (uint64_t)nregions * cap;
+    if (nregions == 1 && limit && limit < total) total = limit;  // one region whose count the caller knows
     if (!total) return hipSuccess;
     uint32_t blocks = (uint32_t)((total + 255) / 256);
     hipLaunchKernelGGL(merge_partials_kernel, dim3(blocks), dim3(256), 0, st, P, G, nregions, cap, in, region_words, err_flags, ngroups);

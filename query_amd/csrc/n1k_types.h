@@ -242,6 +242,10 @@ struct BinAggArgs {
     uint32_t lds_slots, lds_max_fill;
     uint32_t agg_src[kMaxAggs];  // operand slot of every aggregate, 0xFFFFFFFF = none (count(*))
     uint32_t* err_flags;
+    // when set: the bins' groups are appended to this region ([count][0][keys: emit_cap][accumulators]) instead of
+    // being merged into the global table
+    uint64_t* emit;
+    uint64_t emit_cap;
 };
 
 struct DedupeArgs {
