@@ -110,6 +110,7 @@ struct n1k_handle {
     std::vector<std::vector<uint64_t>> js_payload;
     std::vector<n1k_col> js_cols;
     uint32_t opt_json_threads = 0;  // 0 = hardware concurrency (at most 16)
+    bool out_count_dirty = true;  // the finalize position counter holds a previous finish's count
     char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
     size_t pin_cap = 0;
     std::string jit_log;
@@ -1452,6 +1453,7 @@ n1k_status n1k_reset(n1k_handle* h) {
         }
         h->stats.device_ms = 0;
         h->groups_seen = 0;
+        h->out_count_dirty = false;
         // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
@@ -1946,7 +1948,8 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
                 h->pin_cap = total + sizeof counters;
             }
             char* d = h->d_out.p;
-            HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
+            if (h->out_count_dirty) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
+            h->out_count_dirty = true;  // (reopen zeroes every counter in its one launch)
             HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
                                        (uint64_t*)(d + off_rep), h->d_counters.p + 2, spec_groups, h->d_errp, h->stream));
             HIP_TRY(h, hipMemcpyAsync(h->pin_out, d, total, hipMemcpyDeviceToHost, h->stream));
@@ -2029,7 +2032,8 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
         if (!spec_hit) {
             HIP_TRY(h, h->d_out.ensure(total + 16));
             char* d = h->d_out.p;
-            HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
+            if (h->out_count_dirty) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
+            h->out_count_dirty = true;  // (reopen zeroes every counter in its one launch)
             HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
                                        (uint64_t*)(d + off_rep), h->d_counters.p + 2, ng, h->d_errp, h->stream));
             const uint64_t keep = pl.limit >= 0 ? (uint64_t)pl.offset + (uint64_t)pl.limit : ng;

@@ -1614,15 +1614,15 @@ N1K_DEV void finalize_agg(const Program& P, const AggSpec& ag, const uint64_t* g
 
 // Output positions are handed out per workgroup CHUNK (count the chunk's groups, one atomic, then ranks inside the
 // chunk): one same-address atomic per group cost 24 ms for 6.4 M groups.
-constexpr uint32_t kFinalizeChunk = 16384;  // table slots per workgroup
+constexpr uint32_t kFinalizeChunkMax = 16384;  // table slots per workgroup: capacity / 4096, within [256, 16384]
 __global__ __launch_bounds__(256) void finalize_kernel(const Program P, const GlobalTable G, OutValue* out_keys, OutValue* out_aggs,
                                                        OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count,
-                                                       uint64_t max_out, uint32_t* err_flags) {
+                                                       uint64_t max_out, uint32_t* err_flags, uint32_t chunk) {
     __shared__ uint32_t wave_cnt[4];
     __shared__ unsigned long long chunk_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t lo = (uint64_t)blockIdx.x * kFinalizeChunk;
-    const uint64_t hi = lo + kFinalizeChunk < G.capacity ? lo + kFinalizeChunk : G.capacity;
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+    const uint64_t hi = lo + chunk < G.capacity ? lo + chunk : G.capacity;
     // pass 1: groups in the chunk
     uint32_t mine = 0;
     for (uint64_t s = lo + tid; s < hi; s += 256) mine += G.keys[s] != kEmptyKey ? 1u : 0u;
@@ -2307,9 +2307,12 @@ hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, 
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,
                            OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count, uint64_t max_out,
                            uint32_t* err_flags, hipStream_t st) {
-    uint32_t blocks = (uint32_t)((G.capacity + kFinalizeChunk - 1) / kFinalizeChunk);
+    // small tables: one 256-slot step per workgroup (no serial loop); big tables: fewer, longer chunks so that the
+    // position counter sees thousands of atomics, not millions
+    uint32_t chunk = (uint32_t)std::min<uint64_t>(kFinalizeChunkMax, std::max<uint64_t>(256, (G.capacity / 4096 + 255) / 256 * 256));
+    uint32_t blocks = (uint32_t)((G.capacity + chunk - 1) / chunk);
     hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, P, G, out_keys, out_aggs, out_parts, out_rep,
-                       out_count, max_out, err_flags);
+                       out_count, max_out, err_flags, chunk);
     return hipGetLastError();
 }
 
