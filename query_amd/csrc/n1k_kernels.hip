@@ -1399,12 +1399,25 @@ __global__ void export_partials_kernel(const Program P, const GlobalTable G, uin
     // retry without a second collective): bit 0 = some region overflowed, bit 1 = keys hold device-local wide codes
     if (s == 0 && P.wide_count && *P.wide_count)
         for (uint32_t r = 0; r < nparts; r++) atomicOr((unsigned long long*)&out[(size_t)r * region_words + 1], 2ull);
-    if (s >= G.capacity) return;
-    uint64_t key = G.keys[s];
-    if (key == kEmptyKey) return;
-    uint32_t d = (uint32_t)(((mix64(key) >> 32) * (uint64_t)nparts) >> 32);
+    const uint64_t key = s < G.capacity ? G.keys[s] : kEmptyKey;
+    const bool used = key != kEmptyKey;
+    const uint32_t d = used ? (uint32_t)(((mix64(key) >> 32) * (uint64_t)nparts) >> 32) : 0xFFFFFFFFu;
+    // positions: one atomic per wave and destination (a thousand same-address atomics cost ~10 us on their own)
+    unsigned long long pos = 0;
+    unsigned long long todo = __ballot(used);
+    const uint32_t lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t dl = __shfl(d, leader, 64);
+        const unsigned long long same = __ballot(used && d == dl);
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd((unsigned long long*)&out[(size_t)dl * region_words], (unsigned long long)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if (used && d == dl) pos = base + (unsigned long long)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if (!used) return;
     uint64_t* region = out + (size_t)d * region_words;
-    unsigned long long pos = atomicAdd((unsigned long long*)&region[0], 1ull);
     if (pos >= cap) {
         if (!(atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL) & ERR_TABLE_FULL))
             for (uint32_t r = 0; r < nparts; r++) atomicOr((unsigned long long*)&out[(size_t)r * region_words + 1], 1ull);
