@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--workload", default="config2")
-    ap.add_argument("--kcat", type=int, default=1000)
+    ap.add_argument("--kcat", type=int, default=None, help="distinct cat values (default: 1000; 100000 for config5*, as BASELINE.json names them)")
     ap.add_argument("--zipf", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -151,6 +151,8 @@ def main():
                          "partials = always the hash-partitioned partial groups; rows = always the filtered rows")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank")
     args = ap.parse_args()
+    if args.kcat is None:
+        args.kcat = 100_000 if args.workload.startswith("config5") else 1000
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -308,11 +308,12 @@ def bench_main(args, rank: int, world: int, local_rank: int):
             raw, info = op.run_partials(args.rows, cols.by_path, want_rows_selected=last)
         else:
             raw, info = op.run_gathered(args.rows, cols.by_path, want_rows_selected=last)
+        if info.get("mode") == "gathered partials":
+            # every rank already merged every rank's partial groups: its result (raw["keys"], raw["aggs"]) is complete
+            return raw["keys"], info
         rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
                               raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1) \
             if raw["ngroups"] else np.zeros((0, 16 * (raw["nkeys"] + raw["naggs"])), np.uint8)
-        if info.get("mode") == "gathered partials":
-            return rec, info  # every rank already merged every rank's partial groups: the result is complete
         if gather is None:
             gather = FixedGather(rec.shape[1], capacity=max(1024, 2 * rec.shape[0]))
         allg = gather(rec, dev)  # every rank holds the result; rank 0 reports it
