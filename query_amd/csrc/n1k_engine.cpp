@@ -1786,7 +1786,29 @@ static int host_collate(const n1k_handle* h, const n1k_value& a, const n1k_value
         case 2: return (int)(a.tag == N1K_T_TRUE) - (int)(b.tag == N1K_T_TRUE);
         case 3: {
             if (a.tag == N1K_T_INT && b.tag == N1K_T_INT) return a.v.i < b.v.i ? -1 : (a.v.i > b.v.i ? 1 : 0);
-            const double x = a.tag == N1K_T_INT ? (double)a.v.i : a.v.f, y = b.tag == N1K_T_INT ? (double)b.v.i : b.v.f;
+            if (a.tag != b.tag) {
+                // The reference compares an int with a float through float64 (value/float.go:106-121) while two ints
+                // compare exactly: beyond 2^53 that is not transitive (858 < 859, yet both equal the float between
+                // them) and sort.Sort's result is then arbitrary.  A sort needs a strict weak order: the int and the
+                // float are compared exactly here — the same answer wherever the reference's is well defined.
+                const bool a_int = a.tag == N1K_T_INT;
+                const int64_t i = a_int ? a.v.i : b.v.i;
+                const double d = a_int ? b.v.f : a.v.f;
+                int c;  // sign of (i - d)
+                if (d != d) c = 1;  // NaN sorts first
+                else if (d >= 9223372036854775808.0) c = -1;
+                else if (d < -9223372036854775808.0) c = 1;
+                else {
+                    const int64_t t = (int64_t)d;  // truncation toward zero, exact in range
+                    if (i != t) c = i < t ? -1 : 1;
+                    else {
+                        const double frac = d - (double)t;
+                        c = frac > 0 ? -1 : (frac < 0 ? 1 : 0);
+                    }
+                }
+                return a_int ? c : -c;
+            }
+            const double x = a.v.f, y = b.v.f;
             if (x != x) return (y != y) ? 0 : -1;  // NaN sorts first
             if (y != y) return 1;
             return x < y ? -1 : (x > y ? 1 : 0);

@@ -11,6 +11,10 @@ from query_amd import _ffi, plan as qplan
 from oracle import n1o
 
 REL_TOL = 1e-9  # north_star: float SUM/AVG within 1e-9 relative; everything else bit-exact
+# Sums of terms of both signs can cancel to (almost) zero, where no relative bound holds — the reference's own result
+# then depends on the arrival order of the rows.  The random-plan tests (small magnitudes by construction) allow this
+# absolute slack on float SUM / AVG; every other test keeps it at 0.
+ABS_TOL = 0.0
 
 
 def run_gpu(table: n1o.Table, condition: Optional[str], keys: Sequence[str], aggs: Sequence[str], *,
@@ -78,11 +82,17 @@ def values_match(g, o, rel=REL_TOL, float_agg=False, tie_ok=False, folded=False)
             return float(g[1]) == float(o[1])
         if float_agg and {g[0], o[0]} == {n1o.T_INT, n1o.T_FLOAT}:
             a, b = float(g[1]), float(o[1])
-            return a == b or abs(a - b) <= rel * max(abs(a), abs(b))
+            return a == b or abs(a - b) <= rel * max(abs(a), abs(b)) or abs(a - b) <= ABS_TOL
         return False
-    if folded and g[0] == n1o.T_INT and g[1] != o[1] and min(abs(g[1]), abs(o[1])) > 2 ** 53:
-        # AVG is float64(sum) / float64(count) folded to INT when integral (algebra/agg_avg.go:136-157): beyond 2^53
-        # every float64 is integral, so this INT is a float result and carries the float tolerance
+    if tie_ok and g[0] == n1o.T_INT and g[1] != o[1] and min(abs(g[1]), abs(o[1])) > 2 ** 53:
+        # value.Collate compares two ints exactly but an int with a float through float64 (value/integer.go:100-118,
+        # float.go:106-121): beyond 2^53 that order is not transitive (858 < 859 yet both tie with the float between
+        # them), so MIN / MAX over such a mix depend on the arrival order in the reference (and in the oracle's
+        # worker threads).  Any int the float64 image cannot tell apart is a correct answer.
+        return float(g[1]) == float(o[1])
+    if folded and g[0] == n1o.T_INT and g[1] != o[1]:
+        # AVG is float64(sum) / float64(count) folded to INT when integral (algebra/agg_avg.go:136-157): an INT here is
+        # a float result and carries the float tolerance (which only large magnitudes can use: ints differ by >= 1)
         return abs(g[1] - o[1]) <= rel * max(abs(g[1]), abs(o[1]))
     if g[0] == n1o.T_FLOAT:
         a, b = g[1], o[1]
@@ -90,7 +100,7 @@ def values_match(g, o, rel=REL_TOL, float_agg=False, tie_ok=False, folded=False)
             return math.isnan(a) and math.isnan(b)
         if a == b:
             return True
-        return abs(a - b) <= rel * max(abs(a), abs(b))
+        return abs(a - b) <= rel * max(abs(a), abs(b)) or (float_agg and abs(a - b) <= ABS_TOL)
     return g[1] == o[1]
 
 
@@ -182,8 +192,11 @@ def assert_ordered_groups(gpu, ora, keys, aggs, order, limit=None, offset=None, 
 
 
 def _near(g1, g2, order, term_value, rel):
+    """May two rows trade places?  Term by term: identical values defer to the next term; values that only agree within
+    the float tolerance make the order a matter of rounding (either is right); values further apart do not."""
     for text, _ in order:
         a, b = term_value(g1, text), term_value(g2, text)
-        if not values_match(a, b, rel, True, True, True):
-            return False
+        if a == b:
+            continue
+        return values_match(a, b, rel, True, True, True)
     return True
