@@ -144,3 +144,49 @@ def test_threads_agree_and_share_one_dictionary():
     assert [_decode(a, c) for c in ca] == [_decode(b, c) for c in cb]
     a.done()
     b.done()
+
+
+def _rand_value(rng, depth=0):
+    r = rng.integers(0, 12)
+    if r < 3:
+        return int(rng.integers(-10 ** int(rng.integers(0, 19)), 10 ** int(rng.integers(0, 19)) + 1))
+    if r < 5:
+        return float(rng.integers(-10 ** 6, 10 ** 6)) / float(10 ** int(rng.integers(0, 8))) * (10.0 ** int(rng.integers(-3, 4)))
+    if r < 7:
+        alphabet = ["a", "b", " ", "\"", "\\", "\n", "\t", "é", "ü", "€", "\U0001F600", "/", "\x01", "z"]
+        return "".join(alphabet[i] for i in rng.integers(0, len(alphabet), int(rng.integers(0, 8))))
+    if r == 7:
+        return [True, False, None][rng.integers(0, 3)]
+    if depth >= 3 or r == 8:
+        return int(rng.integers(0, 5))
+    if r < 10:
+        return [_rand_value(rng, depth + 1) for _ in range(int(rng.integers(0, 4)))]
+    return {"k%d" % rng.integers(0, 5): _rand_value(rng, depth + 1) for _ in range(int(rng.integers(0, 4)))}
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("N1K_JSON_SEEDS", "40"))))
+def test_random_documents_match_the_python_extraction(seed):
+    """Random nested documents (escapes, non-BMP characters, 19-digit ints, exponents, nested paths) through the C++
+    scanner against json.loads + the golden tests' typing / canonical-text rules."""
+    rng = np.random.default_rng(500 + seed)
+    fields = ["a", "b", "c", "n"]
+    docs = []
+    for _ in range(200):
+        d = {}
+        for f in fields:
+            if rng.random() < 0.85:
+                d[f] = _rand_value(rng)
+        if rng.random() < 0.5:
+            d["n"] = {"x": _rand_value(rng, 2), "y": {"z": _rand_value(rng, 3)}}
+        docs.append({"doc": d})
+    paths = [D("a"), D("b"), D("c"), D("n", "x")]
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(None, paths, ["count(%s)" % D("n", "y", "z")]))
+    paths = op.column_paths
+    raw = [json.dumps(d["doc"], ensure_ascii=bool(rng.integers(0, 2)),
+                      separators=((",", ":") if rng.integers(0, 2) else (", ", ": "))).encode() for d in docs]
+    got = [_decode(op, c) for c in op.extract_json(raw)]
+    exp = _expected(gu.build_table(docs, paths))
+    for c, (g, e) in enumerate(zip(got, exp)):
+        for r, (x, y) in enumerate(zip(g, e)):
+            assert x == y, (paths[c], r, raw[r], x, y)
+    op.done()
