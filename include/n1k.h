@@ -340,6 +340,14 @@ n1k_status n1k_export_partials_device(n1k_handle *h, uint32_t nparts, uint64_t c
 n1k_status n1k_export_partials_async(n1k_handle *h, uint32_t nparts, uint64_t capacity_groups, void *out);
 n1k_status n1k_merge_partials_device(n1k_handle *h, uint32_t nregions, uint64_t capacity_groups, const void *in);
 n1k_status n1k_export_groups(n1k_handle *h, const void **blob, size_t *len);
+
+/*
+ * The multi-GPU tail of ORDER BY ... OFFSET ... LIMIT: when groups are owned by several handles of the same plan and
+ * dictionary (disjoint key ranges after the hash partition), each owner returns its first offset+limit rows and
+ * rank 0 applies the plan's Order / Offset / Limit to their union (≙ execution/order.go:121-169 over the gathered rows).
+ * Host only; `out` belongs to the handle like n1k_finish's.
+ */
+n1k_status n1k_order_rows(n1k_handle *h, uint64_t ngroups, const n1k_value *keys, const n1k_value *aggs, n1k_result *out);
 n1k_status n1k_merge_groups(n1k_handle *h, const void *blob, size_t len);
 
 /* ------------------------------------------------------------- utilities -- */

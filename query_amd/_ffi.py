@@ -72,7 +72,7 @@ SYMBOLS = [
     "n1k_create", "n1k_destroy", "n1k_reset", "n1k_stop", "n1k_last_error", "n1k_create_error", "n1k_num_columns",
     "n1k_column_path", "n1k_num_keys", "n1k_num_aggregates", "n1k_aggregate_name", "n1k_dict_intern", "n1k_dict_size",
     "n1k_dict_get", "n1k_set_option", "n1k_push_batch", "n1k_extract_json", "n1k_push_json", "n1k_push_device_batch", "n1k_sync", "n1k_finish",
-    "n1k_get_stats", "n1k_partition_device_batch", "n1k_export_groups", "n1k_merge_groups", "n1k_synth_columns",
+    "n1k_get_stats", "n1k_partition_device_batch", "n1k_export_groups", "n1k_order_rows", "n1k_merge_groups", "n1k_synth_columns",
     "n1k_jit_check", "n1k_partial_words", "n1k_partial_region_bytes", "n1k_export_partials_device", "n1k_export_partials_async",
     "n1k_merge_partials_device",
     "n1k_abi_version", "n1k_device_count",
@@ -144,6 +144,8 @@ def lib():
     L.n1k_export_groups.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.n1k_merge_groups.restype = C.c_int
     L.n1k_merge_groups.argtypes = [H, C.c_void_p, C.c_size_t]
+    L.n1k_order_rows.restype = C.c_int
+    L.n1k_order_rows.argtypes = [H, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(Result)]
     L.n1k_jit_check.restype = C.c_int
     L.n1k_jit_check.argtypes = [H, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
     L.n1k_partial_words.restype = C.c_uint32

@@ -1687,7 +1687,10 @@ n1k_status n1k_sync(n1k_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     drain_events(h);
-    if (h->plan.has_group) h->stats.rows_selected = counters[0];
+    if (h->plan.has_group) {
+        h->stats.rows_selected = counters[0];
+        h->stats.groups_out = counters[1];  // groups in the table so far
+    }
     h->stats.wide_key_values = counters[13];
     return N1K_OK;
 }
@@ -2149,6 +2152,32 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     out->partials = h->r_parts.data();
     out->rep_row = h->r_rep.data();
     h->stats.groups_out = ng;
+    return N1K_OK;
+}
+
+n1k_status n1k_order_rows(n1k_handle* h, uint64_t ngroups, const n1k_value* keys, const n1k_value* aggs, n1k_result* out) {
+    if (!h || !out || (ngroups && ((!keys && !h->plan.keys.empty()) || (!aggs && !h->plan.aggs.empty())))) return N1K_INVALID;
+    if (!h->plan.has_group) return fail(h, N1K_INVALID, "no groups in a Filter-only plan");
+    const size_t nk = h->plan.keys.size(), na = h->plan.aggs.size();
+    memset(out, 0, sizeof *out);
+    out->nkeys = (uint32_t)nk;
+    out->naggs = (uint32_t)na;
+    for (uint64_t i = 0; i < ngroups * (nk + na); i++) {
+        const n1k_value& v = i < ngroups * nk ? keys[i] : aggs[i - ngroups * nk];
+        if (v.tag >= N1K_T_STRING && v.v.code >= h->dict.size()) return fail(h, N1K_INVALID, "a value's dictionary code is unknown to this handle");
+    }
+    h->r_keys.assign(keys, keys + ngroups * nk);
+    h->r_aggs.assign(aggs, aggs + ngroups * na);
+    h->r_parts.clear();
+    h->r_rep.assign((size_t)ngroups, ~0ull);
+    uint64_t ng = ngroups;
+    n1k_status st = order_groups(h, ng);
+    if (st != N1K_OK) return st;
+    out->ngroups = ng;
+    out->keys = h->r_keys.data();
+    out->aggs = h->r_aggs.data();
+    out->partials = nullptr;
+    out->rep_row = h->r_rep.data();
     return N1K_OK;
 }
 

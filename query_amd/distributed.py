@@ -113,21 +113,35 @@ class ShardedFilterGroup:
     """One rank's share of the distributed operator (device path through libn1k.so)."""
 
     def __init__(self, condition: Optional[str], keys: Sequence[str], aggs: Sequence[str], dictionary: Sequence[bytes],
-                 rank: int, world: int, device: int, **options):
+                 rank: int, world: int, device: int, order=None, limit=None, offset=None, having=None, **options):
         import query_amd
         from query_amd import plan
         self.rank, self.world, self.device = rank, world, device
+        self.tail = order is not None or limit is not None or offset is not None or having is not None
         # sender: Filter + key evaluation; receiver: the same grouping without the Filter (it was applied already)
         import torch
         # one stream for both handles and for torch (RCCL work is ordered against it by c10d's events)
         self.stream = torch.cuda.Stream(device=torch.device("cuda", device))
         self.sender = query_amd.GpuFilterGroup(plan.filter_group_plan(condition, keys, aggs), device=device,
                                                stream=self.stream.cuda_stream)
-        self.receiver = query_amd.GpuFilterGroup(plan.filter_group_plan(None, keys, aggs), device=device,
-                                                 stream=self.stream.cuda_stream, **options)
-        self._recv_ready = False
+        # The grouped tail (HAVING, ORDER BY, OFFSET, LIMIT) belongs to whoever holds COMPLETE groups: `receiver` is the
+        # owner of a hash range (row / partial-group exchange) and keeps its first offset+limit rows after HAVING;
+        # `merger` holds the exact tail: it merges all ranks' partial groups in the gathered mode, and orders the
+        # union of the owners' rows otherwise (n1k_order_rows).
+        owner_limit = None if limit is None else int(limit) + int(offset or 0)
+        self.receiver = query_amd.GpuFilterGroup(
+            plan.filter_group_plan(None, keys, aggs, order=order, limit=owner_limit, having=having) if self.tail
+            else plan.filter_group_plan(None, keys, aggs), device=device, stream=self.stream.cuda_stream, **options)
+        self.merger = query_amd.GpuFilterGroup(
+            plan.filter_group_plan(None, keys, aggs, order=order, limit=limit, offset=offset, having=having),
+            device=device, stream=self.stream.cuda_stream, **options) if self.tail else self.receiver
+        self._recv_ready = set()
+        self._cap_known = False
+        self._gather = None
         self.sender.intern(list(dictionary))
         self.receiver.intern(list(dictionary))
+        if self.merger is not self.receiver:
+            self.merger.intern(list(dictionary))
         self.send_paths = self.sender.column_paths
         self.recv_paths = self.receiver.column_paths
         self._bufs = None
@@ -161,18 +175,19 @@ class ShardedFilterGroup:
         import torch.distributed as dist
         from query_amd import _ffi
         from query_amd.gpu_operator import N1kError
-        snd, rcv = self.sender, self.receiver  # Filter + InitialGroup over the shard; owner-side merge + FinalGroup
+        snd = self.sender  # Filter + InitialGroup over the shard
         lib = snd._lib
         dev = torch.device("cuda", self.device)
         with torch.cuda.stream(self.stream):
-            if not self._recv_ready:  # the owner handle needs the key layout (column kinds) before it can merge
-                rcv.process_device_items(0, [cols_by_path[p] for p in self.recv_paths])
-                self._recv_ready = True
             while True:
                 cap = self.partial_capacity
                 region = int(lib.n1k_partial_region_bytes(snd._h, cap))
                 # the same on every rank: capacities only change on verdicts that all ranks see
                 gathered = replicate and region * self.world <= self.GATHER_LIMIT
+                rcv = self.merger if gathered else self.receiver  # merge + FinalGroup (+ the grouped tail)
+                if id(rcv) not in self._recv_ready:  # the merging handle needs the key layout (column kinds) first
+                    rcv.process_device_items(0, [cols_by_path[p] for p in self.recv_paths])
+                    self._recv_ready.add(id(rcv))
                 nsend = 1 if gathered else self.world
                 if self._pbuf is None or self._pbuf[0].numel() != region * nsend or self._pbuf[1].numel() != region * self.world:
                     self._pbuf = (torch.empty(region * nsend, dtype=torch.uint8, device=dev),
@@ -180,6 +195,22 @@ class ShardedFilterGroup:
                 send, recv = self._pbuf
                 snd.reopen()
                 snd.process_device_items(nrows, [cols_by_path[p] for p in self.send_paths])
+                if not self._cap_known:
+                    # first step: size the regions from the number of groups the shards really hold (one small
+                    # all-reduce) instead of climbing there by x4 retries that each repeat the scan
+                    snd.sync()
+                    ng = torch.tensor([int(snd.stats()["groups_out"])], dtype=torch.int64, device=dev)
+                    dist.all_reduce(ng, op=dist.ReduceOp.MAX)
+                    ng = int(ng.item())
+                    self._cap_known = True
+                    full = 1 << max(12, int(np.ceil(np.log2(ng * 1.25 + 64))))
+                    if replicate and int(lib.n1k_partial_region_bytes(snd._h, full)) * self.world <= self.GATHER_LIMIT:
+                        want = full
+                    else:
+                        want = 1 << max(12, int(np.ceil(np.log2(ng / self.world * 1.5 + 64))))
+                    if want != cap:
+                        self.partial_capacity = want
+                        continue
                 snd._check(lib.n1k_export_partials_async(snd._h, nsend, cap, send.data_ptr()))
                 if gathered:
                     dist.all_gather_into_tensor(recv, send)  # region r = rank r's partial groups, on every rank
@@ -206,6 +237,28 @@ class ShardedFilterGroup:
         return raw, {"mode": "gathered partials" if gathered else "partials", "region_bytes": region,
                      "rows_selected": int(stats["rows_selected"]) if want_rows_selected else None,
                      "scan_ms": float(stats["device_ms"]), "spec_kernel": int(stats["spec_kernel"])}
+
+    def combine(self, raw: dict, info: dict, device) -> Tuple[np.ndarray, np.ndarray]:
+        """The job's result on every rank as (keys, aggs) structured arrays: in the gathered mode the merging handle
+        already holds it; otherwise the owners' rows are gathered (one all-gather) and, when the plan has a grouped
+        tail, ordered and cut by the merger handle (n1k_order_rows)."""
+        from query_amd.gpu_operator import GpuFilterGroup
+        if info.get("mode") == "gathered partials":
+            return raw["keys"], raw["aggs"]
+        nk, na, ng = raw["nkeys"], raw["naggs"], raw["ngroups"]
+        rec = np.concatenate([raw["keys"].view(np.uint8).reshape(ng, -1), raw["aggs"].view(np.uint8).reshape(ng, -1)], axis=1) \
+            if ng else np.zeros((0, 16 * (nk + na)), np.uint8)
+        if self._gather is None:
+            self._gather = FixedGather(16 * (nk + na), capacity=max(1024, 2 * ng))
+        allg = np.ascontiguousarray(self._gather(rec, device))
+        n = allg.shape[0]
+        dt = GpuFilterGroup._VALUE_DT
+        keys = np.ascontiguousarray(allg[:, :16 * nk]).view(dt).reshape(n, nk)
+        aggs = np.ascontiguousarray(allg[:, 16 * nk:]).view(dt).reshape(n, na)
+        if self.tail:
+            r = self.merger.order_rows(keys, aggs)
+            return r["keys"], r["aggs"]
+        return keys, aggs
 
     def _alloc(self, capacity: int, kinds: Sequence[int]):
         import torch
@@ -296,28 +349,18 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     total_rows = args.rows * world
     cols = bench.DeviceColumns(args.rows, args.kcat, bool(args.zipf), rank * args.rows, total_rows, local_rank)
     op = ShardedFilterGroup(wl["cond"], wl["keys"], wl["aggs"], bench.synth_dictionary(args.kcat), rank, world,
-                            local_rank)
+                            local_rank, order=wl.get("order"), limit=wl.get("limit"))
     dev = torch.device("cuda", local_rank)
-    gather = None
 
     def step(last=False):
-        nonlocal gather
         if op.has_distinct or args.exchange == "rows":
             raw, info = op.run(args.rows, cols.by_path)
         elif args.exchange == "partials":
             raw, info = op.run_partials(args.rows, cols.by_path, want_rows_selected=last)
         else:
             raw, info = op.run_gathered(args.rows, cols.by_path, want_rows_selected=last)
-        if info.get("mode") == "gathered partials":
-            # every rank already merged every rank's partial groups: its result (raw["keys"], raw["aggs"]) is complete
-            return raw["keys"], info
-        rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
-                              raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1) \
-            if raw["ngroups"] else np.zeros((0, 16 * (raw["nkeys"] + raw["naggs"])), np.uint8)
-        if gather is None:
-            gather = FixedGather(rec.shape[1], capacity=max(1024, 2 * rec.shape[0]))
-        allg = gather(rec, dev)  # every rank holds the result; rank 0 reports it
-        return allg, info
+        keys, _aggs = op.combine(raw, info, dev)  # every rank holds the job's result; rank 0 reports it
+        return keys, info
 
     for _ in range(args.warmup):
         allg, info = step()

@@ -236,6 +236,26 @@ class GpuFilterGroup:
                "selected": arr(res.selected, int(res.nselected), np.dtype("<u8"))}
         return out
 
+    def order_rows(self, keys: np.ndarray, aggs: np.ndarray) -> dict:
+        """n1k_order_rows: the plan's Order / Offset / Limit over result rows gathered from several owners (structured
+        (tag, v) arrays [n, nkeys] / [n, naggs] as after_items_raw returns them).  Host only."""
+        n = int(keys.shape[0]) if keys.ndim == 2 and keys.shape[1] else int(aggs.shape[0])
+        k = np.ascontiguousarray(keys)
+        a = np.ascontiguousarray(aggs)
+        res = _ffi.Result()
+        self._check(self._lib.n1k_order_rows(self._h, n, k.ctypes.data if k.size else None, a.ctypes.data if a.size else None,
+                                             C.byref(res)))
+        ng, nk, na = int(res.ngroups), int(res.nkeys), int(res.naggs)
+
+        def arr(ptr, count):
+            if not count or not ptr:
+                return np.zeros(0, dtype=self._VALUE_DT)
+            return np.frombuffer(bytearray(C.string_at(ptr, count * self._VALUE_DT.itemsize)), dtype=self._VALUE_DT)
+
+        return {"ngroups": ng, "nkeys": nk, "naggs": na,
+                "keys": arr(res.keys, ng * nk).reshape(ng, nk) if nk else np.zeros((ng, 0), self._VALUE_DT),
+                "aggs": arr(res.aggs, ng * na).reshape(ng, na) if na else np.zeros((ng, 0), self._VALUE_DT)}
+
     def _py_values(self, a: np.ndarray, cache: dict) -> list:
         """structured (tag, v) array [n, m] -> list of n tuples of (tag, python value)."""
         tags = a["tag"]

@@ -222,3 +222,41 @@ def test_rank_pipeline_falls_back_to_rows_for_wide_key_values():
         pu.assert_same_groups(got, ora, aggs=aggs)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["gathered", "partials", "rows"])
+def test_rank_pipeline_grouped_tail(mode):
+    """HAVING / ORDER BY / OFFSET / LIMIT across ranks: the merging handle applies them in the gathered mode; with
+    hash-partitioned owners every owner keeps its first offset+limit rows and their union is ordered by
+    n1k_order_rows (config 5's shape: GROUP BY cat, region_id ORDER BY SUM(price) DESC LIMIT k)."""
+    import torch
+    import torch.distributed as dist
+    from query_amd import distributed as qd
+    from query_amd.gpu_operator import GroupRows
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n = 150_000
+        t = n1o.synth_table(n, k_cat=300)
+        keys = [D("cat"), D("region_id")]
+        aggs = sorted(["sum(%s)" % D("price"), "count(*)"])
+        order, limit, offset = [("sum(%s)" % D("price"), True), (D("cat"), False)], 25, 3
+        having = "(5 < count(*))"
+        op = qd.ShardedFilterGroup(None, keys, aggs, t.dictionary, 0, 1, 0, order=order, limit=limit, offset=offset, having=having)
+        dev, keep = _device_cols(t, op.send_paths)
+        raw, info = {"gathered": op.run_gathered, "partials": op.run_partials, "rows": op.run}[mode](n, dev)
+        k, a = op.combine(raw, info, torch.device("cuda", 0))
+        ora = n1o.run(t, None, keys, aggs)
+        ci = aggs.index("count(*)")
+        kept = [(kk, aa) for kk, aa in zip(ora.keys, ora.aggs) if aa[ci][1] > 5]
+        ora.keys, ora.aggs = [x for x, _ in kept], [y for _, y in kept]
+        cache = {}
+        got = GroupRows(len(keys), len(aggs), op.merger._py_values(k, cache), op.merger._py_values(a, cache), [])
+        pu.assert_ordered_groups(got, ora, keys, aggs, order, limit, offset)
+    finally:
+        dist.destroy_process_group()
