@@ -136,6 +136,7 @@ class ShardedFilterGroup:
             plan.filter_group_plan(None, keys, aggs, order=order, limit=limit, offset=offset, having=having),
             device=device, stream=self.stream.cuda_stream, **options) if self.tail else self.receiver
         self._recv_ready = set()
+        self._sbatch = None
         self._cap_known = False
         self._gather = None
         self.sender.intern(list(dictionary))
@@ -194,7 +195,10 @@ class ShardedFilterGroup:
                                   torch.empty(region * self.world, dtype=torch.uint8, device=dev))
                 send, recv = self._pbuf
                 snd.reopen()
-                snd.process_device_items(nrows, [cols_by_path[p] for p in self.send_paths])
+                if self._sbatch is None or self._sbatch[0] is not cols_by_path or self._sbatch[1] != nrows:
+                    # the n1k_batch of a shard that stays where it is (same dict object, same rows) is built once
+                    self._sbatch = (cols_by_path, nrows, snd.make_device_batch(nrows, [cols_by_path[p] for p in self.send_paths]))
+                snd.process_device_batch(self._sbatch[2])
                 if not self._cap_known:
                     # first step: size the regions from the number of groups the shards really hold (one small
                     # all-reduce) instead of climbing there by x4 retries that each repeat the scan
