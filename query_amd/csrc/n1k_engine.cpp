@@ -1186,20 +1186,24 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
         HIP_TRY(h, hipMemsetAsync(h->d_emit.p, 0, 16, h->stream));
         B.emit = h->d_emit.p;
         B.emit_cap = ecap;
+        B.emit_singletons = h->d_counters.p + 22;
+        HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 22, 0, sizeof(unsigned long long), h->stream));
         const size_t shmem = (size_t)slots * P.lds_words * 8 + 1024;
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
         uint32_t grid = (uint32_t)std::min<uint64_t>(nbins, (uint64_t)h->num_cus * per_cu);
         HIP_TRY(h, launch_agg_bins(P, B, h->table, h->d_counters.p + 1, grid, h->stream));
         // how many partial groups, how many groups already: the table grows to hold both, then the merge
-        unsigned long long emitted = 0, have = 0;
+        unsigned long long emitted = 0, have = 0, singletons = 0;
+        HIP_TRY(h, hipMemcpyAsync(&singletons, h->d_counters.p + 22, sizeof singletons, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(&emitted, h->d_emit.p, sizeof emitted, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(&have, h->d_counters.p + 1, sizeof have, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         emitted = std::min<unsigned long long>(emitted, ecap);
         st = ensure_table_groups(h, have + emitted);
         if (st != N1K_OK) return st;
+        // every key of the region is unique unless rows left the bins on their own: new groups are then plain copies
         HIP_TRY(h, launch_merge_partials(P, h->table, 1, ecap, h->d_emit.p, region_words, h->d_errp, h->d_counters.p + 1,
-                                         h->stream, emitted));
+                                         h->stream, emitted, singletons == 0));
     }
     if (e1) (void)hipEventRecord(e1, h->stream);
     h->events.emplace_back(e0, e1);

@@ -76,7 +76,7 @@ hipError_t launch_export_partials(const Program& P, const GlobalTable& G, uint32
                                   uint64_t region_words, uint32_t* err_flags, hipStream_t st);
 hipError_t launch_merge_partials(const Program& P, const GlobalTable& G, uint32_t nregions, uint64_t cap, const uint64_t* in,
                                  uint64_t region_words, uint32_t* err_flags, unsigned long long* ngroups, hipStream_t st,
-                                 uint64_t limit = 0);
+                                 uint64_t limit = 0, bool unique_keys = false);
 hipError_t launch_arith(const ArithArgs& A, hipStream_t st);
 hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, hipStream_t st);
 struct SpecEntry {

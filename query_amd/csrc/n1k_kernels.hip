@@ -1430,9 +1430,15 @@ __global__ void export_partials_kernel(const Program P, const GlobalTable G, uin
 
 // CumulateIntermediate of one partial group (packed key + raw global accumulators) into the table
 N1K_DEV void merge_partial_record(const Program& P, const GlobalTable& G, uint64_t key, const uint64_t* l, uint32_t* err_flags,
-                                  bool& fresh) {
+                                  bool& fresh, bool unique_keys) {
     long long g = global_find_or_insert_quiet(G, key, err_flags, fresh);
     if (g < 0) return;
+    if (fresh && unique_keys) {
+        // no other record of this launch has the key: the new row is this record (plain stores, no atomics)
+        uint64_t* w = &G.acc[(size_t)g * P.glob_words];
+        for (uint32_t i = 0; i < P.glob_words; i++) w[i] = l[i];
+        return;
+    }
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
         const uint64_t* p = l + ag.glob_off;
@@ -1471,7 +1477,7 @@ N1K_DEV void merge_partial_record(const Program& P, const GlobalTable& G, uint64
 // merge received partial groups into this GPU's table (one thread per record)
 __global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint32_t nregions, uint64_t cap,
                                       const uint64_t* in, uint64_t region_words, uint32_t* err_flags,
-                                      unsigned long long* ngroups) {
+                                      unsigned long long* ngroups, uint32_t unique_keys) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t r = (uint32_t)(i / cap);
     uint64_t pos = i % cap;
@@ -1487,7 +1493,7 @@ __global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint
     const uint64_t* region = in + (size_t)r * region_words;
     uint64_t count = region[0] < cap ? region[0] : cap;
     bool fresh = false;
-    if (pos < count) merge_partial_record(P, G, region[2 + pos], region + 2 + cap + pos * P.glob_words, err_flags, fresh);
+    if (pos < count) merge_partial_record(P, G, region[2 + pos], region + 2 + cap + pos * P.glob_words, err_flags, fresh, unique_keys != 0);
     // new groups: one atomic on the counter per wave (per new group they serialise on one address: 4 ns each)
     const unsigned long long m = __ballot(fresh);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(ngroups, (unsigned long long)__popcll(m));
@@ -1779,6 +1785,7 @@ __global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const 
             if (slot < 0 && A.emit) {
                 // more groups in the bin than the LDS table takes: the row leaves as a group of its own
                 const unsigned long long q = atomicAdd((unsigned long long*)&A.emit[0], 1ull);
+                atomicAdd(A.emit_singletons, 1ull);  // keys in the region are no longer unique
                 if (q >= A.emit_cap) {
                     atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
                     continue;
@@ -1806,6 +1813,7 @@ __global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const 
                         // a value the narrow LDS accumulators do not take (|int| >= 2^40)
                         if (A.emit) {  // leaves as a partial group of its own that holds just this contribution
                             const unsigned long long q = atomicAdd((unsigned long long*)&A.emit[0], 1ull);
+                            atomicAdd(A.emit_singletons, 1ull);
                             if (q < A.emit_cap) {
                                 A.emit[2 + q] = key;
                                 uint64_t* row = A.emit + 2 + A.emit_cap + q * P.glob_words;
@@ -2296,12 +2304,13 @@ hipError_t launch_export_partials(const Program& P, const GlobalTable& G, uint32
 
 hipError_t launch_merge_partials(const Program& P, const GlobalTable& G, uint32_t nregions, uint64_t cap, const uint64_t* in,
                                  uint64_t region_words, uint32_t* err_flags, unsigned long long* ngroups, hipStream_t st,
-                                 uint64_t limit) {
+                                 uint64_t limit, bool unique_keys) {
     uint64_t total = (uint64_t)nregions * cap;
     if (nregions == 1 && limit && limit < total) total = limit;  // one region whose count the caller knows
     if (!total) return hipSuccess;
     uint32_t blocks = (uint32_t)((total + 255) / 256);
-    hipLaunchKernelGGL(merge_partials_kernel, dim3(blocks), dim3(256), 0, st, P, G, nregions, cap, in, region_words, err_flags, ngroups);
+    hipLaunchKernelGGL(merge_partials_kernel, dim3(blocks), dim3(256), 0, st, P, G, nregions, cap, in, region_words, err_flags, ngroups,
+                       unique_keys ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -33,7 +33,7 @@ constexpr int kMaxLdsWords = 40;   // 1 key word + accumulators
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 // device counters of a handle: [0] rows selected [1] groups [2] out count [3] filter total [4] rehash scratch
 // [5] DISTINCT region words [8..11] pair-log cursors [12] error flags [13] wide key values [16..19] word-log cursors
-// [20] DISTINCT LDS-set overflow flag
+// [20] DISTINCT LDS-set overflow flag [21] records of the partitioned path [22] its singleton partial groups
 constexpr uint32_t kCounters = 32;
 
 // value tags == n1k_tag (include/n1k.h)
@@ -246,6 +246,7 @@ struct BinAggArgs {
     // being merged into the global table
     uint64_t* emit;
     uint64_t emit_cap;
+    unsigned long long* emit_singletons;  // records emitted outside the bins' tables: their keys may repeat
 };
 
 struct DedupeArgs {
