@@ -278,7 +278,7 @@ bool to_operand(n1k_handle* h, const Expr* e, Operand& o, PlanError& err) {
     for (auto& c : e->ch) {
         Operand x;
         if (!to_operand(h, c.get(), x, err)) return false;
-        if (x.is_const && x.ctag == T_STRING) h->need_rank = h->need_rank;  // strings just make the result NULL
+        // (a string operand needs no dictionary rank here: arithmetic over a non-number is NULL, expression/arith_add.go:51-70)
         ops.push_back(x);
     }
     // n-ary Add / Mult fold left to right, at most 4 operands per kernel: ((a+b+c+d) + e + ...)
