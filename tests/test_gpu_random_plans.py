@@ -129,8 +129,9 @@ def test_random_plans_agree_with_the_oracle(seed):
     cond, keys, aggs = rand_plan(rng)
     opts = dict(OPTION_SETS[rng.integers(0, len(OPTION_SETS))])
     batches = int(rng.integers(1, 4))
+    resident = bool(rng.random() < 0.3)  # columns already in HBM (n1k_push_device_batch) or host buffers (n1k_push_batch)
     try:
-        gpu, _ = pu.run_gpu(t, cond, keys, aggs, batches=batches, **opts)
+        gpu, _ = pu.run_gpu(t, cond, keys, aggs, batches=batches, device_resident=resident, **opts)
     except query_amd.N1kError as e:
         if e.status == _ffi.UNSUPPORTED:
             pytest.skip("outside the device subset: " + e.message)
