@@ -1125,6 +1125,8 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
     for (uint32_t e = 0; e < pp.nsrc; e++) A.src[e] = pp.src[e];
     A.nsrc = pp.nsrc;
     A.err_flags = h->d_errp;
+    A.hist = levels ? h->d_hist.p : nullptr;
+    if (levels) HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, 256 * sizeof(unsigned long long), h->stream));
     {
         uint64_t tiles = (n + 2047) / 2048;
         uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 4, tiles));
@@ -1162,7 +1164,7 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
             R.out_start = h->d_seg[l + 1].p;
             uint64_t tiles = (nrec + 8191) / 8192;
             uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / nbins + (nbins > 1 ? 8 : 0), tiles));
-            HIP_TRY(h, launch_radix_pass(R, slices, h->stream));
+            HIP_TRY(h, launch_radix_pass(R, slices, h->stream, l == 0));  // the projection counted the first digit
             bin_start = R.out_start;
             nbins *= 256;
             cur++;

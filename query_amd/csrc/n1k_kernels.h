@@ -62,7 +62,7 @@ hipError_t launch_topk_compact(const uint32_t* cand, uint64_t ncand, uint32_t nk
                                OutPartial* oparts, uint64_t* orep, hipStream_t st);
 hipError_t launch_distinct_layout(const Program& P, const GlobalTable& G, const DistinctArgs& D, hipStream_t st);
 // COUNT(DISTINCT) over one-word members: one 256-bin partition pass (histogram, offsets, LDS-staged scatter) ...
-hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st);
+hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st, bool have_hist = false);
 // ... the per-bin LDS sets, the global-memory fallback, and the hand-over of the member counts to the set sizes
 hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, hipStream_t st);
 hipError_t launch_distinct_words_global(const GlobalTable& G, const uint64_t* words, uint64_t n, uint64_t* table, uint64_t mask,

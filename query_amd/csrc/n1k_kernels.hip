@@ -1696,7 +1696,10 @@ template <int R, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void project_records_kernel(const Program P, const ProjectArgs A) {
     __shared__ uint32_t wave_cnt[BLOCK / 64];
     __shared__ unsigned long long tile_base;
+    __shared__ uint32_t s_hist[256];  // first radix digit of the records' keys: the first partition pass needs no histogram pass
     const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 256; i += BLOCK) s_hist[i] = 0;
+    __syncthreads();
     uint32_t unsupported = 0, unpackable = 0;
     const uint64_t tile_rows = (uint64_t)BLOCK * R;
     const uint64_t ntiles = (A.nrows + tile_rows - 1) / tile_rows;
@@ -1729,7 +1732,10 @@ __global__ __launch_bounds__(BLOCK) void project_records_kernel(const Program P,
         }
         uint32_t mine = 0;
 #pragma unroll
-        for (int j = 0; j < R; j++) mine += pass[j] ? 1u : 0u;
+        for (int j = 0; j < R; j++) {
+            mine += pass[j] ? 1u : 0u;
+            if (pass[j] && A.hist) atomicAdd(&s_hist[radix_bin(key[j], 56)], 1u);
+        }
         unsigned long long pos = tile_reserve<BLOCK>(mine, A.cursor, wave_cnt, &tile_base, tid);
         unsigned long long q = pos;
 #pragma unroll
@@ -1753,6 +1759,10 @@ __global__ __launch_bounds__(BLOCK) void project_records_kernel(const Program P,
     }
     if (unsupported) atomicOr(A.err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
     if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+    __syncthreads();
+    if (A.hist)
+        for (uint32_t i = tid; i < 256; i += BLOCK)
+            if (s_hist[i]) atomicAdd(&A.hist[i], (unsigned long long)s_hist[i]);
 }
 
 template <int BLOCK>
@@ -2249,9 +2259,11 @@ hipError_t launch_topk_compact(const uint32_t* cand, uint64_t ncand, uint32_t nk
     return hipGetLastError();
 }
 
-hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st) {
-    (void)hipMemsetAsync(A.hist, 0, (size_t)A.nseg * 256 * sizeof(unsigned long long), st);
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
+hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st, bool have_hist) {
+    if (!have_hist) {  // (the producer of the words may have counted the digits already)
+        (void)hipMemsetAsync(A.hist, 0, (size_t)A.nseg * 256 * sizeof(unsigned long long), st);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
+    }
     hipLaunchKernelGGL(radix_offsets_kernel, dim3(A.nseg), dim3(256), 0, st, A);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
     return hipGetLastError();

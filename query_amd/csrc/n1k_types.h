@@ -233,6 +233,7 @@ struct ProjectArgs {
     Operand src[kRecOperands];
     uint32_t nsrc, pad;
     uint32_t* err_flags;
+    unsigned long long* hist;  // 256 counters of the records' first radix digit (or null)
 };
 struct BinAggArgs {
     RecArrays in;
