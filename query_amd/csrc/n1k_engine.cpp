@@ -144,7 +144,7 @@ struct n1k_handle {
     DevBuf<uint8_t> d_log_cls[kMaxDistinct];
     // COUNT(DISTINCT) member words (ScanArgs::log_word) and the scratch of their partition / de-duplication at finish
     DevBuf<uint64_t> d_log_word[kMaxDistinct], d_part[2], d_seg[3], d_wtable;
-    DevBuf<unsigned long long> d_hist, d_cursor, d_dcounts;
+    DevBuf<unsigned long long> d_hist, d_cursor, d_dcounts, d_word_hist;
     uint32_t opt_distinct_words = 1;      // 0: every pair takes the (key, value, class) log and the global sets
     uint32_t opt_distinct_set_slots = 4096;  // LDS set size of the de-duplication kernel (power of two)
     int32_t opt_distinct_levels = -1;        // partition passes before the LDS sets: -1 = by log size, 0..2 forced (tests)
@@ -807,6 +807,11 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         A.log_capacity = h->log_capacity;
         A.nw_key_bits = h->nw_key_bits;
         A.nw_val_bits = h->nw_val_bits;
+        if (!h->d_word_hist.p) {
+            HIP_TRY(h, h->d_word_hist.ensure(kMaxDistinct * 256));
+            HIP_TRY(h, hipMemsetAsync(h->d_word_hist.p, 0, kMaxDistinct * 256 * sizeof(unsigned long long), h->stream));
+        }
+        A.word_hist = h->d_word_hist.p;
         bool any_words = false;
         for (uint32_t d = 0; d < h->n_distinct; d++) any_words |= h->distinct_words[d];
         A.dcache_aggs = any_words ? h->n_distinct : 0;
@@ -1412,6 +1417,7 @@ void n1k_destroy(n1k_handle* h) {
         h->d_hist.release();
         h->d_cursor.release();
         h->d_dcounts.release();
+        h->d_word_hist.release();
         h->d_wide_int.release();
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -1463,6 +1469,7 @@ n1k_status n1k_reset(n1k_handle* h) {
         // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
+        if (h->d_word_hist.p) HIP_TRY(h, hipMemsetAsync(h->d_word_hist.p, 0, kMaxDistinct * 256 * sizeof(unsigned long long), h->stream));
         if (h->prog.wide_int) {
             const size_t n = (size_t)1 << h->prog.wide_bits;
             HIP_TRY(h, hipMemsetAsync(h->d_wide_int.p, 0xFF, n * 8, h->stream));
@@ -1727,13 +1734,15 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
         R.seg_start = h->d_seg[l].p;
         R.nseg = nbins;
         R.shift = 56 - 8 * l;
-        R.hist = h->d_hist.p;
+        // the scan kernels counted the first digit of every word they logged (ScanArgs::word_hist)
+        const bool counted = l == 0 && h->d_word_hist.p != nullptr;
+        R.hist = counted ? h->d_word_hist.p + (size_t)ag.log_index * 256 : h->d_hist.p;
         R.cursor = h->d_cursor.p;
         R.out_start = h->d_seg[l + 1].p;
         // slices per segment: enough workgroups to fill the GPU, never less than one tile each on average
         uint64_t tiles = (nwords + 8191) / 8192;
         uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / nbins + (nbins > 1 ? 8 : 0), tiles));
-        HIP_TRY(h, launch_radix_pass(R, slices, h->stream));
+        HIP_TRY(h, launch_radix_pass(R, slices, h->stream, counted));
         words = R.dst;
         bin_start = R.out_start;
         nbins *= 256;

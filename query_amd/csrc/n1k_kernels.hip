@@ -683,6 +683,9 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
     if (tid == 0) lds_fill = 0;
     uint64_t* dcache = lds + (size_t)S * P.lds_words;  // "already logged" caches of the COUNT(DISTINCT) aggregates
     for (uint32_t i = tid; i < A.dcache_slots * A.dcache_aggs; i += BLOCK) *(volatile lds_u64*)lds_word(dcache, i) = kEmptyKey;
+    __shared__ uint32_t s_whist[kMaxDistinct * 256];  // first radix digit of the words this workgroup logs
+    if (A.word_hist)
+        for (uint32_t i = tid; i < kMaxDistinct * 256; i += BLOCK) s_whist[i] = 0;
     __syncthreads();
 
     uint32_t unsupported = 0, unpackable = 0;
@@ -812,8 +815,11 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
 #pragma unroll
                     for (int j = 0; j < R; j++) {
                         if (!q[j] || !nar[j]) continue;
-                        if (pos < A.log_capacity) A.log_word[ag.log_index][pos] = val[j];
-                        else atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                        if (pos < A.log_capacity) {
+                            A.log_word[ag.log_index][pos] = val[j];
+                            if (A.word_hist) atomicAdd(&s_whist[ag.log_index * 256 + radix_bin(val[j], 56)], 1u);
+                        } else
+                            atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
                         pos++;
                     }
                     __syncthreads();
@@ -839,6 +845,11 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
 
     if (unsupported) atomicOr(A.err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
     if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+    if (A.word_hist) {
+        __syncthreads();
+        for (uint32_t i = tid; i < kMaxDistinct * 256; i += BLOCK)
+            if (s_whist[i]) atomicAdd(&A.word_hist[i], (unsigned long long)s_whist[i]);
+    }
     // rows that passed the Filter (≙ Filter #itemsOut): one global atomic per workgroup
     __shared__ unsigned long long block_selected;
     if (tid == 0) block_selected = 0;

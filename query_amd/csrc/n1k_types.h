@@ -197,6 +197,7 @@ struct ScanArgs {
     uint32_t nw_key_bits, nw_val_bits;
     uint32_t dcache_slots;  // per DISTINCT aggregate: slots (power of two) of the workgroup's "already logged" cache, 0 = none
     uint32_t dcache_aggs;   // number of such caches (== DISTINCT aggregates of the plan)
+    unsigned long long* word_hist;  // kMaxDistinct x 256 counters: first radix digit of the logged words (n1k_finish's first pass)
 };
 
 // radix partition of a word log by bits of mix64(word) (finish step of COUNT(DISTINCT), see n1k_kernels.hip)
