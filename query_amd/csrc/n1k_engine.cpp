@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -1179,8 +1180,12 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
         B.bin_start = bin_start;
         B.nbins = nbins;
         B.nsrc = pp.nsrc;
-        B.lds_slots = slots;
-        B.lds_max_fill = std::max(1u, slots * 5 / 8);
+        // the bins' tables are cleared and scanned once per bin: no larger than the groups expected there need
+        uint32_t bslots = slots;
+        const uint64_t per = groups_est / nbins + 1;
+        while (bslots > 256 && (uint64_t)bslots / 8 >= per) bslots /= 2;
+        B.lds_slots = bslots;
+        B.lds_max_fill = std::max(1u, bslots * 5 / 8);
         for (uint32_t a = 0; a < kMaxAggs; a++) B.agg_src[a] = a < P.naggs ? pp.agg_src[a] : 0xFFFFFFFFu;
         B.err_flags = h->d_errp;
         // partial groups of the bins: at most one per record, plus one per record and SUM/AVG for the values the
@@ -1195,7 +1200,7 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
         B.emit_cap = ecap;
         B.emit_singletons = h->d_counters.p + 22;
         HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 22, 0, sizeof(unsigned long long), h->stream));
-        const size_t shmem = (size_t)slots * P.lds_words * 8 + 1024;
+        const size_t shmem = (size_t)bslots * P.lds_words * 8 + 1024;
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
         uint32_t grid = (uint32_t)std::min<uint64_t>(nbins, (uint64_t)h->num_cus * per_cu);
         HIP_TRY(h, launch_agg_bins(P, B, h->table, h->d_counters.p + 1, grid, h->stream));
@@ -1276,7 +1281,20 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
             const uint64_t fresh = ng > h->groups_seen ? ng - h->groups_seen : 0;
             h->groups_seen = ng;
             partition = fresh >= h->opt_partition_min_groups;
-            groups_est = std::min<uint64_t>(groups_est, std::max<uint64_t>(1, fresh) * ((b->nrows - head + head - 1) / head));
+            // how many groups will the rest bring?  If the keys are draws from a universe of U values, m draws show
+            // d = U (1 - e^(-m/U)) of them: solve for U from the probe (m = head rows, d = fresh groups) and evaluate at
+            // the batch.  (All-distinct probes have no finite U: the row count stays the bound.)  Only the number of
+            // partition passes and the size of the per-bin LDS tables hang on it; a low guess costs speed, not results.
+            const double m = (double)head, d = (double)std::max<uint64_t>(1, fresh);
+            if (d < 0.98 * m) {
+                double lo = d, hi = 1e18;
+                for (int it = 0; it < 200; it++) {
+                    const double U = std::sqrt(lo * hi);
+                    if (U * (1.0 - std::exp(-m / U)) < d) lo = U; else hi = U;
+                }
+                const double U = lo, nn = (double)b->nrows;
+                groups_est = std::min<uint64_t>(groups_est, (uint64_t)(2.0 * U * (1.0 - std::exp(-nn / U))) + 1024);
+            }
         }
         view(head, b->nrows - head, cols, v);
         st = bind_columns(h, &v);
