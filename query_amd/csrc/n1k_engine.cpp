@@ -91,6 +91,9 @@ struct n1k_handle {
     DevBuf<uint64_t> d_rec_key[3], d_rec_pay[3][kRecOperands];
     DevBuf<uint8_t> d_rec_tag[3][kRecOperands];
     DevBuf<uint64_t> d_emit;  // the bins' partial groups before they are merged into the table
+    // ... or instead of it: while the table is empty and their keys are unique, the region IS the set of groups;
+    // n1k_finish finalizes it directly, anything else that needs the table merges it first (flush_pending)
+    struct { uint64_t count = 0, cap = 0; } pending;
     // (measured, 100 M rows, GROUP BY cat, region_id: 6 400 groups 11.3 ms scan kernels vs 6.6 ms partitioned; 64 000 groups
     //  14.4 vs 9.8 ms: the LDS hash stage holds about a thousand groups, beyond that rows turn into global atomics)
     uint64_t opt_partition_min_rows = 8u << 20, opt_partition_probe_rows = 512u << 10, opt_partition_min_groups = 4096;
@@ -1084,7 +1087,22 @@ bool small_key_domain(const n1k_handle* h) {
     return dom <= 4096;
 }
 
-n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const PartitionPlan& pp, uint64_t groups_est) {
+n1k_status flush_pending(n1k_handle* h) {
+    if (!h->pending.count) return N1K_OK;
+    unsigned long long have = 0;
+    HIP_TRY(h, hipMemcpyAsync(&have, h->d_counters.p + 1, sizeof have, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    n1k_status st = ensure_table_groups(h, have + h->pending.count);
+    if (st != N1K_OK) return st;
+    const uint64_t region_words = 2 + h->pending.cap * (1 + (uint64_t)h->prog.glob_words);
+    HIP_TRY(h, launch_merge_partials(h->prog, h->table, 1, h->pending.cap, h->d_emit.p, region_words, h->d_errp,
+                                     h->d_counters.p + 1, h->stream, h->pending.count, true));
+    h->pending.count = 0;
+    return N1K_OK;
+}
+
+n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const PartitionPlan& pp, uint64_t groups_est,
+                                 bool may_keep_region) {
     Program& P = h->prog;
     const uint64_t n = b->nrows;
     // the table is NOT sized by this batch's rows: the bins' groups are counted first (below) and the table grows to
@@ -1211,6 +1229,16 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
         HIP_TRY(h, hipMemcpyAsync(&have, h->d_counters.p + 1, sizeof have, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         emitted = std::min<unsigned long long>(emitted, ecap);
+        if (may_keep_region && have == 0 && singletons == 0) {
+            // nothing else in the handle and every key of the region is unique: the region is the set of groups
+            h->pending.count = emitted;
+            h->pending.cap = ecap;
+            if (e1) (void)hipEventRecord(e1, h->stream);
+            h->events.emplace_back(e0, e1);
+            h->stats.agg_mode = N1K_MODE_PARTITIONED;
+            h->stats.spec_kernel = 0;
+            return N1K_OK;
+        }
         st = ensure_table_groups(h, have + emitted);
         if (st != N1K_OK) return st;
         // every key of the region is unique unless rows left the bins on their own: new groups are then plain copies
@@ -1237,6 +1265,9 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     // High-cardinality GROUP BY: beyond a few ten thousand groups the scan's LDS stage absorbs nothing and every row
     // costs atomics on a table in HBM.  Whether a batch is like that is learnt from the data: the first rows of a
     // large batch run through the scan kernels; if they bring many new groups, the rest is partitioned (below).
+    st = flush_pending(h);  // a region kept from the previous batch joins the table before more rows arrive
+    if (st != N1K_OK) return st;
+    const bool first_rows = h->row_base == 0 && h->merged_groups_bound == 0;  // nothing in the handle yet
     PartitionPlan pp;
     const bool can_partition = h->plan.has_group && partition_eligible(h, pp);
     uint64_t head = b->nrows;
@@ -1296,12 +1327,22 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
                 groups_est = std::min<uint64_t>(groups_est, (uint64_t)(2.0 * U * (1.0 - std::exp(-nn / U))) + 1024);
             }
         }
-        view(head, b->nrows - head, cols, v);
+        uint64_t from = head;
+        if (partition && decide && first_rows && h->table.capacity) {
+            // The probe's groups are all the handle holds: drop them and let the whole batch take the partitioned
+            // path, whose groups can then stay in their compact region (no table at all for this query).
+            HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, nullptr, h->stream));
+            HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 2 * sizeof(unsigned long long), h->stream));  // rows selected, groups
+            h->row_base = 0;
+            h->groups_seen = 0;
+            from = 0;
+        }
+        view(from, b->nrows - from, cols, v);
         st = bind_columns(h, &v);
         if (st != N1K_OK) return st;
         st = ensure_rank(h);
         if (st != N1K_OK) return st;
-        st = partition ? run_group_partitioned(h, &v, pp, groups_est) : run_group_batch(h, &v);
+        st = partition ? run_group_partitioned(h, &v, pp, groups_est, first_rows) : run_group_batch(h, &v);
         if (st != N1K_OK) return st;
         h->row_base += v.nrows;
     }
@@ -1484,6 +1525,7 @@ n1k_status n1k_reset(n1k_handle* h) {
         h->stats.device_ms = 0;
         h->groups_seen = 0;
         h->out_count_dirty = false;
+        h->pending.count = 0;
         // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
@@ -1993,7 +2035,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
         HIP_TRY(h, hipSetDevice(h->device));
         const bool topk_forced = pl.has_order && pl.limit >= 0 && !pl.has_having && h->opt_topk_min_groups < 4096;  // tests
         // (a table of millions of slots is not worth scanning twice: the sized pass alone then)
-        if (pl.has_group && !h->has_distinct && h->table.capacity && h->table.capacity <= (1u << 20) && !topk_forced) {
+        if (pl.has_group && !h->has_distinct && h->table.capacity && h->table.capacity <= (1u << 20) && !topk_forced && !h->pending.count) {
             spec_groups = std::min<uint64_t>(h->table.capacity, 4096);
             const size_t off_aggs = spec_groups * rec_keys, off_parts = off_aggs + spec_groups * rec_aggs,
                          off_rep = off_parts + spec_groups * rec_parts, total = off_rep + spec_groups * 8;
@@ -2036,7 +2078,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     h->stats.rows_selected = counters[0];
     h->stats.wide_key_values = counters[13];
     h->stats.distinct_path = 0;
-    uint64_t ng = counters[1];
+    uint64_t ng = h->pending.count ? h->pending.count : counters[1];  // (a kept region: the table is empty)
     h->r_keys.clear();
     h->r_aggs.clear();
     h->r_parts.clear();
@@ -2092,8 +2134,12 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             char* d = h->d_out.p;
             if (h->out_count_dirty) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
             h->out_count_dirty = true;  // (reopen zeroes every counter in its one launch)
-            HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
-                                       (uint64_t*)(d + off_rep), h->d_counters.p + 2, ng, h->d_errp, h->stream));
+            if (h->pending.count)
+                HIP_TRY(h, launch_finalize_region(h->prog, h->d_emit.p, h->pending.cap, ng, (OutValue*)d, (OutValue*)(d + off_aggs),
+                                                  (OutPartial*)(d + off_parts), (uint64_t*)(d + off_rep), h->d_errp, h->stream));
+            else
+                HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
+                                           (uint64_t*)(d + off_rep), h->d_counters.p + 2, ng, h->d_errp, h->stream));
             const uint64_t keep = pl.limit >= 0 ? (uint64_t)pl.offset + (uint64_t)pl.limit : ng;
             size_t copy_bytes = total;
             const char* src = d;
@@ -2321,6 +2367,10 @@ uint64_t n1k_partial_region_bytes(const n1k_handle* h, uint64_t capacity_groups)
 
 n1k_status n1k_export_partials_async(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
     if (!h || !out || nparts == 0 || capacity_groups == 0) return N1K_INVALID;
+    if (h->pending.count) {
+        n1k_status pst = flush_pending(h);
+        if (pst != N1K_OK) return pst;
+    }
     if (!h->plan.has_group) return fail(h, N1K_INVALID, "no groups in a Filter-only plan");
     if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
     n1k_status st = ensure_device(h);
@@ -2361,6 +2411,10 @@ n1k_status n1k_merge_partials_device(n1k_handle* h, uint32_t nregions, uint64_t 
     if (!h || !in || nregions == 0 || capacity_groups == 0) return N1K_INVALID;
     if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
     if (!h->layout_fixed) return fail(h, N1K_INVALID, "merge needs the key layout: push a batch (even an empty one) first");
+    if (h->pending.count) {
+        n1k_status pst = flush_pending(h);
+        if (pst != N1K_OK) return pst;
+    }
     n1k_status st = ensure_device(h);
     if (st != N1K_OK) return st;
     // the incoming groups bound the growth of the table
@@ -2379,6 +2433,8 @@ n1k_status n1k_merge_partials_device(n1k_handle* h, uint32_t nregions, uint64_t 
 n1k_status n1k_export_groups(n1k_handle* h, const void** blob, size_t* len) {
     if (!h || !blob || !len) return N1K_INVALID;
     n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    st = flush_pending(h);
     if (st != N1K_OK) return st;
     unsigned long long ng = 0;
     HIP_TRY(h, hipMemcpyAsync(&ng, h->d_counters.p + 1, sizeof ng, hipMemcpyDeviceToHost, h->stream));

@@ -1695,6 +1695,27 @@ __global__ __launch_bounds__(256) void finalize_kernel(const Program P, const Gl
     }
 }
 
+// FinalGroup straight from a region of partial groups with unique keys ([count][0][keys: cap][accumulators]): record i
+// is output row i (no table, no position counter)
+__global__ void finalize_region_kernel(const Program P, const uint64_t* region, uint64_t cap, uint64_t count, OutValue* out_keys,
+                                       OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t key = region[2 + i];
+    for (uint32_t k = 0; k < P.nkeys; k++) {
+        const KeySpec& ks = P.keys[k];
+        uint64_t field = ks.bits >= 64 ? key : ((key >> ks.shift) & ((1ull << ks.bits) - 1ull));
+        uint32_t tag;
+        uint64_t p;
+        unpack_key_field(P, ks.mode, field, tag, p);
+        put_value(&out_keys[i * P.nkeys + k], tag, p);
+    }
+    const uint64_t* g = region + 2 + cap + i * P.glob_words;
+    for (uint32_t a = 0; a < P.naggs; a++)
+        finalize_agg(P, P.aggs[a], g, &out_aggs[i * P.naggs + a], &out_parts[i * P.naggs + a], err_flags);
+    if (out_rep) out_rep[i] = ~0ull;
+}
+
 // ------------------------------------------------------------------ high-cardinality GROUP BY: partition, then LDS
 //
 // With millions of groups the workgroup tables stop absorbing anything and every row costs 3-5 atomics on a table in
@@ -2225,6 +2246,14 @@ __global__ void add_counter_kernel(unsigned long long* p, unsigned long long v) 
 
 hipError_t launch_add_counter(unsigned long long* p, unsigned long long v, hipStream_t st) {
     hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, st, p, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_region(const Program& P, const uint64_t* region, uint64_t cap, uint64_t count, OutValue* out_keys,
+                                  OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags, hipStream_t st) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(finalize_region_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, st, P, region, cap, count,
+                       out_keys, out_aggs, out_parts, out_rep, err_flags);
     return hipGetLastError();
 }
 
