@@ -1290,62 +1290,52 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     };
     std::vector<n1k_col> cols;
     n1k_batch v{};
-    if (head || !b->nrows) {
-        view(0, head, cols, v);
-        st = bind_columns(h, &v);
+    view(0, b->nrows, cols, v);
+    st = bind_columns(h, &v);
+    if (st != N1K_OK) return st;
+    st = ensure_rank(h);
+    if (st != N1K_OK) return st;
+    bool partition = can_partition && head == 0 && b->nrows > 0;
+    uint64_t groups_est = b->nrows;
+    if (decide) {
+        // probe: Filter + group key of the first `head` rows into the table (keys only), counted before and after
+        st = ensure_table(h, head);
         if (st != N1K_OK) return st;
-        st = ensure_rank(h);
-        if (st != N1K_OK) return st;
-        if (v.nrows) {
-            st = h->plan.has_group ? run_group_batch(h, &v) : run_filter_batch(h, &v);
-            if (st != N1K_OK) return st;
-        }
-        h->row_base += v.nrows;
-    }
-    if (head < b->nrows) {
-        uint64_t groups_est = b->nrows - head;
-        bool partition = !decide;
-        if (decide) {
-            unsigned long long ng = 0;
-            HIP_TRY(h, hipMemcpyAsync(&ng, h->d_counters.p + 1, sizeof ng, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            const uint64_t fresh = ng > h->groups_seen ? ng - h->groups_seen : 0;
-            h->groups_seen = ng;
-            partition = fresh >= h->opt_partition_min_groups;
-            // how many groups will the rest bring?  If the keys are draws from a universe of U values, m draws show
-            // d = U (1 - e^(-m/U)) of them: solve for U from the probe (m = head rows, d = fresh groups) and evaluate at
-            // the batch.  (All-distinct probes have no finite U: the row count stays the bound.)  Only the number of
-            // partition passes and the size of the per-bin LDS tables hang on it; a low guess costs speed, not results.
-            const double m = (double)head, d = (double)std::max<uint64_t>(1, fresh);
-            if (d < 0.98 * m) {
-                double lo = d, hi = 1e18;
-                for (int it = 0; it < 200; it++) {
-                    const double U = std::sqrt(lo * hi);
-                    if (U * (1.0 - std::exp(-m / U)) < d) lo = U; else hi = U;
-                }
-                const double U = lo, nn = (double)b->nrows;
-                groups_est = std::min<uint64_t>(groups_est, (uint64_t)(2.0 * U * (1.0 - std::exp(-nn / U))) + 1024);
+        unsigned long long before = 0, after = 0;
+        HIP_TRY(h, hipMemcpyAsync(&before, h->d_counters.p + 1, sizeof before, hipMemcpyDeviceToHost, h->stream));
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 4, (head + 1023) / 1024));
+        HIP_TRY(h, launch_probe_keys(h->prog, head, h->table, h->d_errp, h->d_counters.p + 1, grid, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(&after, h->d_counters.p + 1, sizeof after, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const uint64_t fresh = after > before ? after - before : 0;
+        partition = fresh >= h->opt_partition_min_groups;
+        // how many groups will the batch bring?  If the keys are draws from a universe of U values, m draws show
+        // d = U (1 - e^(-m/U)) of them: solve for U from the probe (m = head rows, d = fresh groups) and evaluate at
+        // the batch.  (All-distinct probes have no finite U: the row count stays the bound.)  Only the number of
+        // partition passes and the size of the per-bin LDS tables hang on it; a low guess costs speed, not results.
+        const double m = (double)head, d = (double)std::max<uint64_t>(1, fresh);
+        if (d < 0.98 * m) {
+            double lo = d, hi = 1e18;
+            for (int it = 0; it < 200; it++) {
+                const double U = std::sqrt(lo * hi);
+                if (U * (1.0 - std::exp(-m / U)) < d) lo = U; else hi = U;
             }
+            const double U = lo, nn = (double)b->nrows;
+            groups_est = std::min<uint64_t>(groups_est, (uint64_t)(2.0 * U * (1.0 - std::exp(-nn / U))) + 1024);
         }
-        uint64_t from = head;
-        if (partition && decide && first_rows && h->table.capacity) {
-            // The probe's groups are all the handle holds: drop them and let the whole batch take the partitioned
-            // path, whose groups can then stay in their compact region (no table at all for this query).
+        if (partition && first_rows && h->table.capacity) {
+            // the probe's keys are all the handle holds: drop them, so that the partitioned path's groups can stay in
+            // their compact region (no table at all for this query)
             HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, nullptr, h->stream));
-            HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, 2 * sizeof(unsigned long long), h->stream));  // rows selected, groups
-            h->row_base = 0;
-            h->groups_seen = 0;
-            from = 0;
+            HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 1, 0, sizeof(unsigned long long), h->stream));
         }
-        view(from, b->nrows - from, cols, v);
-        st = bind_columns(h, &v);
-        if (st != N1K_OK) return st;
-        st = ensure_rank(h);
-        if (st != N1K_OK) return st;
-        st = partition ? run_group_partitioned(h, &v, pp, groups_est, first_rows) : run_group_batch(h, &v);
-        if (st != N1K_OK) return st;
-        h->row_base += v.nrows;
     }
+    if (b->nrows) {
+        if (!h->plan.has_group) st = run_filter_batch(h, &v);
+        else st = partition ? run_group_partitioned(h, &v, pp, groups_est, first_rows) : run_group_batch(h, &v);
+        if (st != N1K_OK) return st;
+    }
+    h->row_base += b->nrows;
     h->stats.rows_in += b->nrows;
     h->stats.batches += 1;
     h->stats.bytes_scanned += b->nrows * batch_bytes_per_row(h);

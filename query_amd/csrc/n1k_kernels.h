@@ -52,6 +52,8 @@ hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalT
 hipError_t launch_finalize_region(const Program& P, const uint64_t* region, uint64_t cap, uint64_t count, OutValue* out_keys,
                                   OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags, hipStream_t st);
 hipError_t launch_add_counter(unsigned long long* p, unsigned long long v, hipStream_t st);
+hipError_t launch_probe_keys(const Program& P, uint64_t nrows, const GlobalTable& G, uint32_t* err_flags, unsigned long long* ngroups,
+                             uint32_t grid, hipStream_t st);
 hipError_t launch_project_records(const Program& P, const ProjectArgs& A, uint32_t grid, hipStream_t st);
 hipError_t launch_agg_bins(const Program& P, const BinAggArgs& A, const GlobalTable& G, unsigned long long* ngroups, uint32_t grid,
                            hipStream_t st);

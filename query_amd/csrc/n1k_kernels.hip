@@ -1797,6 +1797,46 @@ __global__ __launch_bounds__(BLOCK) void project_records_kernel(const Program P,
             if (s_hist[i]) atomicAdd(&A.hist[i], (unsigned long long)s_hist[i]);
 }
 
+// How many groups do the first rows of a batch bring?  Filter + group key only: every surviving row's key is looked up /
+// inserted in the global table (its accumulators stay at their identities; the rows themselves are aggregated later,
+// by whichever path the answer selects).
+template <int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void probe_keys_kernel(const Program P, uint64_t nrows, const GlobalTable G, uint32_t* err_flags,
+                                                          unsigned long long* ngroups) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t unsupported = 0;
+    const uint64_t tile_rows = (uint64_t)BLOCK * R;
+    const uint64_t ntiles = (nrows + tile_rows - 1) / tile_rows;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t row[R];
+        bool valid[R], pass[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            row[j] = tile * tile_rows + (uint64_t)j * BLOCK + tid;
+            valid[j] = row[j] < nrows;
+        }
+        eval_predicate<R>(P, row, valid, pass, unsupported);
+        uint64_t key[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) key[j] = 0;
+        for (uint32_t k = 0; k < P.nkeys; k++) {
+            const KeySpec& ks = P.keys[k];
+            uint32_t kt[R];
+            uint64_t kp[R];
+            load_operand<R>(P, ks.src, row, pass, kt, kp);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                uint64_t f = 0, canon = 0;
+                if (pass[j] && !pack_key_field(P, ks, kt[j], kp[j], f, canon)) pass[j] = false;  // reported by the real pass
+                key[j] |= f << ks.shift;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (pass[j]) (void)global_find_or_insert(G, key[j], err_flags, ngroups);
+    }
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const BinAggArgs A, const GlobalTable G,
                                                         unsigned long long* ngroups) {
@@ -2254,6 +2294,12 @@ hipError_t launch_finalize_region(const Program& P, const uint64_t* region, uint
     if (!count) return hipSuccess;
     hipLaunchKernelGGL(finalize_region_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, st, P, region, cap, count,
                        out_keys, out_aggs, out_parts, out_rep, err_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe_keys(const Program& P, uint64_t nrows, const GlobalTable& G, uint32_t* err_flags, unsigned long long* ngroups,
+                             uint32_t grid, hipStream_t st) {
+    hipLaunchKernelGGL((probe_keys_kernel<4, 256>), dim3(grid), dim3(256), 0, st, P, nrows, G, err_flags, ngroups);
     return hipGetLastError();
 }
 
