@@ -9,8 +9,8 @@ Workload at N=1 (BASELINE.json metric: rows/sec filter+group-by on 100M syntheti
     config 2's query  SELECT cat, SUM(price) FROM default WHERE price > 50 GROUP BY cat   at 100 M rows, K_cat = 1000
 (13 algorithmic bytes per row: price tag 1 + payload 8 + cat code 4).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (scan_group_kernel) against the HBM peak
-from its HIP-event duration; `cpu_baseline` times the CPU oracle (a port of the reference's algorithm) on a
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (scan_spec_kernel + merge_slabs_kernel for
+config 2) against the HBM peak from its HIP-event duration; `cpu_baseline` times the CPU oracle (a port of the reference's algorithm) on a
 bounded sample of the same workload on this box's host cores.
 """
 from __future__ import annotations
