@@ -217,7 +217,9 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
                 if (c < Spec::ncols) {
                     if (Spec::col_kind[c] == COLK_DICT32) {
                         if (WIDE) {
-                            uint2 cc = valid[j] ? ((const uint2*)F.cols[c].codes)[i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                            typedef uint32_t n1k_u32x2 __attribute__((ext_vector_type(2)));
+                            n1k_u32x2 cc = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                            if (valid[j]) cc = __builtin_nontemporal_load((const n1k_u32x2*)F.cols[c].codes + i);
                             pv[j][0][c] = cc.x;
                             pv[j][WIDE ? 1 : 0][c] = cc.y;
                         } else {
@@ -230,8 +232,10 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
                         }
                     } else {
                         if (WIDE) {
-                            ulonglong2 pp = valid[j] ? ((const ulonglong2*)F.cols[c].payload)[i] : make_ulonglong2(0, 0);
-                            uint32_t tt = valid[j] ? (uint32_t)((const uint16_t*)F.cols[c].tags)[i] : 0u;
+                            typedef unsigned long long n1k_u64x2 __attribute__((ext_vector_type(2)));
+                            n1k_u64x2 pp = {0ull, 0ull};
+                            if (valid[j]) pp = __builtin_nontemporal_load((const n1k_u64x2*)F.cols[c].payload + i);
+                            uint32_t tt = valid[j] ? (uint32_t)__builtin_nontemporal_load((const uint16_t*)F.cols[c].tags + i) : 0u;
                             pv[j][0][c] = pp.x;
                             pv[j][WIDE ? 1 : 0][c] = pp.y;
                             tg[j][0][c] = tt & 255u;
