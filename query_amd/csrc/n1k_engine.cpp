@@ -1777,7 +1777,9 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
     const uint64_t* bin_start = h->d_seg[0].p;
     uint32_t nbins = 1;
     for (uint32_t l = 0; l < levels; l++) {
-        HIP_TRY(h, h->d_part[l].ensure(nwords));
+        // (the number of logged words varies a little from run to run — racing duplicates in the scan's cache — so the
+        //  buffers get slack: growing them by a few words would mean a fresh 800 MB allocation each time)
+        HIP_TRY(h, h->d_part[l].ensure(nwords + nwords / 8 + (1u << 20)));
         RadixArgs R{};
         R.src = words;
         R.dst = h->d_part[l].p;

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
 // one more member of its group's set (Set.Len(), value/set.go:198-215), counted in a second LDS table keyed by the
 // packed group key (flushed to the groups once per workgroup) — a look-up of the global group table per new member
 // costs 0.8 ms per 100 M members in scattered loads, the LDS table a quarter of that.
-template <int BLOCK>
+template <int BLOCK, int U>
 __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P, const GlobalTable G, const DedupeArgs D) {
     extern __shared__ uint64_t dl[];
     uint64_t* set = dl;
@@ -560,7 +560,6 @@ __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P,
         for (uint32_t i = tid; i < D.set_slots; i += BLOCK) *(volatile lds_u64*)lds_word(set, i) = kEmptyKey;
         __syncthreads();
         // U words per thread and step, loaded together: a bin of a few thousand words pays one memory latency
-        constexpr int U = 4;
         for (uint64_t base = lo; base < hi; base += (uint64_t)BLOCK * U) {
             uint64_t w[U];
 #pragma unroll
@@ -2356,10 +2355,11 @@ hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st
 }
 
 hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, hipStream_t st) {
-    auto k = distinct_dedupe_kernel<512>;
     size_t shmem = (size_t)D.set_slots * 8 + (size_t)D.lds_counters * 12;
+    // 1024 threads x 2 words per step: measured best of {256, 512, 1024} x {2, 4, 8} at 20 M - 100 M words
+    auto k = distinct_dedupe_kernel<1024, 2>;
     if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), shmem, st, P, G, D);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(1024), shmem, st, P, G, D);
     return hipGetLastError();
 }
 
