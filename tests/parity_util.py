@@ -196,7 +196,9 @@ def _near(g1, g2, order, term_value, rel):
     the float tolerance make the order a matter of rounding (either is right); values further apart do not."""
     for text, _ in order:
         a, b = term_value(g1, text), term_value(g2, text)
-        if a == b:
-            continue
+        if a == b and a[0] != n1o.T_FLOAT:
+            continue  # an exact value: the next term decides
+        # float sums: g1 carries the oracle's values and g2 the device's; two groups whose sums agree to the last
+        # digits on one side may differ in the last bit on the other, and then this term alone orders them
         return values_match(a, b, rel, True, True, True)
     return True

@@ -85,6 +85,10 @@ def rand_operand(rng, depth=0):
         # sums that cancel at 1e300 / 2^61 are order dependent in any engine (the reference's Parallel copies too)
         small = [D("b"), "3", "2.5", D("b"), "-2"]
         return "(%s * %s)" % (small[rng.integers(0, 5)], small[rng.integers(0, 5)])
+    if op == "/":
+        # likewise the divisor is never the signed column `a`: 1e300 / -3 and 1e300 / 3 in one sum cancel
+        pos = [D("b"), D("f"), "3", "2.5", "100"]
+        return "(%s / %s)" % (rand_operand(rng, depth + 1), pos[rng.integers(0, 5)])
     return "(%s %s %s)" % (rand_operand(rng, depth + 1), op, rand_operand(rng, depth + 1))
 
 
