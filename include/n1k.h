@@ -179,6 +179,13 @@ typedef struct n1k_handle n1k_handle;
  *   {"#operator":"InitialGroup", …}            (no Filter)
  *   {"#operator":"Filter","condition":"…"}     (Filter only: result = selected row ordinals)
  *   {"#operator":"Parallel","~child":<one of the above>, "maxParallelism":n}
+ *   {"#operator":"Sequence","~children":[<one of the above>, IntermediateGroup, FinalGroup,      (the grouped tail:
+ *        {"#operator":"Filter","condition":"…"},                                       HAVING, plan/filter.go
+ *        {"#operator":"Order","sort_terms":[{"expr":"…","desc":true}],"offset":"…","limit":"…"},  plan/order.go:51-79
+ *        {"#operator":"Offset","expr":"…"}, {"#operator":"Limit","expr":"…"}]}               plan/limit.go:46-53)
+ *     IntermediateGroup / FinalGroup must repeat the InitialGroup's lists (plan/group.go:106-273) and are subsumed;
+ *     the HAVING condition and the sort terms may name only group keys and aggregates of the plan (by their text);
+ *     offset / limit are integer constants.  n1k_finish then returns the groups filtered, ordered and cut.
  * exactly as plan.(*Filter).MarshalJSON (plan/filter.go:46-53),
  * plan.(*InitialGroup).MarshalJSON (plan/group.go:54-70), plan/sequence.go:48-57 and
  * plan/parallel.go:54-67 emit them; expressions are expression.Stringer text.
