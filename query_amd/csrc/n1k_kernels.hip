@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void radix_offsets_kernel(const RadixArgs A) {
 __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixArgs A) {
     __shared__ uint64_t stage[kRadixTile];
     __shared__ uint8_t sbin[kRadixTile];  // bin of every staged position (records only)
-    __shared__ uint32_t cnt[256], pre[256];
+    __shared__ uint32_t cnt[256], pre[256], wsum[4];
     __shared__ unsigned long long gbase[256];
     const uint32_t tid = threadIdx.x, s = blockIdx.y;
     uint64_t lo, hi;
@@ -485,18 +485,22 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
             }
         }
         __syncthreads();
-        // exclusive scan of the 256 counts (threads 0..255) and one global reservation per non-empty bin
+        // exclusive scan of the 256 counts: shuffles inside each of the first four waves, their totals through LDS
+        // (two barriers, not sixteen), and one global reservation per non-empty bin
         uint32_t mine = tid < 256 ? cnt[tid] : 0u;
-        if (tid < 256) pre[tid] = mine;
-        __syncthreads();
-        for (uint32_t off = 1; off < 256; off <<= 1) {
-            uint32_t x = (tid < 256 && tid >= off) ? pre[tid - off] : 0u;
-            __syncthreads();
-            if (tid < 256) pre[tid] += x;
-            __syncthreads();
-        }
+        uint32_t incl = mine;
         if (tid < 256) {
-            pre[tid] -= mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t t = __shfl_up(incl, off, 64);
+                if ((int)(tid & 63) >= off) incl += t;
+            }
+            if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < (tid >> 6); w++) before += wsum[w];
+            pre[tid] = before + incl - mine;
             gbase[tid] = mine ? atomicAdd(&A.cursor[(size_t)s * 256 + tid], (unsigned long long)mine) : 0ull;
         }
         __syncthreads();
