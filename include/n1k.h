@@ -241,7 +241,8 @@ n1k_status n1k_dict_get(const n1k_handle *h, uint32_t code, const char **ptr, si
  *         de-duplicated by radix partition + LDS sets), "partition_min_rows" / "partition_probe_rows" / "partition_min_groups" / "partition_levels" (when AUTO takes the
  *         partitioned high-cardinality path: batches of at least min_rows (8 Mi) rows whose first probe_rows (512 Ki) rows
  *         bring at least min_groups (4096) new groups; forced number of passes), "topk_min_groups" (ORDER BY ... LIMIT: the device top-k filter runs from this many groups on, default 65536),
- *         "distinct_set_slots" / "distinct_levels" (LDS set size, forced number of partition passes: tests), "wide_values" (before the first push: how many distinct float / wide-integer group key
+ *         "distinct_set_slots" / "distinct_levels" (LDS set size, forced number of partition passes: tests),
+ *         "distinct_region_cap" (forced capacity of the specialised scan's hash regions: tests), "dedupe_block" (256 / 512 / 1024: tuning), "wide_values" (before the first push: how many distinct float / wide-integer group key
  *         values the handle can code, default 1<<20; 0 = such keys are N1K_UNSUPPORTED_DATA)} */
 n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);
 

@@ -149,6 +149,15 @@ struct n1k_handle {
     // COUNT(DISTINCT) member words (ScanArgs::log_word) and the scratch of their partition / de-duplication at finish
     DevBuf<uint64_t> d_log_word[kMaxDistinct], d_part[2], d_seg[3], d_wtable;
     DevBuf<unsigned long long> d_hist, d_cursor, d_dcounts, d_word_hist;
+    // hash regions of the specialised scan's COUNT(DISTINCT) (WordLogArgs): 256 regions x wregion_cap words per aggregate
+    DevBuf<uint64_t> d_wregion[kMaxDistinct], d_woff, d_wgather;
+    DevBuf<unsigned long long> d_wcursor;  // kMaxDistinct x 256 counters, kCursorStride apart
+    std::vector<unsigned long long> wcursor_host;
+    uint64_t wregion_cap = 0, wregion_reserved = 0;
+    bool wregion_used = false;             // some batch of this query went through the regions
+    uint32_t opt_dedupe_block = 1025;      // workgroup size of the de-duplication kernel, +1: probe word by word (tuning)
+    uint32_t opt_spec_debug = 0;           // timing experiments: 1 words not stored, 2 word scatter skipped, 4 no workgroup cache, 8 finish skips the sets
+    uint64_t opt_region_cap = 0;           // forced capacity of a hash region (tests: overflow into the plain log), 0 = from the rows
     uint32_t opt_distinct_words = 1;      // 0: every pair takes the (key, value, class) log and the global sets
     uint32_t opt_distinct_set_slots = 4096;  // LDS set size of the de-duplication kernel (power of two)
     int32_t opt_distinct_levels = -1;        // partition passes before the LDS sets: -1 = by log size, 0..2 forced (tests)
@@ -409,6 +418,7 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
             }
             h->has_distinct = true;
             s.log_index = h->n_distinct++;
+            s.lds_n = kLdsWordsDistinct;
             lds_w += kLdsWordsDistinct;
             glob_w += (d.kind == AGG_SUM || d.kind == AGG_AVG) ? kGlobWordsDistinctSum : kGlobWordsDistinct;
         } else if (d.kind == AGG_COUNT || d.kind == AGG_COUNTN) {
@@ -720,9 +730,16 @@ bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F) {
         F.lds_max_fill = std::max(1u, (uint32_t)((uint64_t)slots * 5 / 8));
     }
     F.naggs = P.naggs;
+    uint32_t ndist = 0;
     for (uint32_t a = 0; a < P.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
-        if (ag.distinct) return false;
+        if (ag.distinct) {
+            // COUNT(DISTINCT column) whose members leave as one word: the specialised kernels scatter them into hash
+            // regions; anything else DISTINCT stays with the interpreter kernel
+            if (ag.kind != AGG_COUNT || !ag.has_operand || ag.src.is_const || !h->layout_fixed || !h->distinct_words[ag.log_index] ||
+                ++ndist > kSpecDistinct)
+                return false;
+        }
         if (ag.has_operand) {
             if (ag.src.is_const) return false;
             F.agg_col[a] = ag.src.col;
@@ -751,6 +768,7 @@ SpecSig make_plan_sig(const n1k_handle* h, const FastArgs& F) {
         g.aggs[a].kind = P.aggs[a].kind;
         g.aggs[a].has_operand = P.aggs[a].has_operand;
         g.aggs[a].col = P.aggs[a].has_operand ? F.agg_col[a] : 0u;
+        g.aggs[a].distinct = P.aggs[a].distinct ? 1u : 0u;
     }
     return g;
 }
@@ -830,11 +848,41 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     // DIRECT tables may take (almost) the whole 160 KiB LDS of a CU: occupancy is chosen from the table size
     const uint32_t direct_max_slots = (uint32_t)std::min<uint64_t>((156u * 1024u) / (P.lds_words * 8), 1u << 15);
     if (h->opt_agg_mode != N1K_MODE_LDS_HASH && build_fast_args(h, direct_max_slots, F)) {
+        // Shapes with COUNT(DISTINCT): the specialised kernels keep nothing of a DISTINCT aggregate in the workgroup
+        // table (its member words go to the hash regions), so they run on a copy of the program with a compact LDS layout
+        Program Pc;
+        uint32_t ndist = 0;
+        for (uint32_t a = 0; a < P.naggs; a++) ndist += P.aggs[a].distinct ? 1u : 0u;
+        if (ndist) {
+            Pc = P;
+            uint32_t w = 1;
+            for (uint32_t a = 0; a < Pc.naggs; a++) {
+                AggSpec& ag = Pc.aggs[a];
+                ag.lds_off = w;
+                if (ag.distinct) ag.lds_n = 0;
+                else w += (ag.kind == AGG_COUNT || ag.kind == AGG_COUNTN) ? 1u : (ag.kind == AGG_SUM ? kLdsWordsSum : (ag.kind == AGG_AVG ? kLdsWordsAvg : kWordsMinMax));
+            }
+            Pc.lds_words = w;
+        }
+        const Program& P = ndist ? Pc : h->prog;  // (shadows the handle's program for the launches below)
         const uint32_t table_bytes = F.lds_slots * P.lds_words * 8;
+        // the word scatter's LDS (write-combining slots and chunk state per DISTINCT aggregate, n1k_spec.h: WcLds) and, in
+        // what is left of the workgroup's share of the CU, its "already logged" caches
+        const uint32_t scatter_bytes = ndist * (256u * 16u * 8u + 8u * 256u * 4u) + (ndist ? 64u : 0u);
+        uint32_t dcache_slots = 0;
+        if (ndist) {
+            const uint32_t without = table_bytes + scatter_bytes;
+            const uint32_t share = 160u * 1024u / std::max(1u, std::min(3u, 160u * 1024u / (without + 512u)));
+            for (uint32_t sl = 4096; sl >= 64; sl >>= 1)
+                if (without + ndist * sl * 8u + 512u <= share) { dcache_slots = sl; break; }
+        }
+        const uint32_t lds_total = table_bytes + scatter_bytes + ndist * dcache_slots * 8u;
         // workgroups per CU that fit: 512 threads x 3 (<= 48 KiB each), x 2 (<= 72 KiB), else 1024 threads x 1
         uint32_t fblock = h->opt_block == 1024 || h->opt_block == 512 ? h->opt_block : (table_bytes <= 72 * 1024 ? 512u : 1024u);
-        uint32_t per_cu = fblock == 512 ? (table_bytes <= 48 * 1024 ? 3u : (table_bytes <= 72 * 1024 ? 2u : 1u))
-                                        : (table_bytes <= 72 * 1024 ? 2u : 1u);
+        if (ndist) fblock = 512;
+        uint32_t per_cu = fblock == 512 ? (lds_total <= 48 * 1024 ? 3u : (lds_total <= 72 * 1024 ? 2u : 1u))
+                                        : (lds_total <= 72 * 1024 ? 2u : 1u);
+        if (ndist) per_cu = std::max(1u, std::min(3u, 160u * 1024u / (lds_total + 512u)));  // (two workgroups of 80 KiB fit a CU)
         uint32_t frpl = h->opt_rows_per_lane;
         uint32_t fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
         // slabs + merge kernel pay off once the table is more than a few KiB
@@ -862,7 +910,68 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
         }
         h->stats.spec_kernel = spec ? 1u : (jit ? 2u : 0u);
-        if (F.hashed && !spec && !jit) goto interpreter;  // the bounded-shape kernel is DIRECT only
+        if ((F.hashed || ndist) && !spec && !jit) goto interpreter;  // the bounded-shape kernel is DIRECT only, no DISTINCT
+        WordLogArgs L;
+        memset(&L, 0, sizeof L);
+        if (ndist) {
+            // hash regions: 256 per DISTINCT aggregate, each with room for its share of all rows pushed so far plus a
+            // quarter (mix64 spreads distinct words evenly; many copies of few words overflow into the plain word log)
+            const uint64_t rows_total = h->row_base + b->nrows;
+            // (every workgroup of a launch reserves two chunks per region ahead of its words and pads what it leaves)
+            {
+                const uint64_t per_launch = std::min<uint64_t>(b->nrows, 1ull << 31);
+                const uint64_t tiles4 = (per_launch / 1024 + 1 + 3) / 4;  // >= the tiles of a launch (1024+ rows each) / 4
+                // three lines of 16 words per workgroup and region, plus a line per word that found its region's slots full
+                h->wregion_reserved += ((std::min<uint64_t>(fgrid, tiles4) + 1) * 3 * 16 + per_launch / 8192 + 64) * ((b->nrows >> 31) + 1);
+            }
+            uint64_t need = h->opt_region_cap ? h->opt_region_cap : (rows_total + rows_total / 4) / 256 + h->wregion_reserved + 4096;
+            need = (need + 15) / 16 * 16;  // whole 128-byte lines
+            if (!h->d_wcursor.p) {
+                HIP_TRY(h, h->d_wcursor.ensure(kMaxDistinct * 256 * kCursorStride));
+                HIP_TRY(h, hipMemsetAsync(h->d_wcursor.p, 0, kMaxDistinct * 256 * kCursorStride * sizeof(unsigned long long), h->stream));
+            }
+            if (need > h->wregion_cap) {
+                const uint64_t ncap = (std::max<uint64_t>(need, h->wregion_cap * 2) + 15) / 16 * 16;
+                if (ncap >= 0xFFFFFF00ull) return fail(h, N1K_OOM, "COUNT(DISTINCT): more than 2^32 words per hash region");
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                for (uint32_t a = 0; a < P.naggs; a++) {
+                    if (!P.aggs[a].distinct) continue;
+                    const uint32_t li = P.aggs[a].log_index;
+                    DevBuf<uint64_t> nb;
+                    HIP_TRY(h, nb.ensure(256 * ncap));
+                    if (h->wregion_cap && h->wregion_used)
+                        HIP_TRY(h, launch_regrow_regions(h->d_wregion[li].p, h->wregion_cap, nb.p, ncap, h->d_wcursor.p + (size_t)li * 256 * kCursorStride, h->stream));  // (clamps the cursors of regions that had overflowed)
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                    h->d_wregion[li].release();
+                    h->d_wregion[li] = nb;
+                }
+                h->wregion_cap = ncap;
+            }
+            uint32_t d = 0;
+            for (uint32_t a = 0; a < P.naggs; a++) {
+                if (!P.aggs[a].distinct) continue;
+                const uint32_t li = P.aggs[a].log_index;
+                L.region[d] = h->d_wregion[li].p;
+                L.region_cursor[d] = h->d_wcursor.p + (size_t)li * 256 * kCursorStride;
+                L.over_word[d] = A.log_word[li];
+                L.log_key[d] = A.log_key[li];
+                L.log_val[d] = A.log_val[li];
+                L.log_cls[d] = A.log_cls[li];
+                L.log_index[d] = li;
+                d++;
+            }
+            L.region_cap = h->wregion_cap;
+            L.over_cursor = A.word_cursor;
+            L.over_hist = A.word_hist;
+            L.over_capacity = A.log_capacity;
+            L.log_cursor = A.log_cursor;
+            L.log_capacity = A.log_capacity;
+            L.nw_key_bits = h->nw_key_bits;
+            L.nw_val_bits = h->nw_val_bits;
+            L.dcache_slots = (h->opt_spec_debug & 4u) ? 0u : dcache_slots;
+            L.pad = h->opt_spec_debug;
+            h->wregion_used = true;
+        }
         hipEvent_t e0 = get_event(h), e1 = get_event(h);
         if (e0) (void)hipEventRecord(e0, h->stream);
         const uint64_t chunk = 1ull << 31;  // 32-bit row indices inside one launch
@@ -886,6 +995,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 uint64_t items = wide ? n_main / 2 : n_main;
                 uint32_t rpl = wide ? 2 : 4;
                 uint64_t tiles = (items + (uint64_t)fblock * rpl - 1) / ((uint64_t)fblock * rpl);
+                if (ndist) tiles = (tiles + 3) / 4;  // a workgroup reserves chunks in every hash region: give it a few tiles to fill them
                 uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(fgrid, tiles));
                 F.slabs = nullptr;
                 if (use_slabs && g > 1) {
@@ -894,8 +1004,8 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                     F.slabs = h->d_slabs.p;
                     F.block_selected = h->d_block_sel.p;
                 }
-                if (spec) HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, h->stream));
-                else HIP_TRY(h, jit_launch(jit, P, F, h->table, h->d_counters.p + 1, g, wide, h->stream));
+                if (spec) HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, L, h->stream));
+                else HIP_TRY(h, jit_launch(jit, P, F, h->table, h->d_counters.p + 1, g, wide, L, ndist, h->stream));
                 if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
                 F.slabs = nullptr;
                 if (n_main < n) {
@@ -906,8 +1016,8 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                     }
                     F.nrows = (uint32_t)(n - n_main);
                     F.row_base += n_main;
-                    if (spec) HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, 1, fblock, false, h->stream));
-                    else HIP_TRY(h, jit_launch(jit, P, F, h->table, h->d_counters.p + 1, 1, false, h->stream));
+                    if (spec) HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, 1, fblock, false, L, h->stream));
+                    else HIP_TRY(h, jit_launch(jit, P, F, h->table, h->d_counters.p + 1, 1, false, L, ndist, h->stream));
                 }
                 continue;
             }
@@ -1185,6 +1295,7 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
             R.shift = 56 - 8 * l;
             R.hist = h->d_hist.p;
             R.cursor = h->d_cursor.p;
+            R.cursor_stride = nbins == 1 ? kCursorStride : 1u;  // one segment: its 256 cursors would share 16 lines
             R.out_start = h->d_seg[l + 1].p;
             uint64_t tiles = (nrec + 8191) / 8192;
             uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / nbins + (nbins > 1 ? 8 : 0), tiles));
@@ -1467,6 +1578,10 @@ void n1k_destroy(n1k_handle* h) {
         h->d_cursor.release();
         h->d_dcounts.release();
         h->d_word_hist.release();
+        for (uint32_t d = 0; d < kMaxDistinct; d++) h->d_wregion[d].release();
+        h->d_wcursor.release();
+        h->d_woff.release();
+        h->d_wgather.release();
         h->d_wide_int.release();
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -1520,6 +1635,9 @@ n1k_status n1k_reset(n1k_handle* h) {
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
         if (h->d_word_hist.p) HIP_TRY(h, hipMemsetAsync(h->d_word_hist.p, 0, kMaxDistinct * 256 * sizeof(unsigned long long), h->stream));
+        if (h->d_wcursor.p) HIP_TRY(h, hipMemsetAsync(h->d_wcursor.p, 0, kMaxDistinct * 256 * kCursorStride * sizeof(unsigned long long), h->stream));
+        h->wregion_used = false;
+        h->wregion_reserved = 0;
         if (h->prog.wide_int) {
             const size_t n = (size_t)1 << h->prog.wide_bits;
             HIP_TRY(h, hipMemsetAsync(h->d_wide_int.p, 0xFF, n * 8, h->stream));
@@ -1582,6 +1700,13 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         uint32_t v = 64;
         while (v < (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 8192)) v <<= 1;
         h->opt_distinct_set_slots = v;
+    } else if (n == "spec_debug") {
+        h->opt_spec_debug = (uint32_t)value;
+    } else if (n == "distinct_region_cap") {
+        h->opt_region_cap = (uint64_t)std::max<int64_t>(value, 0);
+    } else if (n == "dedupe_block") {
+        if ((value | 1) != 257 && (value | 1) != 513 && (value | 1) != 1025) return fail(h, N1K_INVALID, "dedupe_block must be 256, 512 or 1024 (+1: probe word by word)");
+        h->opt_dedupe_block = (uint32_t)value;
     } else if (n == "json_threads") {
         h->opt_json_threads = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64);
     } else if (n == "partition_min_rows") {
@@ -1758,14 +1883,38 @@ n1k_status n1k_sync(n1k_handle* h) {
     return N1K_OK;
 }
 
+// where the de-duplication kernel counts the new members of each group: by the packed key itself when the plan has one
+// dictionary key of a small domain, in an LDS hash table while the group table is small, else per member in HBM
+static void dedupe_counters(const n1k_handle* h, DedupeArgs& D) {
+    D.direct_keys = 0;
+    D.lds_counters = 0;
+    const Program& P = h->prog;
+    if (P.nkeys == 1 && P.keys[0].mode == KEYM_DICT && P.keys[0].shift == 0 && h->dict.size() + 2 <= 8192)
+        D.direct_keys = (uint32_t)h->dict.size() + 2;
+    else if (P.nkeys == 0)
+        D.direct_keys = 1;
+    else if (h->table.capacity <= 4096)
+        D.lds_counters = (uint32_t)h->table.capacity;
+}
+
+// workgroups of the de-duplication kernel: as many per CU as their LDS (set + member counters) and threads allow
+static uint32_t dedupe_grid(const n1k_handle* h, const DedupeArgs& D, uint32_t nbins) {
+    const size_t shmem = distinct_dedupe_lds(D) + 512;
+    const uint32_t by_threads = 2048u / std::max(256u, h->opt_dedupe_block & ~1u);
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(by_threads, (160 * 1024) / shmem));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nbins, (uint64_t)h->num_cus * per_cu));
+}
+
 // COUNT(DISTINCT) over the one-word members of one aggregate: radix partition of the word log until a bin's distinct
 // words fit an LDS set, per-bin LDS sets, member counts added to the groups' set sizes (see n1k_kernels.hip).
-static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64_t nwords) {
+static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64_t nwords, bool hist_counted = true,
+                                        const uint64_t* log = nullptr) {
     const uint32_t set_slots = h->opt_distinct_set_slots;
     const uint64_t per_bin = std::max<uint64_t>(set_slots / 4, 16);  // expected distinct words per final bin: load <= 1/4
     const uint32_t levels = h->opt_distinct_levels >= 0 ? (uint32_t)h->opt_distinct_levels
                                                         : (nwords <= per_bin ? 0u : (nwords <= 256 * per_bin ? 1u : 2u));
-    const uint64_t* words = h->d_log_word[ag.log_index].p;
+    if (!log) log = h->d_log_word[ag.log_index].p;
+    const uint64_t* words = log;
     HIP_TRY(h, h->d_seg[0].ensure(2));
     HIP_TRY(h, h->d_seg[1].ensure(257));
     HIP_TRY(h, h->d_seg[2].ensure(65537));
@@ -1787,9 +1936,10 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
         R.nseg = nbins;
         R.shift = 56 - 8 * l;
         // the scan kernels counted the first digit of every word they logged (ScanArgs::word_hist)
-        const bool counted = l == 0 && h->d_word_hist.p != nullptr;
+        const bool counted = l == 0 && hist_counted && h->d_word_hist.p != nullptr;
         R.hist = counted ? h->d_word_hist.p + (size_t)ag.log_index * 256 : h->d_hist.p;
         R.cursor = h->d_cursor.p;
+        R.cursor_stride = nbins == 1 ? kCursorStride : 1u;  // one segment: its 256 cursors would share 16 lines
         R.out_start = h->d_seg[l + 1].p;
         // slices per segment: enough workgroups to fill the GPU, never less than one tile each on average
         uint64_t tiles = (nwords + 8191) / 8192;
@@ -1799,7 +1949,7 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
         bin_start = R.out_start;
         nbins *= 256;
     }
-    uint32_t* d_overflow = (uint32_t*)(h->d_counters.p + 20);
+    uint32_t* d_overflow = (uint32_t*)(h->d_counters.p + 24);
     HIP_TRY(h, hipMemsetAsync(h->d_dcounts.p, 0, (h->table.capacity + 2) * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipMemsetAsync(d_overflow, 0, 8, h->stream));
     DedupeArgs D{};
@@ -1811,12 +1961,8 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
     D.glob_off = ag.glob_off;
     D.counts = h->d_dcounts.p;
     D.overflow = d_overflow;
-    D.lds_counters = h->table.capacity <= 4096 ? (uint32_t)h->table.capacity : 0;  // LDS table of per-group member counts
-    // 512-thread workgroups, as many per CU as their LDS (set + group counters) allows
-    const size_t shmem = (size_t)set_slots * 8 + (size_t)D.lds_counters * 12 + 512;
-    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
-    uint32_t grid = (uint32_t)std::min<uint64_t>(nbins, (uint64_t)h->num_cus * per_cu);
-    HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, grid, h->stream));
+    dedupe_counters(h, D);
+    HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, dedupe_grid(h, D, nbins), h->opt_dedupe_block, h->stream));
     uint32_t overflow = 0;
     HIP_TRY(h, hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1828,12 +1974,100 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
         HIP_TRY(h, h->d_wtable.ensure(cap));
         HIP_TRY(h, hipMemsetAsync(h->d_wtable.p, 0xFF, cap * 8, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_dcounts.p, 0, (h->table.capacity + 2) * sizeof(unsigned long long), h->stream));
-        HIP_TRY(h, launch_distinct_words_global(h->table, h->d_log_word[ag.log_index].p, nwords, h->d_wtable.p, cap - 1,
+        HIP_TRY(h, launch_distinct_words_global(h->table, log, nwords, h->d_wtable.p, cap - 1,
                                                 h->nw_val_bits + 3, h->d_dcounts.p, h->d_errp, h->num_cus * 8, h->stream));
         h->distinct_path |= 4u;
     }
     HIP_TRY(h, launch_distinct_add_counts(h->prog, h->table, h->d_dcounts.p, ag.glob_off, h->stream));
     return N1K_OK;
+}
+
+// The same when the specialised scan scattered the words into its 256 hash regions already (the first partition pass
+// is done): one more pass into bins of fixed capacity — no histogram, mix64 spreads distinct words evenly — and the LDS
+// sets.  Whenever that optimism fails (a region or a bin overflowed: many copies of few words; an LDS set too small;
+// words of the interpreter kernel in the plain log as well) everything is gathered into one log and the exact path
+// above runs instead.  `rc` = the regions' word counts, `nover` = words in the plain log.
+static n1k_status distinct_regions_finish(n1k_handle* h, const AggSpec& ag, const unsigned long long* rc, uint64_t nover,
+                                          bool force_exact, bool* deferred) {
+    const uint32_t li = ag.log_index;
+    const uint64_t cap = h->wregion_cap;
+    uint64_t total = 0, biggest = 0;
+    bool spilled = false;
+    for (uint32_t b = 0; b < 256; b++) {
+        spilled |= rc[b] > cap;
+        const uint64_t c = std::min<uint64_t>(rc[b], cap);
+        total += c;
+        biggest = std::max(biggest, c);
+    }
+    if (total == 0) return nover ? distinct_words_finish(h, ag, nover) : N1K_OK;
+    const uint32_t set_slots = h->opt_distinct_set_slots;
+    const uint64_t per_bin = std::max<uint64_t>(set_slots / 4, 16);
+    bool exact = force_exact || spilled || nover > 0 || h->opt_distinct_levels == 0;
+    uint32_t* d_overflow = (uint32_t*)(h->d_counters.p + 20);  // [0] an LDS set overflowed, [1] a bin of the second pass
+    if (!exact) {
+        // Optimistic and without a host synchronisation: the member counts are only added to the groups when neither flag
+        // came up (the kernel checks), and n1k_finish reads the flags together with the results (*deferred)
+        const bool second = h->opt_distinct_levels >= 0 ? h->opt_distinct_levels == 2 : total > 256 * per_bin;
+        HIP_TRY(h, h->d_dcounts.ensure(h->table.capacity + 2));
+        HIP_TRY(h, hipMemsetAsync(h->d_dcounts.p, 0, (h->table.capacity + 2) * sizeof(unsigned long long), h->stream));
+        DedupeArgs D{};
+        D.words = h->d_wregion[li].p;
+        D.bin_count = h->d_wcursor.p + (size_t)li * 256 * kCursorStride;
+        D.count_stride = kCursorStride;
+        D.bin_stride = cap;
+        D.nbins = 256;
+        if (second) {
+            const uint64_t mean = biggest / 256 + 1;
+            const uint64_t bin_cap = mean + mean / 2 + 256;
+            HIP_TRY(h, h->d_part[0].ensure(65536 * bin_cap));
+            HIP_TRY(h, h->d_cursor.ensure(65536));
+            RadixArgs R{};
+            R.src = h->d_wregion[li].p;
+            R.dst = h->d_part[0].p;
+            R.seg_count = h->d_wcursor.p + (size_t)li * 256 * kCursorStride;
+            R.seg_stride = cap;
+            R.nseg = 256;
+            R.shift = 48;
+            R.cursor = h->d_cursor.p;
+            R.bin_cap = bin_cap;
+            R.overflow = d_overflow + 1;
+            const uint64_t tiles = (biggest + 8191) / 8192;
+            const uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / 256 + 8, tiles));
+            HIP_TRY(h, launch_radix_pass(R, slices, h->stream, false));
+            D.words = R.dst;
+            D.bin_count = h->d_cursor.p;
+            D.count_stride = 1;
+            D.bin_stride = bin_cap;
+            D.nbins = 65536;
+        }
+        D.set_slots = set_slots;
+        D.key_shift = h->nw_val_bits + 3;
+        D.glob_off = ag.glob_off;
+        D.counts = h->d_dcounts.p;
+        D.overflow = d_overflow;
+        dedupe_counters(h, D);
+        HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, dedupe_grid(h, D, D.nbins), h->opt_dedupe_block, h->stream));
+        HIP_TRY(h, launch_distinct_add_counts(h->prog, h->table, h->d_dcounts.p, ag.glob_off, h->stream, d_overflow));
+        h->distinct_path |= 2u;
+        *deferred = true;
+        return N1K_OK;
+    }
+    // exact path: the regions' words join the plain log (behind its own words), then partition by histogram
+    std::vector<uint64_t> off(256);
+    uint64_t at = nover;
+    for (uint32_t b = 0; b < 256; b++) {
+        off[b] = at;
+        at += std::min<uint64_t>(rc[b], cap);
+    }
+    // (the regions' padding comes along — "no word" entries every step below skips — so the gathered log has its own buffer)
+    HIP_TRY(h, h->d_wgather.ensure(at));
+    HIP_TRY(h, h->d_woff.ensure(256));
+    if (nover) HIP_TRY(h, hipMemcpyAsync(h->d_wgather.p, h->d_log_word[li].p, nover * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_woff.p, off.data(), 256 * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, launch_compact_regions(h->d_wregion[li].p, cap, h->d_wcursor.p + (size_t)li * 256 * kCursorStride, h->d_woff.p,
+                                      h->d_wgather.p, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // (`off` lives on this stack frame)
+    return distinct_words_finish(h, ag, at, false, h->d_wgather.p);
 }
 
 // value.Collate for result values (value/value.go:69-79 type order; integer.go:100-118, float.go:106-172,
@@ -2050,6 +2284,11 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             memcpy(counters, h->pin_out + total, sizeof counters);
         } else {
             HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+            if (h->wregion_used) {  // the hash regions' word counts travel with the counters: one synchronisation
+                h->wcursor_host.resize((size_t)kMaxDistinct * 256 * kCursorStride);
+                HIP_TRY(h, hipMemcpyAsync(h->wcursor_host.data(), h->d_wcursor.p, h->wcursor_host.size() * sizeof(unsigned long long),
+                                          hipMemcpyDeviceToHost, h->stream));
+            }
             HIP_TRY(h, hipStreamSynchronize(h->stream));
         }
         err_flags = (uint32_t)counters[12];
@@ -2075,9 +2314,13 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     h->r_aggs.clear();
     h->r_parts.clear();
     h->r_rep.clear();
+    bool sets_exact = false, sets_deferred = false;  // the optimistic COUNT(DISTINCT) path reports failure with the results
+redo_sets:
+    sets_deferred = false;
     if (ng > 0 && h->has_distinct) {
         // K6: de-duplicate the logged (group, value) pairs of every DISTINCT aggregate (≙ Set.Len(), value/set.go:198-215)
         h->distinct_path = 0;
+        if (h->wregion_used) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 20, 0, 8, h->stream));
         for (uint32_t a = 0; a < na; a++) {
             const AggSpec& ag = h->prog.aggs[a];
             if (!ag.distinct) continue;
@@ -2106,7 +2349,13 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
                 HIP_TRY(h, launch_distinct_insert(h->prog, h->table, D, h->d_errp, h->stream));
                 h->distinct_path |= 1u;
             }
-            if (nwords) {
+            if (h->opt_spec_debug & 8u) continue;
+            if (h->wregion_used && h->distinct_words[ag.log_index]) {
+                unsigned long long rc[256];
+                for (uint32_t b = 0; b < 256; b++) rc[b] = h->wcursor_host[((size_t)ag.log_index * 256 + b) * kCursorStride];
+                n1k_status st = distinct_regions_finish(h, ag, rc, nwords, sets_exact, &sets_deferred);
+                if (st != N1K_OK) return st;
+            } else if (nwords) {
                 n1k_status st = distinct_words_finish(h, ag, nwords);
                 if (st != N1K_OK) return st;
             }
@@ -2164,9 +2413,17 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
                 ng = ncand;
             }
             h->out_host.resize(copy_bytes);
+            uint32_t veto[2] = {0, 0};
             HIP_TRY(h, hipMemcpyAsync(h->out_host.data(), src, copy_bytes, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
+            if (sets_deferred) HIP_TRY(h, hipMemcpyAsync(veto, h->d_counters.p + 20, 8, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (sets_deferred && (veto[0] | veto[1])) {
+                // a set or a bin overflowed on the optimistic path: no counts were added; once more, exactly
+                sets_exact = true;
+                ng = counters[1];
+                goto redo_sets;
+            }
             hp = h->out_host.data();
         }
         h->r_keys.assign((const n1k_value*)hp, (const n1k_value*)hp + ng * nk);

@@ -70,8 +70,8 @@ std::string jit_source(const SpecSig& g) {
     };
     auto agg = [&](int a) {
         std::ostringstream x;
-        if (a < g.naggs) x << "SpecAgg{" << g.aggs[a].kind << "u, " << g.aggs[a].has_operand << "u, " << g.aggs[a].col << "u}";
-        else x << "SpecAgg{0u, 0u, 0u}";
+        if (a < g.naggs) x << "SpecAgg{" << g.aggs[a].kind << "u, " << g.aggs[a].has_operand << "u, " << g.aggs[a].col << "u, " << g.aggs[a].distinct << "u}";
+        else x << "SpecAgg{0u, 0u, 0u, 0u}";
         return x.str();
     };
     o << "struct SpecJ {\n"
@@ -84,11 +84,11 @@ std::string jit_source(const SpecSig& g) {
       << "    static constexpr SpecAgg aggs[kFastAggs] = {" << agg(0) << ", " << agg(1) << ", " << agg(2) << ", " << agg(3)
       << ", " << agg(4) << "};\n};\n}  // namespace n1k\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_wide(const n1k::Program P, const n1k::FastArgs F,\n"
-      << "        const n1k::GlobalTable G, unsigned long long* ngroups) {\n"
-      << "    n1k::scan_spec_body<n1k::SpecJ, 2, 512, true>(P, F, G, ngroups);\n}\n"
+      << "        const n1k::GlobalTable G, unsigned long long* ngroups, const n1k::WordLogArgs L) {\n"
+      << "    n1k::scan_spec_body<n1k::SpecJ, 2, 512, true>(P, F, G, ngroups, L);\n}\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
-      << "        const n1k::GlobalTable G, unsigned long long* ngroups) {\n"
-      << "    n1k::scan_spec_body<n1k::SpecJ, 4, 512, false>(P, F, G, ngroups);\n}\n";
+      << "        const n1k::GlobalTable G, unsigned long long* ngroups, const n1k::WordLogArgs L) {\n"
+      << "    n1k::scan_spec_body<n1k::SpecJ, 4, 512, false>(P, F, G, ngroups, L);\n}\n";
     return o.str();
 }
 
@@ -122,9 +122,9 @@ const JitKernel* jit_get(const SpecSig& sig) {
 }
 
 hipError_t jit_launch(const JitKernel* k, const Program& P, const FastArgs& F, const GlobalTable& G,
-                      unsigned long long* ngroups, uint32_t grid, bool wide, hipStream_t st) {
-    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8;
-    void* args[] = {(void*)&P, (void*)&F, (void*)&G, (void*)&ngroups};
+                      unsigned long long* ngroups, uint32_t grid, bool wide, const WordLogArgs& L, uint32_t ndistinct, hipStream_t st) {
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * ndistinct * 8;
+    void* args[] = {(void*)&P, (void*)&F, (void*)&G, (void*)&ngroups, (void*)&L};
     return hipModuleLaunchKernel(wide ? k->wide : k->narrow, grid, 1, 1, 512, 1, 1, (unsigned)shmem, st, args, nullptr);
 }
 

@@ -27,6 +27,6 @@ const JitKernel* jit_get(const SpecSig& sig);
 // Compile only (no GPU needed): returns true when the shape builds for gfx950.
 bool jit_compile_check(const SpecSig& sig, std::string* log);
 hipError_t jit_launch(const JitKernel* k, const Program& P, const FastArgs& F, const GlobalTable& G,
-                      unsigned long long* ngroups, uint32_t grid, bool wide, hipStream_t st);
+                      unsigned long long* ngroups, uint32_t grid, bool wide, const WordLogArgs& L, uint32_t ndistinct, hipStream_t st);
 
 }  // namespace n1k

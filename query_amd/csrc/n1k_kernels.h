@@ -68,12 +68,17 @@ hipError_t launch_distinct_layout(const Program& P, const GlobalTable& G, const 
 // COUNT(DISTINCT) over one-word members: one 256-bin partition pass (histogram, offsets, LDS-staged scatter) ...
 hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st, bool have_hist = false);
 // ... the per-bin LDS sets, the global-memory fallback, and the hand-over of the member counts to the set sizes
-hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, hipStream_t st);
+hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, uint32_t block, hipStream_t st);
+size_t distinct_dedupe_lds(const DedupeArgs& D);
+hipError_t launch_compact_regions(const uint64_t* region, uint64_t cap, const unsigned long long* count, const uint64_t* off,
+                                  uint64_t* dst, hipStream_t st);
+hipError_t launch_regrow_regions(const uint64_t* src, uint64_t src_cap, uint64_t* dst, uint64_t dst_cap, unsigned long long* count,
+                                 hipStream_t st);
 hipError_t launch_distinct_words_global(const GlobalTable& G, const uint64_t* words, uint64_t n, uint64_t* table, uint64_t mask,
                                         uint32_t key_shift, unsigned long long* counts, uint32_t* err_flags, uint32_t grid,
                                         hipStream_t st);
 hipError_t launch_distinct_add_counts(const Program& P, const GlobalTable& G, const unsigned long long* counts, uint32_t glob_off,
-                                      hipStream_t st);
+                                      hipStream_t st, const uint32_t* veto = nullptr);
 hipError_t launch_distinct_insert(const Program& P, const GlobalTable& G, const DistinctArgs& D, uint32_t* err_flags,
                                   hipStream_t st);
 hipError_t launch_export_partials(const Program& P, const GlobalTable& G, uint32_t nparts, uint64_t cap, uint64_t* out,
@@ -87,7 +92,7 @@ struct SpecEntry {
     const char* name;
     SpecSig sig;
     hipError_t (*launch)(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
-                         uint32_t grid, uint32_t block, bool wide, hipStream_t st);
+                         uint32_t grid, uint32_t block, bool wide, const WordLogArgs& L, hipStream_t st);
 };
 const std::vector<SpecEntry>& spec_registry();
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,

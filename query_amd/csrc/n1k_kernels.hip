@@ -254,34 +254,9 @@ __global__ void arith_kernel(const ArithArgs A) {
 }
 
 // ------------------------------------------------------------------ K6: DISTINCT sets
-//
-// value.Set (value/set.go:22-110) keeps one hash map per type: ints and integral floats share the int map, other
-// floats their own, strings / arrays / objects are keyed by text (here: dictionary code), booleans by value.
-// CountDistinct adds every operand of type > NULL (algebra/agg_count_distinct.go:84-95), CountnDistinct every
-// NUMBER.  Returns false when the operand does not enter the set.
-N1K_DEV bool distinct_classify(uint32_t kind, uint32_t tag, uint64_t p, uint32_t& cls, uint64_t& val) {
-    if (tag <= T_NULL) return false;
-    if (tag == T_INT) { cls = DC_INT; val = p; return true; }
-    if (tag == T_FLOAT) {
-        double d = as_f64(p);
-        if (is_int_f64(d)) { cls = DC_INT; val = (uint64_t)go_f2i(d); }
-        else { cls = DC_FLOAT; val = p; }
-        return true;
-    }
-    if (kind != AGG_COUNT) return false;  // COUNTN / SUM / AVG (DISTINCT): NUMBER operands only
-    cls = DC_OTHER;
-    val = ((uint64_t)tag << 40) | (p & 0xFFFFFFFFFFull);
-    return true;
-}
-
-// One-word form of a (group key, class, value) member of a COUNT(DISTINCT) set, when both parts are small enough
-// (ScanArgs::nw_*).  Non-integral floats never are; DC_OTHER values (tag << 40 | code) are re-packed as code << 4 | tag.
+// (distinct_classify / member_word_bits / radix_bin live in n1k_tables.h: the specialised scan uses them too)
 N1K_DEV bool member_word(const ScanArgs& A, uint64_t key, uint32_t cls, uint64_t val, uint64_t& word) {
-    if (cls == DC_FLOAT) return false;
-    uint64_t v = cls == DC_INT ? zigzag((int64_t)val) : (((val & 0xFFFFFFFFFFull) << 4) | (val >> 40));
-    if ((key >> A.nw_key_bits) != 0ull || (v >> A.nw_val_bits) != 0ull) return false;
-    word = (key << (A.nw_val_bits + 3)) | ((uint64_t)cls << A.nw_val_bits) | v;
-    return true;
+    return member_word_bits(A.nw_key_bits, A.nw_val_bits, key, cls, val, word);
 }
 
 // Workgroup-wide reservation of `mine` consecutive entries per thread behind *cursor: returns this thread's first
@@ -417,11 +392,18 @@ __global__ __launch_bounds__(BLOCK) void distinct_insert_kernel(const Program P,
 // counts the new members per group.  Equal words always meet in the same bin, so the bins are independent.
 constexpr int kRadixBlock = 512, kRadixPer = 16, kRadixTile = kRadixBlock * kRadixPer;  // 8192 words = 64 KB staged
 
-N1K_DEV uint32_t radix_bin(uint64_t w, uint32_t shift) { return (uint32_t)(mix64(w) >> shift) & 255u; }
 
 // slice of segment `s` that workgroup blockIdx.x owns (the same in the histogram and the scatter pass)
 N1K_DEV void radix_slice(const RadixArgs& A, uint32_t s, uint64_t& lo, uint64_t& hi) {
-    const uint64_t s0 = A.seg_start[s], s1 = A.seg_start[s + 1];
+    uint64_t s0, s1;
+    if (A.seg_count) {  // hash regions of fixed capacity
+        const uint64_t c = A.seg_count[(size_t)s * kCursorStride];
+        s0 = (uint64_t)s * A.seg_stride;
+        s1 = s0 + (c < A.seg_stride ? c : A.seg_stride);
+    } else {
+        s0 = A.seg_start[s];
+        s1 = A.seg_start[s + 1];
+    }
     uint64_t chunk = (s1 - s0 + gridDim.x - 1) / gridDim.x;
     chunk = (chunk + kRadixTile - 1) / kRadixTile * kRadixTile;
     lo = s0 + (uint64_t)blockIdx.x * chunk;
@@ -455,17 +437,18 @@ __global__ __launch_bounds__(256) void radix_offsets_kernel(const RadixArgs A) {
         __syncthreads();
     }
     const unsigned long long excl = sc[t] - v + A.seg_start[s];
-    A.cursor[(size_t)s * 256 + t] = excl;
+    A.cursor[((size_t)s * 256 + t) * (A.cursor_stride ? A.cursor_stride : 1u)] = excl;
     A.out_start[(size_t)s * 256 + t] = excl;
     if (s == A.nseg - 1 && t == 255) A.out_start[(size_t)A.nseg * 256] = A.seg_start[A.nseg];
 }
 
+template <bool RECORDS>
 __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixArgs A) {
     __shared__ uint64_t stage[kRadixTile];
-    __shared__ uint8_t sbin[kRadixTile];  // bin of every staged position (records only)
+    __shared__ uint8_t sbin[RECORDS ? kRadixTile : 1];  // bin of every staged position (records only)
     __shared__ uint32_t cnt[256], pre[256], wsum[4];
     __shared__ unsigned long long gbase[256];
-    const uint32_t tid = threadIdx.x, s = blockIdx.y;
+    const uint32_t tid = threadIdx.x, s = blockIdx.y, cstride = A.cursor_stride ? A.cursor_stride : 1u;
     uint64_t lo, hi;
     radix_slice(A, s, lo, hi);
     for (uint64_t tile = lo; tile < hi; tile += kRadixTile) {
@@ -474,12 +457,19 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
         __syncthreads();
         uint64_t w[kRadixPer];
         uint32_t rk[kRadixPer];  // bin << 16 | rank of the word inside (tile, bin)
+        // (all loads of the tile first, no branch in between: sixteen of them in flight per thread)
+#pragma unroll
+        for (int j = 0; j < kRadixPer; j++) {
+            const uint32_t p = (uint32_t)j * kRadixBlock + tid;
+            w[j] = p < n ? A.src[tile + p] : kEmptyKey;
+        }
 #pragma unroll
         for (int j = 0; j < kRadixPer; j++) {
             const uint32_t p = (uint32_t)j * kRadixBlock + tid;
             rk[j] = 0xFFFFFFFFu;
-            if (p < n) {
-                w[j] = A.src[tile + p];
+            // (kEmptyKey among the words = "no word", the padding of the hash regions: dropped on the way into bins of
+            //  fixed capacity; the exact pass moves it like any word — its histogram counted it — and the sets skip it)
+            if (p < n && (RECORDS || !A.bin_cap || w[j] != kEmptyKey)) {
                 const uint32_t b = radix_bin(w[j], A.shift);
                 rk[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
             }
@@ -501,7 +491,7 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
             uint32_t before = 0;
             for (uint32_t w = 0; w < (tid >> 6); w++) before += wsum[w];
             pre[tid] = before + incl - mine;
-            gbase[tid] = mine ? atomicAdd(&A.cursor[(size_t)s * 256 + tid], (unsigned long long)mine) : 0ull;
+            gbase[tid] = mine ? atomicAdd(&A.cursor[((size_t)s * 256 + tid) * cstride], (unsigned long long)mine) : 0ull;
         }
         __syncthreads();
 #pragma unroll
@@ -509,15 +499,21 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
             if (rk[j] != 0xFFFFFFFFu) stage[pre[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = w[j];
         __syncthreads();
         // the staged tile is ordered by bin: consecutive threads write consecutive words of a bin's run
-        for (uint32_t p = tid; p < n; p += kRadixBlock) {
+        const uint32_t staged = RECORDS ? n : pre[255] + cnt[255];  // (padding words of the hash regions were dropped)
+        for (uint32_t p = tid; p < staged; p += kRadixBlock) {
             const uint64_t x = stage[p];
             const uint32_t b = radix_bin(x, A.shift);
-            A.dst[gbase[b] + (p - pre[b])] = x;
-            if (A.nextra) sbin[p] = (uint8_t)b;
+            const unsigned long long pos = gbase[b] + (p - pre[b]);
+            if (!RECORDS && A.bin_cap) {  // bins of fixed capacity: no histogram pass came before
+                if (pos < A.bin_cap) A.dst[((size_t)s * 256 + b) * A.bin_cap + pos] = x;
+                else *(volatile uint32_t*)A.overflow = 1u;
+            } else
+                A.dst[pos] = x;
+            if (RECORDS) sbin[p] = (uint8_t)b;
         }
         __syncthreads();
         // records: the other arrays follow the same permutation, one at a time through the same staging buffer
-        for (uint32_t e = 0; e < A.nextra; e++) {
+        for (uint32_t e = 0; RECORDS && e < A.nextra; e++) {
 #pragma unroll
             for (int j = 0; j < kRadixPer; j++)
                 if (rk[j] != 0xFFFFFFFFu) stage[pre[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = A.src_pay[e][tile + (uint32_t)j * kRadixBlock + tid];
@@ -542,90 +538,172 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
 }
 
 // one workgroup per bin (persistent over bins): LDS open-addressed set of the bin's words; every first insertion is
-// one more member of its group's set (Set.Len(), value/set.go:198-215), counted in a second LDS table keyed by the
-// packed group key (flushed to the groups once per workgroup) — a look-up of the global group table per new member
-// costs 0.8 ms per 100 M members in scattered loads, the LDS table a quarter of that.
-template <int BLOCK, int U>
+// one more member of its group's set (Set.Len(), value/set.go:198-215), counted in LDS per packed group key — by the
+// key itself when the keys are small (direct_keys), else in a second LDS table keyed by the packed key — and handed
+// to the groups once per workgroup (a look-up of the global group table per new member costs 0.8 ms per 100 M
+// members in scattered loads).  The first words of the NEXT bin are loaded before the current bin is processed:
+// a bin of a few thousand words is one memory latency, which would otherwise be paid bin after bin.
+template <int BLOCK, int U, bool TOGETHER>
 __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P, const GlobalTable G, const DedupeArgs D) {
     extern __shared__ uint64_t dl[];
     uint64_t* set = dl;
-    uint64_t* gkeys = dl + D.set_slots;                       // lds_counters packed keys ...
-    lds_u32* gcnt = (lds_u32*)(dl + D.set_slots + D.lds_counters);  // ... and their member counts
-    const uint32_t tid = threadIdx.x, mask = D.set_slots - 1, gcap = D.lds_counters;
-    for (uint32_t i = tid; i < gcap; i += BLOCK) {
-        *(volatile lds_u64*)lds_word(gkeys, i) = kEmptyKey;
-        gcnt[i] = 0;
+    const uint32_t tid = threadIdx.x, mask = D.set_slots - 1, gcap = D.lds_counters, dk = D.direct_keys;
+    uint64_t* gkeys = dl + D.set_slots;                                                 // hashed: gcap packed keys ...
+    lds_u32* gcnt = (lds_u32*)(dl + D.set_slots + (dk ? 0u : gcap));                    // ... and the member counts
+    if (dk) {
+        for (uint32_t i = tid; i < dk; i += BLOCK) gcnt[i] = 0;
+    } else {
+        for (uint32_t i = tid; i < gcap; i += BLOCK) {
+            *(volatile lds_u64*)lds_word(gkeys, i) = kEmptyKey;
+            gcnt[i] = 0;
+        }
     }
+    auto bounds = [&](uint32_t bin, uint64_t& lo, uint64_t& hi) {
+        lo = hi = 0;
+        if (bin >= D.nbins) return;
+        if (D.bin_count) {
+            const uint64_t c = D.bin_count[(size_t)bin * (D.count_stride ? D.count_stride : 1u)];
+            lo = (uint64_t)bin * D.bin_stride;
+            hi = lo + (c < D.bin_stride ? c : D.bin_stride);
+        } else {
+            lo = D.bin_start[bin];
+            hi = D.bin_start[bin + 1];
+        }
+    };
     uint32_t overflow = 0;
-    for (uint32_t bin = blockIdx.x; bin < D.nbins; bin += gridDim.x) {
-        const uint64_t lo = D.bin_start[bin], hi = D.bin_start[bin + 1];
-        if (lo == hi) continue;
-        __syncthreads();
-        for (uint32_t i = tid; i < D.set_slots; i += BLOCK) *(volatile lds_u64*)lds_word(set, i) = kEmptyKey;
-        __syncthreads();
-        // U words per thread and step, loaded together: a bin of a few thousand words pays one memory latency
-        for (uint64_t base = lo; base < hi; base += (uint64_t)BLOCK * U) {
-            uint64_t w[U];
+    uint32_t bin = blockIdx.x;
+    uint64_t lo, hi;
+    bounds(bin, lo, hi);
+    uint64_t cur[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint64_t i = base + (uint64_t)u * BLOCK + tid;
-                w[u] = i < hi ? D.words[i] : kEmptyKey;
-            }
+    for (int u = 0; u < U; u++) {
+        const uint64_t i = lo + (uint64_t)u * BLOCK + tid;
+        cur[u] = i < hi ? D.words[i] : kEmptyKey;
+    }
+    while (bin < D.nbins) {
+        uint64_t nlo, nhi, nxt[U];
+        bounds(bin + gridDim.x, nlo, nhi);
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (w[u] == kEmptyKey) continue;
-                uint32_t h = (uint32_t)mix64(w[u]) & mask;  // low bits: the partition consumed the high ones
-                int state = 0;                              // 1 fresh, 2 already a member
-                for (int probe = 0; probe < 64 && !state; probe++) {
-                    lds_u64* sp = lds_word(set, h);
-                    unsigned long long cur = lds_peek(sp);
-                    if (cur == w[u]) state = 2;
-                    else if (cur == kEmptyKey) {
-                        unsigned long long expected = kEmptyKey;
-                        if (__hip_atomic_compare_exchange_strong(sp, &expected, (unsigned long long)w[u], __ATOMIC_RELAXED,
-                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                            state = 1;
-                        else if (expected == w[u]) state = 2;
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = nlo + (uint64_t)u * BLOCK + tid;
+            nxt[u] = i < nhi ? D.words[i] : kEmptyKey;
+        }
+        if (lo != hi) {
+            __syncthreads();
+            for (uint32_t i = tid; i < D.set_slots; i += BLOCK) *(volatile lds_u64*)lds_word(set, i) = kEmptyKey;
+            __syncthreads();
+            for (uint64_t base = lo; base < hi; base += (uint64_t)BLOCK * U) {
+                if (base != lo) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint64_t i = base + (uint64_t)u * BLOCK + tid;
+                        cur[u] = i < hi ? D.words[i] : kEmptyKey;
                     }
-                    h = (h + 1) & mask;
                 }
-                if (!state) overflow = 1;  // more distinct words in the bin than the LDS set takes: the caller falls back
-                if (state != 1) continue;
-                const uint64_t key = w[u] >> D.key_shift;
-                if (gcap) {
-                    uint32_t gh = lds_hash(key, gcap);
-                    bool placed = false;
-                    for (uint32_t probe = 0; probe < gcap && !placed; probe++) {
-                        lds_u64* kp = lds_word(gkeys, gh);
-                        unsigned long long cur = lds_peek(kp);
-                        if (cur == kEmptyKey) {
-                            unsigned long long expected = kEmptyKey;
-                            if (__hip_atomic_compare_exchange_strong(kp, &expected, (unsigned long long)key, __ATOMIC_RELAXED,
-                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                                cur = key;
-                            else
-                                cur = expected;
+                // all U words probe together, one compare-and-swap per word and round: the LDS latency of a round is paid
+                // once for the U of them, and a slot that already holds the word answers without a separate read
+                uint32_t hh[U];
+                int state[U];  // 0 probing, 1 fresh, 2 already a member / no word
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint64_t w = cur[u];
+                    // slot in the set: any spreading function will do (the partition hashed with mix64; the words of a
+                    // bin differ in their value and key bits)
+                    uint32_t h = ((uint32_t)w ^ ((uint32_t)(w >> 32) * 0x9E3779B1u)) * 0x85EBCA6Bu;
+                    hh[u] = (h ^ (h >> 15)) & mask;
+                    state[u] = w == kEmptyKey ? 2 : 0;
+                }
+                if (!TOGETHER) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        for (int probe = 0; probe < 64 && !state[u]; probe++) {
+                            lds_u64* sp = lds_word(set, hh[u]);
+                            unsigned long long c = lds_peek(sp);
+                            if (c == cur[u]) state[u] = 2;
+                            else if (c == kEmptyKey) {
+                                unsigned long long expected = kEmptyKey;
+                                if (__hip_atomic_compare_exchange_strong(sp, &expected, (unsigned long long)cur[u], __ATOMIC_RELAXED,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                                    state[u] = 1;
+                                else if (expected == cur[u]) state[u] = 2;
+                            }
+                            hh[u] = (hh[u] + 1) & mask;
                         }
-                        if (cur == key) {
-                            (void)__hip_atomic_fetch_add(gcnt + gh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            placed = true;
-                        }
-                        gh = gh + 1 == gcap ? 0 : gh + 1;
                     }
-                    if (!placed) overflow = 1;  // cannot happen: gcap is the capacity of the group table itself
-                } else {
-                    long long g = global_find(G, key);
-                    if (g < 0) overflow = 1;
-                    else atomicAdd(&D.counts[g], 1ull);
+                }
+                for (int probe = 0; TOGETHER && probe < 64; probe++) {
+                    // a round: read the U slots, then swap into the ones found free (an atomic only where it can succeed)
+                    unsigned long long seen[U];
+                    bool busy = false;
+#pragma unroll
+                    for (int u = 0; u < U; u++) seen[u] = state[u] ? 0ull : lds_peek(lds_word(set, hh[u]));
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (state[u] || seen[u] != kEmptyKey) continue;
+                        (void)__hip_atomic_compare_exchange_strong(lds_word(set, hh[u]), &seen[u], (unsigned long long)cur[u],
+                                                                   __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (seen[u] == kEmptyKey) {  // the swap went through: a new member
+                            state[u] = 1;
+                            seen[u] = cur[u];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (state[u]) continue;
+                        if (seen[u] == cur[u]) state[u] = 2;
+                        else { hh[u] = (hh[u] + 1) & mask; busy = true; }
+                    }
+                    if (!busy) break;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (!state[u]) overflow = 1;  // more distinct words in the bin than the LDS set takes: the caller falls back
+                    if (state[u] != 1) continue;
+                    const uint64_t key = cur[u] >> D.key_shift;
+                    if (dk) {
+                        if (key < dk) (void)__hip_atomic_fetch_add(gcnt + (uint32_t)key, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else overflow = 1;  // cannot happen: the key domain was sized from the dictionary
+                    } else if (gcap) {
+                        uint32_t gh = lds_hash(key, gcap);
+                        bool placed = false;
+                        for (uint32_t probe = 0; probe < gcap && !placed; probe++) {
+                            lds_u64* kp = lds_word(gkeys, gh);
+                            unsigned long long c = lds_peek(kp);
+                            if (c == kEmptyKey) {
+                                unsigned long long expected = kEmptyKey;
+                                if (__hip_atomic_compare_exchange_strong(kp, &expected, (unsigned long long)key, __ATOMIC_RELAXED,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                                    c = key;
+                                else
+                                    c = expected;
+                            }
+                            if (c == key) {
+                                (void)__hip_atomic_fetch_add(gcnt + gh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                placed = true;
+                            }
+                            gh = gh + 1 == gcap ? 0 : gh + 1;
+                        }
+                        if (!placed) overflow = 1;  // cannot happen: gcap is the capacity of the group table itself
+                    } else {
+                        long long g = global_find(G, key);
+                        if (g < 0) overflow = 1;
+                        else atomicAdd(&D.counts[g], 1ull);
+                    }
                 }
             }
         }
+        bin += gridDim.x;
+        lo = nlo;
+        hi = nhi;
+#pragma unroll
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
     __syncthreads();
-    for (uint32_t i = tid; i < gcap; i += BLOCK) {
+    const uint32_t ncount = dk ? dk : gcap;
+    for (uint32_t i = tid; i < ncount; i += BLOCK) {
         const uint32_t c = gcnt[i];
         if (!c) continue;
-        long long g = global_find(G, lds_peek(lds_word(gkeys, i)));
+        long long g = global_find(G, dk ? (uint64_t)i : (uint64_t)lds_peek(lds_word(gkeys, i)));
         if (g < 0) overflow = 1;
         else atomicAdd(&D.counts[g], (unsigned long long)c);
     }
@@ -638,6 +716,7 @@ __global__ void distinct_words_global_kernel(const GlobalTable G, const uint64_t
                                              uint32_t* err_flags) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t w = words[i];
+        if (w == kEmptyKey) continue;  // "no word"
         uint64_t h = mix64(w) & mask;
         int state = 0;
         for (uint64_t probe = 0; probe <= mask && !state; probe++) {
@@ -659,9 +738,13 @@ __global__ void distinct_words_global_kernel(const GlobalTable G, const uint64_t
     }
 }
 
-__global__ void distinct_add_counts_kernel(const Program P, const GlobalTable G, const unsigned long long* counts, uint32_t glob_off) {
+// `veto` (or null): two flags of the optimistic path (an LDS set / a bin of fixed capacity overflowed) — when either is
+// set the counts are worthless, nothing is added and the host, which reads the flags with the results, takes the exact path
+__global__ void distinct_add_counts_kernel(const Program P, const GlobalTable G, const unsigned long long* counts, uint32_t glob_off,
+                                           const uint32_t* veto) {
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= G.capacity) return;
+    if (veto && (veto[0] | veto[1])) return;
     if (counts[s]) G.acc[s * P.glob_words + glob_off] += counts[s];
 }
 
@@ -1073,7 +1156,8 @@ namespace n1k {
 #define T64 COLK_TAGGED64
 #define D32 COLK_DICT32
 #define ST(op, col, ci) SpecTerm{op, col, ci}
-#define SA(kind, has, col) SpecAgg{kind, has, col}
+#define SA(kind, has, col) SpecAgg{kind, has, col, 0}
+#define SAD(col) SpecAgg{AGG_COUNT, 1, col, 1}  // COUNT(DISTINCT col)
 #define NOTERM ST(0, 0, 0)
 #define NOAGG SA(0, 0, 0)
 // SELECT k, SUM(x) WHERE x <cmp> int GROUP BY k          (BASELINE config 2)
@@ -1095,12 +1179,17 @@ N1K_DEFINE_SPEC(Spec_gt_nokey_count, 1, T64, 0, 0, 1, ST(TERM_NUM_GT, 0, 1), NOT
 N1K_DEFINE_SPEC(Spec_ik_count, 1, T64, 0, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_COUNT, 0, 0), NOAGG, NOAGG, NOAGG, NOAGG);
 N1K_DEFINE_SPEC(Spec_ik_sum, 2, T64, T64, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SA(AGG_SUM, 1, 1), NOAGG, NOAGG, NOAGG, NOAGG);
 N1K_DEFINE_SPEC(Spec_dik_sum, 3, D32, T64, T64, 0, NOTERM, NOTERM, 2, 0, 1, 1, SA(AGG_SUM, 1, 2), NOAGG, NOAGG, NOAGG, NOAGG);
+// SELECT k, COUNT(DISTINCT u), AVG(x) GROUP BY k        (BASELINE config 3; aggregates sorted by text: avg, count)
+N1K_DEFINE_SPEC(Spec_cd_avg, 3, D32, T64, T64, 0, NOTERM, NOTERM, 1, 0, 0, 2, SA(AGG_AVG, 1, 1), SAD(2), NOAGG, NOAGG, NOAGG);
+// SELECT k, COUNT(DISTINCT u) GROUP BY k ; ... , COUNT(u)
+N1K_DEFINE_SPEC(Spec_cd, 2, D32, T64, 0, 0, NOTERM, NOTERM, 1, 0, 0, 1, SAD(1), NOAGG, NOAGG, NOAGG, NOAGG);
 // SELECT k1, k2, SUM(x) GROUP BY k1, k2 (two dictionary keys)
 N1K_DEFINE_SPEC(Spec_2k_sum, 3, D32, D32, T64, 0, NOTERM, NOTERM, 2, 0, 1, 1, SA(AGG_SUM, 1, 2), NOAGG, NOAGG, NOAGG, NOAGG);
 #undef T64
 #undef D32
 #undef ST
 #undef SA
+#undef SAD
 #undef NOTERM
 #undef NOAGG
 
@@ -1118,13 +1207,13 @@ static SpecSig make_sig() {
 
 template <class Spec>
 static hipError_t launch_spec(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
-                              uint32_t grid, uint32_t block, bool wide, hipStream_t st) {
-    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8;
+                              uint32_t grid, uint32_t block, bool wide, const WordLogArgs& L, hipStream_t st) {
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * spec_ndistinct<Spec>() * 8;
 #define N1K_LAUNCH(R, B, W)                                                                                       \
     do {                                                                                                          \
         auto k = scan_spec_kernel<Spec, R, B, W>;                                                                 \
         if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(B), shmem, st, P, F, G, ngroups);                                  \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(B), shmem, st, P, F, G, ngroups, L);                               \
     } while (0)
     if (block == 512) { if (wide) N1K_LAUNCH(2, 512, true); else N1K_LAUNCH(4, 512, false); }
     else { if (wide) N1K_LAUNCH(2, 1024, true); else N1K_LAUNCH(4, 1024, false); }
@@ -1137,7 +1226,7 @@ const std::vector<SpecEntry>& spec_registry() {
 #define N1K_REG(S) SpecEntry{#S, make_sig<S>(), &launch_spec<S>}
         N1K_REG(Spec_gt_sum), N1K_REG(Spec_lt_sum), N1K_REG(Spec_gtf_sum), N1K_REG(Spec_gt_all), N1K_REG(Spec_gt_count),
         N1K_REG(Spec_sum), N1K_REG(Spec_avg), N1K_REG(Spec_count), N1K_REG(Spec_gt_nokey_count), N1K_REG(Spec_2k_sum),
-        N1K_REG(Spec_ik_count), N1K_REG(Spec_ik_sum), N1K_REG(Spec_dik_sum),
+        N1K_REG(Spec_ik_count), N1K_REG(Spec_ik_sum), N1K_REG(Spec_dik_sum), N1K_REG(Spec_cd_avg), N1K_REG(Spec_cd),
 #undef N1K_REG
     };
     return reg;
@@ -2349,21 +2438,78 @@ hipError_t launch_topk_compact(const uint32_t* cand, uint64_t ncand, uint32_t nk
 }
 
 hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st, bool have_hist) {
+    if (A.bin_cap) {  // bins of fixed capacity: cursors from zero, no histogram, no offsets
+        (void)hipMemsetAsync(A.cursor, 0, (size_t)A.nseg * 256 * (A.cursor_stride ? A.cursor_stride : 1u) * sizeof(unsigned long long), st);
+        hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
+        return hipGetLastError();
+    }
     if (!have_hist) {  // (the producer of the words may have counted the digits already)
         (void)hipMemsetAsync(A.hist, 0, (size_t)A.nseg * 256 * sizeof(unsigned long long), st);
         hipLaunchKernelGGL(radix_hist_kernel, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
     }
     hipLaunchKernelGGL(radix_offsets_kernel, dim3(A.nseg), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
+    if (A.nextra) hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
+    else hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(slices, A.nseg), dim3(kRadixBlock), 0, st, A);
     return hipGetLastError();
 }
 
-hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, hipStream_t st) {
-    size_t shmem = (size_t)D.set_slots * 8 + (size_t)D.lds_counters * 12;
-    // 1024 threads x 2 words per step: measured best of {256, 512, 1024} x {2, 4, 8} at 20 M - 100 M words
-    auto k = distinct_dedupe_kernel<1024, 2>;
-    if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(1024), shmem, st, P, G, D);
+// hash regions -> one contiguous word log (n1k_finish's exact path when a region overflowed, or for the forced
+// partition depths of the tests): region b's words go to dst[off[b] ..]
+__global__ __launch_bounds__(256) void compact_regions_kernel(const uint64_t* region, uint64_t cap, const unsigned long long* count,
+                                                              const uint64_t* off, uint64_t* dst) {
+    const uint32_t b = blockIdx.y;
+    const uint64_t n = count[b * kCursorStride] < cap ? count[b * kCursorStride] : cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        dst[off[b] + i] = region[(size_t)b * cap + i];
+}
+
+hipError_t launch_compact_regions(const uint64_t* region, uint64_t cap, const unsigned long long* count, const uint64_t* off,
+                                  uint64_t* dst, hipStream_t st) {
+    hipLaunchKernelGGL(compact_regions_kernel, dim3(32, 256), dim3(256), 0, st, region, cap, count, off, dst);
+    return hipGetLastError();
+}
+
+// hash regions grow with the rows pushed: the words of region b move to the same region of a wider layout
+__global__ __launch_bounds__(256) void regrow_regions_kernel(const uint64_t* src, uint64_t src_cap, uint64_t* dst, uint64_t dst_cap,
+                                                             const unsigned long long* count) {
+    const uint32_t b = blockIdx.y;
+    const uint64_t n = count[b * kCursorStride] < src_cap ? count[b * kCursorStride] : src_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        dst[(size_t)b * dst_cap + i] = src[(size_t)b * src_cap + i];
+}
+
+// a region that overflowed counted words it never took (they went to the plain log): its cursor goes back to the
+// capacity it had, so that the wider region continues right behind the words that are really there
+__global__ void clamp_cursors_kernel(unsigned long long* count, uint64_t cap) {
+    const uint32_t b = threadIdx.x;
+    if (count[b * kCursorStride] > cap) count[b * kCursorStride] = cap;
+}
+
+hipError_t launch_regrow_regions(const uint64_t* src, uint64_t src_cap, uint64_t* dst, uint64_t dst_cap, unsigned long long* count,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(regrow_regions_kernel, dim3(32, 256), dim3(256), 0, st, src, src_cap, dst, dst_cap, count);
+    hipLaunchKernelGGL(clamp_cursors_kernel, dim3(1), dim3(256), 0, st, count, src_cap);
+    return hipGetLastError();
+}
+
+size_t distinct_dedupe_lds(const DedupeArgs& D) {
+    return (size_t)D.set_slots * 8 + (D.direct_keys ? (size_t)D.direct_keys * 4 : (size_t)D.lds_counters * 12);
+}
+
+hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, uint32_t block, hipStream_t st) {
+    const size_t shmem = distinct_dedupe_lds(D);
+    const bool together = !(block & 1u);
+    block &= ~1u;
+#define N1K_DEDUPE(B, U)                                                                                              \
+    do {                                                                                                              \
+        auto k = together ? distinct_dedupe_kernel<B, U, true> : distinct_dedupe_kernel<B, U, false>;                 \
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(B), shmem, st, P, G, D);                                               \
+    } while (0)
+    if (block == 256) N1K_DEDUPE(256, 8);
+    else if (block == 1024) N1K_DEDUPE(1024, 2);
+    else N1K_DEDUPE(512, 4);
+#undef N1K_DEDUPE
     return hipGetLastError();
 }
 
@@ -2375,9 +2521,9 @@ hipError_t launch_distinct_words_global(const GlobalTable& G, const uint64_t* wo
 }
 
 hipError_t launch_distinct_add_counts(const Program& P, const GlobalTable& G, const unsigned long long* counts, uint32_t glob_off,
-                                      hipStream_t st) {
+                                      hipStream_t st, const uint32_t* veto) {
     uint32_t blocks = (uint32_t)((G.capacity + 255) / 256);
-    hipLaunchKernelGGL(distinct_add_counts_kernel, dim3(blocks), dim3(256), 0, st, P, G, counts, glob_off);
+    hipLaunchKernelGGL(distinct_add_counts_kernel, dim3(blocks), dim3(256), 0, st, P, G, counts, glob_off, veto);
     return hipGetLastError();
 }
 

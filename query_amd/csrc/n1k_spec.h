@@ -33,6 +33,20 @@ namespace n1k {
 #define SPEC_FLAG(ptr, bit) lds_or_u64((ptr), (bit))
 #endif
 
+// DISTINCT aggregates of a Spec (COUNT(DISTINCT col) over one-word members, see WordLogArgs)
+template <class Spec>
+constexpr int spec_ndistinct() {
+    int n = 0;
+    for (int a = 0; a < Spec::naggs; a++) n += Spec::aggs[a].distinct ? 1 : 0;
+    return n;
+}
+template <class Spec>
+constexpr int spec_distinct_index(int a) {
+    int n = 0;
+    for (int i = 0; i < a; i++) n += Spec::aggs[i].distinct ? 1 : 0;
+    return n;
+}
+
 // a Spec whose keys are not all dictionary columns uses the open-addressed LDS table (decided at compile time, so
 // the perfect-hash kernels carry none of the hashing code)
 template <class Spec>
@@ -81,6 +95,15 @@ N1K_DEV bool spec_term_true(int t, const FastArgs& F, uint32_t tg, uint64_t p) {
 
 // CumulateInitial of aggregate `a` (compile-time kind) into the LDS slot; false -> take the global path
 template <class Spec>
+N1K_DEV void spec_flag(lds_u64* w, unsigned long long bit) {
+    // Shapes with COUNT(DISTINCT) run at the CU's LDS-atomic rate (about one lane per clock: four atomics per row were
+    // 0.65 ms per 100 M rows), so there the flag is read first and set once; the other shapes are bound by HBM and
+    // prefer the fire-and-forget atomic, which never makes the row loop wait for an LDS read.
+    if (spec_ndistinct<Spec>() > 0) lds_set_flag(w, bit);
+    else SPEC_FLAG(w, bit);
+}
+
+template <class Spec>
 N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32_t slot, uint32_t tag, uint64_t p) {
     const uint32_t kind = Spec::aggs[a].kind;
     lds_u64* w = lds_word(lds, P.aggs[a].lds_off * S + slot);
@@ -97,11 +120,11 @@ N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32
             int64_t x = (int64_t)p;
             if (x >= (1ll << 40) || x <= -(1ll << 40)) return false;
             lds_add_u64(w, (unsigned long long)x);
-            SPEC_FLAG(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
+            spec_flag<Spec>(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
         } else if (tag == T_FLOAT) {
             lds_add_f64(w + S, as_f64(p));
-            SPEC_FLAG(w + 2 * S, (unsigned long long)SF_FLOAT);
+            spec_flag<Spec>(w + 2 * S, (unsigned long long)SF_FLOAT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
         }
         return true;
@@ -131,10 +154,27 @@ N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32
 }
 
 // one row, everything about the plan shape folded at compile time
+// a member that does not fit one word (non-integral float, wide value): the (key, value, class) pair log and the
+// per-class operand counts of the group, as the interpreter kernel keeps them — rare, so plain global atomics
+N1K_DEV void spec_pair_log(const Program& P, const GlobalTable& G, const WordLogArgs& L, int d, const AggSpec& ag, uint64_t gkey,
+                           uint32_t cls, uint64_t val, uint32_t* err_flags, unsigned long long* ngroups) {
+    const unsigned long long pos = atomicAdd(&L.log_cursor[L.log_index[d]], 1ull);
+    if (pos < L.log_capacity) {
+        L.log_key[d][pos] = gkey;
+        L.log_val[d][pos] = val;
+        L.log_cls[d][pos] = (uint8_t)cls;
+    } else
+        atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+    const long long g = global_find_or_insert(G, gkey, err_flags, ngroups);
+    if (g >= 0) atomicAdd((unsigned long long*)&G.acc[(size_t)g * P.glob_words + ag.glob_off + 1 + cls], 1ull);
+}
+
 template <class Spec>
 N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                       uint64_t* lds, uint32_t S, uint32_t* lds_fill, const uint32_t (&tg)[kFastCols],
-                      const uint64_t (&pv)[kFastCols], uint32_t& selected, uint32_t& unpackable) {
+                      const uint64_t (&pv)[kFastCols], uint32_t& selected, uint32_t& unpackable, const WordLogArgs& L,
+                      uint64_t* dcache, uint64_t (&words)[kSpecDistinct], uint32_t (&bins)[kSpecDistinct]) {
+    constexpr int kND = spec_ndistinct<Spec>();
     bool pass = true;
 #pragma unroll
     for (int t = 0; t < Spec::nterms; t++) pass = pass && spec_term_true<Spec>(t, F, tg[Spec::terms[t].col], pv[Spec::terms[t].col]);
@@ -170,6 +210,7 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
                 return;
             }
             slot += f * F.keys[k].stride;
+            if (kND) key |= (uint64_t)f << F.keys[k].shift;  // the packed key, for the members of the DISTINCT sets
         }
         *(volatile lds_u64*)lds_word(lds, slot) = 1ull;  // "touched": every writer stores the same value, nobody reads it here
     }
@@ -179,6 +220,26 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
         const uint32_t c = Spec::aggs[a].has_operand ? Spec::aggs[a].col : 0u;
         const uint32_t t = Spec::aggs[a].has_operand ? tg[c] : (uint32_t)T_NULL;
         const uint64_t p = Spec::aggs[a].has_operand ? pv[c] : 0ull;
+        if (Spec::aggs[a].distinct) {
+            // setAdd (algebra/agg_util.go:30-47): the (group, value) member leaves as one word; n1k_finish builds the sets
+            const int d = spec_distinct_index<Spec>(a);
+            uint32_t cls;
+            uint64_t val, word;
+            if (!distinct_classify(AGG_COUNT, t, p, cls, val)) continue;
+            if (!member_word_bits(L.nw_key_bits, L.nw_val_bits, key, cls, val, word)) {
+                spec_pair_log(P, G, L, d, P.aggs[a], key, cls, val, F.err_flags, ngroups);
+                continue;
+            }
+            const uint64_t hw = mix64(word);  // top byte: the hash region; low bits: the slot of the workgroup's cache
+            if (L.dcache_slots) {  // skip a word this workgroup logged already (direct-mapped; a race costs a redundant word)
+                lds_u64* c = lds_word(dcache, (uint32_t)d * L.dcache_slots + ((uint32_t)hw & (L.dcache_slots - 1u)));
+                if (lds_peek(c) == word) continue;
+                *(volatile lds_u64*)c = word;
+            }
+            words[d] = word;
+            bins[d] = (uint32_t)(hw >> 56);
+            continue;
+        }
         if (kHashed && grow >= 0) {  // the LDS table is full: this group lives in the global table only
             acc_global(P, P.aggs[a], &G.acc[(size_t)grow * P.glob_words], t, p);
         } else if (!spec_acc<Spec>(a, P, lds, S, slot, t, p)) {  // rare: an integer too large for the narrow LDS sum
@@ -188,18 +249,178 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
     }
 }
 
+// ---- member words -> hash regions: write combining in LDS ------------------------------------------------------
+//
+// Every workgroup keeps, per DISTINCT aggregate and hash region, kWcSlots staging slots in LDS and private CHUNKS of
+// kWcChunk consecutive words inside the region: the one it is filling, the next one, and a third one reserved ahead.
+// A chunk is one aligned 128-byte line.  Per tile: each thread appends its words to their region's slots (one LDS
+// atomic each); after a barrier a 16-lane group per region copies the slots to the chunk — consecutive lanes,
+// consecutive words of a line — and the region's owner (thread b for region b) moves on to the next chunk when the
+// current one is full, reserving the one after the next at that moment.  The answer of that reservation is only read
+// a tile later, so no global round trip sits between the barriers of a tile (a reservation per tile and region cost
+// 0.5 ms per 100 M rows in exposed latency).  What a workgroup reserved but did not fill it pads with kEmptyKey,
+// which every reader of the regions skips.  (Region capacities and all reservations are multiples of kWcChunk.)
+constexpr uint32_t kWcSlots = 16, kWcChunk = 16;
+
+// LDS of one DISTINCT aggregate.  The chunk state and the tile counters exist twice: in tile t everybody reads copy
+// t & 1 and region b's owner writes copy (t + 1) & 1, so that the owners' updates need no barrier of their own.
+struct WcLds {
+    uint64_t slot[256 * kWcSlots];
+    uint32_t cur[2][256], next[2][256];  // first word of the current / next chunk (position inside the region, < 2^32)
+    uint32_t used[2][256];               // words of the current chunk already written
+    uint32_t fill[2][256];               // words appended to the slots in this tile
+};
+constexpr uint32_t kWcNone = 0xFFFFFFFFu;  // "no chunk": the region is full
+
+// what the owner of a region carries in registers from tile to tile
+struct WcOwner {
+    unsigned long long pend;  // answer of the reservation issued a tile ago (when `pending`)
+    uint32_t third;           // the chunk after `next` (valid unless `pending`)
+    bool pending;
+};
+
+N1K_DEV void wc_over_append(const WordLogArgs& L, int d, uint32_t b, uint64_t word, uint32_t* err_flags) {
+    // the region is full (many copies of few words): the plain word log takes the word, n1k_finish the exact path
+    const uint32_t li = L.log_index[d];
+    const unsigned long long q = atomicAdd(&L.over_cursor[li], 1ull);
+    if (q < L.over_capacity) {
+        L.over_word[d][q] = word;
+        atomicAdd(&L.over_hist[li * 256u + b], 1ull);
+    } else
+        atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
+}
+
+// a reservation [base, base + kWcChunk) as a chunk: inside the region or not at all (both are multiples of kWcChunk)
+N1K_DEV uint32_t wc_chunk(const WordLogArgs& L, unsigned long long base) {
+    return base + kWcChunk <= L.region_cap ? (uint32_t)base : kWcNone;
+}
+
+template <int BLOCK>
+N1K_DEV void wc_init(const WordLogArgs& L, int d, WcLds& W, WcOwner& O) {
+    O.pend = 0;
+    O.third = kWcNone;
+    O.pending = false;
+    for (uint32_t b = threadIdx.x; b < 256; b += BLOCK) {
+        const unsigned long long r = atomicAdd(&L.region_cursor[d][b * kCursorStride], (unsigned long long)(3 * kWcChunk));
+        W.cur[0][b] = wc_chunk(L, r);
+        W.next[0][b] = wc_chunk(L, r + kWcChunk);
+        O.third = wc_chunk(L, r + 2 * kWcChunk);
+        W.used[0][b] = 0;
+        W.fill[0][b] = 0;
+        W.fill[1][b] = 0;
+    }
+}
+
+// All threads of the workgroup call it once per tile (two barriers).  `par` = tile & 1.
+template <int BLOCK, int NW>
+N1K_DEV void wc_tile(const WordLogArgs& L, int d, const uint64_t (&w)[NW], const uint32_t (&wb)[NW], WcLds& W, uint32_t par,
+                     WcOwner& O, uint32_t* err_flags) {
+    static_assert(BLOCK >= 256, "one owner thread per hash region");
+    constexpr int kPer = 256 * 16 / BLOCK;  // regions per 16-lane group
+    const uint32_t tid = threadIdx.x;
+    if (L.pad & 2u) return;  // (timing experiments only: words dropped)
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        if (w[j] == kEmptyKey) continue;
+        const uint32_t b = wb[j];
+        const uint32_t r = atomicAdd(&W.fill[par][b], 1u);
+        if (r < kWcSlots) {
+            W.slot[b * kWcSlots + r] = w[j];
+        } else {
+            // more words for one region in one tile than its slots take (a few per thousand tiles): a line of its own
+            const unsigned long long q = atomicAdd(&L.region_cursor[d][b * kCursorStride], (unsigned long long)kWcChunk);
+            if (q + kWcChunk <= L.region_cap) {
+                uint64_t* line = L.region[d] + (size_t)b * L.region_cap + q;
+                line[0] = w[j];
+                for (uint32_t i = 1; i < kWcChunk; i++) line[i] = kEmptyKey;
+            } else
+                wc_over_append(L, d, b, w[j], err_flags);
+        }
+    }
+    __syncthreads();
+    // owners: the state of the next tile.  A region whose chunk fills up in this tile moves on to the next one (which has
+    // been known for a tile at least), the third becomes the next, and a new third is reserved; its answer is read at the
+    // start of the next tile's owner step.  (A tile brings at most kWcSlots = kWcChunk words: one move per tile.)
+    if (tid < 256) {
+        const uint32_t b = tid, f = W.fill[par][b], n = f < kWcSlots ? f : kWcSlots, used = W.used[par][b];
+        if (O.pending) {
+            O.third = wc_chunk(L, O.pend);
+            O.pending = false;
+        }
+        if (used + n >= kWcChunk) {
+            W.cur[par ^ 1][b] = W.next[par][b];
+            W.next[par ^ 1][b] = O.third;
+            W.used[par ^ 1][b] = used + n - kWcChunk;
+            O.pend = atomicAdd(&L.region_cursor[d][b * kCursorStride], (unsigned long long)kWcChunk);
+            O.pending = true;
+        } else {
+            W.cur[par ^ 1][b] = W.cur[par][b];
+            W.next[par ^ 1][b] = W.next[par][b];
+            W.used[par ^ 1][b] = used + n;
+        }
+        W.fill[par ^ 1][b] = 0;
+    }
+    // copy: a 16-lane group per region, consecutive lanes write consecutive words of a line
+    const uint32_t g = tid >> 4, l = tid & 15u;
+#pragma unroll 2
+    for (int k = 0; k < kPer; k++) {
+        const uint32_t b = (uint32_t)k * (BLOCK / 16) + g;
+        const uint32_t f = W.fill[par][b];
+        const uint32_t n = f < kWcSlots ? f : kWcSlots;
+        if (l >= n) continue;
+        const uint32_t pos = W.used[par][b] + l;
+        const uint32_t base = pos < kWcChunk ? W.cur[par][b] : W.next[par][b];
+        const uint64_t word = W.slot[b * kWcSlots + l];
+        if (L.pad & 1u) continue;  // (timing experiments only: words not stored)
+        if (base != kWcNone) L.region[d][(size_t)b * L.region_cap + base + (pos & (kWcChunk - 1))] = word;
+        else wc_over_append(L, d, b, word, err_flags);
+    }
+    __syncthreads();
+}
+
+// end of the kernel: what the workgroup reserved and did not fill reads as "no word".  `par` = parity of the next tile.
+template <int BLOCK>
+N1K_DEV void wc_finish(const WordLogArgs& L, int d, WcLds& W, uint32_t par, WcOwner& O) {
+    const uint32_t b = threadIdx.x;
+    if (b >= 256) return;
+    const uint32_t cur = W.cur[par][b], nx = W.next[par][b], used = W.used[par][b];
+    const uint32_t third = O.pending ? wc_chunk(L, O.pend) : O.third;
+    uint64_t* region = L.region[d] + (size_t)b * L.region_cap;
+    if (cur != kWcNone)
+        for (uint32_t pos = used; pos < kWcChunk; pos++) region[cur + pos] = kEmptyKey;
+    if (nx != kWcNone)
+        for (uint32_t pos = 0; pos < kWcChunk; pos++) region[nx + pos] = kEmptyKey;
+    if (third != kWcNone)
+        for (uint32_t pos = 0; pos < kWcChunk; pos++) region[third + pos] = kEmptyKey;
+}
+
 template <class Spec, int R, int BLOCK, bool WIDE>
-N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups) {
+N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
+                            const WordLogArgs& L) {
     extern __shared__ uint64_t lds[];
     __shared__ uint32_t lds_fill;
     const uint32_t S = F.lds_slots;
     const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
+    // COUNT(DISTINCT): scratch of the word scatter (nothing when the shape has no DISTINCT aggregate)
+    constexpr int kND = spec_ndistinct<Spec>();
+    constexpr int kNW = R * (int)kRowsPerItem;  // member words a thread can produce per tile and aggregate
+    __shared__ WcLds w_lds[kND ? kND : 1];
+    WcOwner w_own[kND ? kND : 1];
+    uint32_t w_par = 0;
+    uint64_t* dcache = lds + (size_t)S * P.lds_words;  // "already logged" caches of the DISTINCT aggregates
+    if constexpr (kND > 0) {
+        for (uint32_t i = tid; i < L.dcache_slots * (uint32_t)kND; i += BLOCK) *(volatile lds_u64*)lds_word(dcache, i) = kEmptyKey;
+#pragma unroll
+        for (int d = 0; d < kND; d++) {
+            wc_init<BLOCK>(L, d, w_lds[d], w_own[d]);
+        }
+    }
     lds_table_init<BLOCK>(P, lds, S, tid);
     if (tid == 0) lds_fill = 0;
     __syncthreads();
 
     uint32_t unpackable = 0, selected = 0;
-    constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
     const uint32_t nitems = WIDE ? F.nrows / 2u : F.nrows;  // the engine passes an even row count to WIDE launches
     const uint32_t tile = BLOCK * R;
 
@@ -251,16 +472,32 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
                 }
             }
         }
+        uint64_t mw[kSpecDistinct][kNW];  // this thread's member words of the tile (kEmptyKey = none) and their hash regions
+        uint32_t mb[kSpecDistinct][kNW];
 #pragma unroll
         for (int j = 0; j < R; j++) {
-            if (valid[j]) {
 #pragma unroll
-                for (int h = 0; h < (int)kRowsPerItem; h++)
-                    spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable);
+            for (int h = 0; h < (int)kRowsPerItem; h++) {
+                uint64_t words[kSpecDistinct];
+                uint32_t bins[kSpecDistinct];
+#pragma unroll
+                for (int d = 0; d < (int)kSpecDistinct; d++) { words[d] = kEmptyKey; bins[d] = 0; }
+                if (valid[j]) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins);
+#pragma unroll
+                for (int d = 0; d < (int)kSpecDistinct; d++) { mw[d][j * (int)kRowsPerItem + h] = words[d]; mb[d][j * (int)kRowsPerItem + h] = bins[d]; }
             }
+        }
+        if constexpr (kND > 0) {
+#pragma unroll
+            for (int d = 0; d < kND; d++) wc_tile<BLOCK, kNW>(L, d, mw[d], mb[d], w_lds[d], w_par, w_own[d], F.err_flags);
+            w_par ^= 1u;
         }
     }
 
+    if constexpr (kND > 0) {
+#pragma unroll
+        for (int d = 0; d < kND; d++) wc_finish<BLOCK>(L, d, w_lds[d], w_par, w_own[d]);
+    }
     if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
     // rows that passed the Filter (≙ Filter #itemsOut): wave shuffle, then ONE LDS counter per workgroup — thousands of
     // same-address global atomics at the end of the kernel cost ~10 % of its time
@@ -290,8 +527,8 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
 // ahead-of-time instantiations use this kernel; kernels compiled at run time wrap scan_spec_body themselves
 template <class Spec, int R, int BLOCK, bool WIDE>
 __global__ __launch_bounds__(BLOCK) void scan_spec_kernel(const Program P, const FastArgs F, const GlobalTable G,
-                                                         unsigned long long* ngroups) {
-    scan_spec_body<Spec, R, BLOCK, WIDE>(P, F, G, ngroups);
+                                                         unsigned long long* ngroups, const WordLogArgs L) {
+    scan_spec_body<Spec, R, BLOCK, WIDE>(P, F, G, ngroups, L);
 }
 
 }  // namespace n1k

@@ -117,7 +117,7 @@ N1K_DEV void lds_table_init(const Program& P, uint64_t* lds, uint32_t S, uint32_
         const AggSpec& ag = P.aggs[a];
         uint64_t* w = lds + (size_t)ag.lds_off * S;
         if (ag.distinct) {
-            for (uint32_t i = 0; i < kLdsWordsDistinct; i++)
+            for (uint32_t i = 0; i < ag.lds_n; i++)
                 for (uint32_t s = tid; s < S; s += BLOCK) w[(size_t)i * S + s] = 0;
             continue;
         }
@@ -261,7 +261,7 @@ N1K_DEV void merge_slot(const Program& P, const uint64_t* lds, uint32_t S, uint3
         const uint64_t* l = lds + (size_t)ag.lds_off * S + slot;  // word i at l[i * S]
         unsigned long long* w = (unsigned long long*)(g + ag.glob_off);
         if (ag.distinct) {
-            for (uint32_t i = 0; i < kLdsWordsDistinct; i++)
+            for (uint32_t i = 0; i < ag.lds_n; i++)
                 if (l[(size_t)i * S]) atomicAdd(&w[1 + i], (unsigned long long)l[(size_t)i * S]);
             continue;
         }
@@ -297,6 +297,41 @@ N1K_DEV void merge_slot(const Program& P, const uint64_t* lds, uint32_t S, uint3
         }
     }
 }
+
+// ------------------------------------------------------------------ DISTINCT members
+//
+// value.Set (value/set.go:22-110) keeps one hash map per type: ints and integral floats share the int map, other
+// floats their own, strings / arrays / objects are keyed by text (here: dictionary code), booleans by value.
+// CountDistinct adds every operand of type > NULL (algebra/agg_count_distinct.go:84-95), CountnDistinct every
+// NUMBER.  Returns false when the operand does not enter the set.
+N1K_DEV bool distinct_classify(uint32_t kind, uint32_t tag, uint64_t p, uint32_t& cls, uint64_t& val) {
+    if (tag <= T_NULL) return false;
+    if (tag == T_INT) { cls = DC_INT; val = p; return true; }
+    if (tag == T_FLOAT) {
+        double d = as_f64(p);
+        if (is_int_f64(d)) { cls = DC_INT; val = (uint64_t)go_f2i(d); }
+        else { cls = DC_FLOAT; val = p; }
+        return true;
+    }
+    if (kind != AGG_COUNT) return false;  // COUNTN / SUM / AVG (DISTINCT): NUMBER operands only
+    cls = DC_OTHER;
+    val = ((uint64_t)tag << 40) | (p & 0xFFFFFFFFFFull);
+    return true;
+}
+
+// One-word form of a (group key, class, value) member of a COUNT(DISTINCT) set, when both parts are small enough:
+//   [key : key_bits][class : 3][value : val_bits]      (key_bits + 3 + val_bits == 64)
+// Non-integral floats never are; DC_OTHER values (tag << 40 | code) are re-packed as code << 4 | tag.
+N1K_DEV bool member_word_bits(uint32_t key_bits, uint32_t val_bits, uint64_t key, uint32_t cls, uint64_t val, uint64_t& word) {
+    if (cls == DC_FLOAT) return false;
+    uint64_t v = cls == DC_INT ? zigzag((int64_t)val) : (((val & 0xFFFFFFFFFFull) << 4) | (val >> 40));
+    if ((key >> key_bits) != 0ull || (v >> val_bits) != 0ull) return false;
+    word = (key << (val_bits + 3)) | ((uint64_t)cls << val_bits) | v;
+    return true;
+}
+
+// radix digit of a member word / record key: 8 bits of its hash (equal words always share every digit)
+N1K_DEV uint32_t radix_bin(uint64_t w, uint32_t shift) { return (uint32_t)(mix64(w) >> shift) & 255u; }
 
 // perfect-hash slot -> packed group key (inverse of slot = sum(field_k * stride_k))
 N1K_DEV uint64_t fast_slot_key(const FastArgs& F, uint32_t slot) {

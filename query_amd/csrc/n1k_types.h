@@ -33,7 +33,8 @@ constexpr int kMaxLdsWords = 40;   // 1 key word + accumulators
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 // device counters of a handle: [0] rows selected [1] groups [2] out count [3] filter total [4] rehash scratch
 // [5] DISTINCT region words [8..11] pair-log cursors [12] error flags [13] wide key values [16..19] word-log cursors
-// [20] DISTINCT LDS-set overflow flag [21] records of the partitioned path [22] its singleton partial groups
+// [20] COUNT(DISTINCT) optimistic path: set / bin overflow flags [21] records of the partitioned path [22] its singleton
+// partial groups [24] COUNT(DISTINCT) exact path: LDS-set overflow flag
 constexpr uint32_t kCounters = 32;
 
 // value tags == n1k_tag (include/n1k.h)
@@ -109,6 +110,8 @@ struct AggSpec {
     uint32_t lds_off;   // first accumulator word inside an LDS slot
     uint32_t glob_off;  // first accumulator word inside a global-table row
     uint32_t log_index; // DISTINCT: which pair log this aggregate appends to
+    uint32_t lds_n;     // accumulator words inside an LDS slot (0: a DISTINCT aggregate whose kernel counts nothing in LDS)
+    uint32_t pad;
     Operand src;
 };
 
@@ -200,6 +203,34 @@ struct ScanArgs {
     unsigned long long* word_hist;  // kMaxDistinct x 256 counters: first radix digit of the logged words (n1k_finish's first pass)
 };
 
+// COUNT(DISTINCT) inside the plan-specialised scan (n1k_spec.h): the member words of aggregate d are scattered by the
+// first radix digit of mix64(word) straight into 256 HASH REGIONS of fixed capacity (the first partition pass of
+// n1k_finish, fused into the scan: no log round trip, no histogram pass).  mix64 spreads distinct words evenly, so a
+// region holds words / 256 plus slack; a word that finds its region full goes to the plain word log instead (and
+// n1k_finish then takes the exact path over everything).
+constexpr uint32_t kSpecDistinct = 2;  // DISTINCT aggregates a specialised kernel handles
+// Write cursors that every workgroup bumps once per tile sit one per 128-byte line: 256 neighbouring counters share 16
+// lines (a handful of L2 channels), and the atomics on them then bound the whole scatter.
+constexpr uint32_t kCursorStride = 16;
+struct WordLogArgs {
+    uint64_t* region[kSpecDistinct];              // 256 regions x region_cap words
+    unsigned long long* region_cursor[kSpecDistinct];  // 256 counters each, kCursorStride apart (words offered to a region, may exceed the capacity)
+    uint64_t region_cap;
+    uint64_t* over_word[kSpecDistinct];           // the plain word log (ScanArgs::log_word) and its cursors / histogram
+    unsigned long long* over_cursor;              // kMaxDistinct counters, indexed by log_index
+    unsigned long long* over_hist;                // kMaxDistinct x 256
+    uint64_t over_capacity;
+    // members that do not fit one word (non-integral floats, wide values): the pair log of ScanArgs
+    uint64_t* log_key[kSpecDistinct];
+    uint64_t* log_val[kSpecDistinct];
+    uint8_t* log_cls[kSpecDistinct];
+    unsigned long long* log_cursor;               // kMaxDistinct counters, indexed by log_index
+    uint64_t log_capacity;
+    uint32_t log_index[kSpecDistinct];
+    uint32_t nw_key_bits, nw_val_bits;
+    uint32_t dcache_slots, pad;                   // per aggregate: "already logged" cache in LDS (power of two), 0 = none
+};
+
 // radix partition of a word log by bits of mix64(word) (finish step of COUNT(DISTINCT), see n1k_kernels.hip)
 struct RadixArgs {
     const uint64_t* src;
@@ -210,6 +241,14 @@ struct RadixArgs {
     unsigned long long* hist;   // nseg * 256 counters
     unsigned long long* cursor; // nseg * 256 write cursors (absolute positions in dst)
     uint64_t* out_start;        // nseg * 256 + 1 entries: starts of the finer segments
+    // Segments of fixed capacity instead (hash regions): segment s is src[s * seg_stride .. + min(seg_count[s], seg_stride))
+    const unsigned long long* seg_count;  // (counter of segment s at seg_count[s * kCursorStride])
+    uint64_t seg_stride;
+    uint32_t cursor_stride, pad1;         // `cursor` entry i lives at cursor[i * cursor_stride] (0 = 1)
+    // Output bins of fixed capacity (no histogram pass): bin (s, b) is dst[(s * 256 + b) * bin_cap ..], `cursor` counts
+    // from zero, words beyond the capacity are dropped and *overflow is set (the caller then takes the exact path)
+    uint64_t bin_cap;
+    uint32_t* overflow;
     // records: arrays that travel with the word (same permutation), see RecArrays
     uint32_t nextra, pad;
     const uint64_t* src_pay[2];
@@ -253,7 +292,13 @@ struct BinAggArgs {
 
 struct DedupeArgs {
     const uint64_t* words;
-    const uint64_t* bin_start;  // nbins + 1
+    const uint64_t* bin_start;  // nbins + 1 (null with bin_count)
+    // bins of fixed capacity: bin i is words[i * bin_stride .. + min(bin_count[i], bin_stride))
+    const unsigned long long* bin_count;
+    uint64_t bin_stride;
+    uint32_t count_stride, pad1;  // bin_count entry i lives at bin_count[i * count_stride] (0 = 1)
+    uint32_t direct_keys;       // > 0: packed keys are < direct_keys, the LDS member counters are indexed by the key itself
+    uint32_t pad0;
     uint32_t nbins;
     uint32_t set_slots;         // LDS set size (power of two)
     uint32_t key_shift;         // word >> key_shift = packed group key
@@ -346,6 +391,7 @@ struct SpecAgg {
     uint32_t kind;  // AGG_*
     uint32_t has_operand;
     uint32_t col;
+    uint32_t distinct;  // COUNT(DISTINCT col): one-word members scattered into the hash regions (WordLogArgs)
 };
 struct SpecSig {
     int ncols, nterms, nkeys, naggs;

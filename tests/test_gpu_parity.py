@@ -511,6 +511,62 @@ def test_count_distinct_paths(n, nvals, ngroups, opts, path):
     assert stats["distinct_path"] == path
 
 
+@pytest.mark.parametrize("n,nvals,ngroups,opts,path", [
+    (3_000, 50, 4, {}, 3),                                   # a few words per hash region: LDS sets straight over the regions
+    (120_000, 40_000, 7, {}, 3),
+    (900_000, 700_000, 50, {}, 3),                           # second partition pass into bins of fixed capacity
+    (900_000, 700_000, 50, {"distinct_levels": 2, "distinct_set_slots": 1024}, 3),
+    (400_000, 16, 5, {}, 3),                                 # few members, each logged many times (workgroup caches)
+    (400_000, 16, 5, {"distinct_region_cap": 64}, 3),        # regions overflow into the plain log: gathered, exact path
+    (300_000, 200_000, 9, {"distinct_region_cap": 300}, 3),
+    (300_000, 200_000, 9, {"distinct_set_slots": 64, "distinct_levels": 1}, 7),  # LDS sets overflow: global one-word set
+    (3_000, 50, 4, {"distinct_levels": 0}, 3),              # forced depth 0: gathered, one set
+], ids=["tiny", "regions", "two-pass", "two-pass-forced", "duplicates", "spill-dups", "spill", "set-overflow", "gathered"])
+@pytest.mark.parametrize("batches", [1, 3])
+def test_count_distinct_in_the_specialised_scan(n, nvals, ngroups, opts, path, batches):
+    """COUNT(DISTINCT) logged by the plan-specialised scan (built at run time for this shape: integer key, open-addressed
+    LDS table): member words go straight into the 256 hash regions (first partition pass fused into the scan), the
+    rest of value.Set's semantics (value/set.go:22-110) as in the interpreter path; two-word members take the pair log."""
+    t = _distinct_table(n, nvals, ngroups)
+    aggs = sorted(["count(distinct %s)" % D("v"), "count(%s)" % D("v")])
+    ora = n1o.run(t, None, [D("g")], aggs, threads=2)
+    gpu, stats = pu.run_gpu(t, None, [D("g")], aggs, batches=batches, jit=2, **opts)
+    assert stats["spec_kernel"] == 2
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert stats["distinct_path"] == path
+
+
+def test_count_distinct_regions_grow_and_mix_with_the_interpreter():
+    """The hash regions grow with the rows pushed (their words move to the wider layout), and a query whose batches ran
+    through both kernels (regions + plain word log) is finished through the exact path."""
+    t = n1o.synth_table(600_000, k_cat=50, total_rows=3_000_000)
+    cond, keys, aggs = CONFIG3
+    ora = n1o.run(t, cond, keys, aggs, threads=2)
+    pj = query_amd.plan.filter_group_plan(cond, keys, aggs)
+    by = {c.name: c for c in t.columns}
+    cuts = [0, 1_000, 5_000, 40_000, 300_000, 600_000]  # growing batches: the regions are re-laid out several times
+    for mixed in (False, True):
+        op = query_amd.GpuFilterGroup(pj)
+        for i in range(len(cuts) - 1):
+            part = t.slice(cuts[i], cuts[i + 1])
+            if mixed:
+                op.set_option("spec", i % 2)  # every other batch through the interpreter kernel
+            op.process_items([{c.name: c for c in part.columns}[p] for p in op.column_paths], t.dictionary)
+        rows = op.after_items()
+        assert op.stats()["distinct_path"] & 2
+        op.done()
+        pu.assert_same_groups(rows, ora, aggs=aggs)
+
+
+def test_config3_shape_runs_the_prebuilt_specialised_kernel():
+    t = n1o.synth_table(300_000, k_cat=1000, total_rows=3_000_000)
+    cond, keys, aggs = CONFIG3
+    ora = n1o.run(t, cond, keys, aggs, threads=2)
+    gpu, stats = pu.run_gpu(t, cond, keys, aggs, device_resident=True)
+    assert stats["spec_kernel"] == 1 and stats["distinct_path"] == 2
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+
+
 def test_count_distinct_words_refinish_and_reopen():
     """The word log survives n1k_finish (more batches may follow) and is dropped by reopen."""
     t = _distinct_table(150_000, 60_000, 5)
