@@ -136,7 +136,7 @@ struct n1k_handle {
     bool layout_fixed = false;
     uint32_t col_kinds[kMaxCols]{};
     std::vector<std::string> agg_names;
-    bool has_distinct = false;
+    bool has_distinct = false, has_minmax = false;
     uint32_t n_distinct = 0;
     // arithmetic operands -> derived columns (input columns first, then one per arithmetic node)
     struct Derived { uint32_t op, nops; Operand ops[4]; };
@@ -432,6 +432,7 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
             glob_w += kGlobWordsAvg;
         } else {
             h->need_rank = true;
+            h->has_minmax = true;
             lds_w += kWordsMinMax;
             glob_w += kWordsMinMax;
         }
@@ -486,8 +487,12 @@ n1k_status ensure_rank(n1k_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // earlier launches may still read the old table
     HIP_TRY(h, h->d_rank.ensure(std::max(n, (size_t)1)));
     if (n) HIP_TRY(h, hipMemcpy(h->d_rank.p, rank.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const bool rebuilt = h->rank_built_for != (size_t)-1;
     h->rank_built_for = n;
     h->prog.str_rank = h->d_rank.p;
+    // groups that hold string MIN / MAX winners carry ranks of the old order: re-stamp them (n1k_kernels.hip)
+    if (rebuilt && h->has_minmax && h->layout_fixed && h->table.capacity && (h->row_base || h->merged_groups_bound))
+        HIP_TRY(h, launch_restamp_ranks(h->prog, h->table, h->stream));
     return N1K_OK;
 }
 
@@ -1469,6 +1474,25 @@ void default_value(const AggDef& d, n1k_value& v, n1k_partial& p) {
 
 // ================================================================== C ABI
 
+// No C++ exception leaves the library ("no C++ exceptions or abort() across the ABI"; a Go caller cannot
+// unwind through cgo): allocation failures of the host containers become N1K_OOM, anything else N1K_DEVICE_ERROR.
+template <class F>
+static n1k_status guarded(const n1k_handle* ch, F&& f) noexcept {
+    n1k_handle* h = const_cast<n1k_handle*>(ch);
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        try { if (h) h->last_error = "out of host memory"; else g_create_error = "out of host memory"; } catch (...) {}
+        return N1K_OOM;
+    } catch (const std::exception& e) {
+        try { if (h) h->last_error = std::string("internal error: ") + e.what(); else g_create_error = e.what(); } catch (...) {}
+        return N1K_DEVICE_ERROR;
+    } catch (...) {
+        return N1K_DEVICE_ERROR;
+    }
+}
+
+
 extern "C" {
 
 int n1k_abi_version(void) { return N1K_ABI_VERSION; }
@@ -1482,6 +1506,7 @@ int n1k_device_count(void) {
 const char* n1k_create_error(void) { return g_create_error.c_str(); }
 
 n1k_status n1k_create(const char* plan_json, size_t len, n1k_handle** out) {
+    return guarded(nullptr, [&]() -> n1k_status {
     if (out) *out = nullptr;
     if (!plan_json || !out) {
         g_create_error = "null argument";
@@ -1542,10 +1567,18 @@ n1k_status n1k_create(const char* plan_json, size_t len, n1k_handle** out) {
     g_create_error.clear();
     *out = h;
     return N1K_OK;
+    });
 }
 
+static void destroy_handle(n1k_handle* h);
 void n1k_destroy(n1k_handle* h) {
     if (!h) return;
+    try {
+        destroy_handle(h);
+    } catch (...) {
+    }
+}
+static void destroy_handle(n1k_handle* h) {
     if (h->having) n1k_destroy(h->having);
     h->having = nullptr;
     if (h->device_ready) {
@@ -1611,6 +1644,7 @@ void n1k_destroy(n1k_handle* h) {
 }
 
 n1k_status n1k_reset(n1k_handle* h) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h) return N1K_INVALID;
     h->stop_flag.store(0);
     h->row_base = 0;
@@ -1645,6 +1679,7 @@ n1k_status n1k_reset(n1k_handle* h) {
         }
     }
     return N1K_OK;
+    });
 }
 
 void n1k_stop(n1k_handle* h) {
@@ -1664,6 +1699,7 @@ const char* n1k_aggregate_name(const n1k_handle* h, uint32_t i) {
 }
 
 n1k_status n1k_dict_intern(n1k_handle* h, uint32_t n, const uint64_t* offsets, const char* bytes, uint32_t* out_codes) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || (n && (!offsets || !bytes || !out_codes))) return N1K_INVALID;
     for (uint32_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i]) return fail(h, N1K_INVALID, "dictionary offsets are not monotone");
@@ -1671,18 +1707,22 @@ n1k_status n1k_dict_intern(n1k_handle* h, uint32_t n, const uint64_t* offsets, c
     }
     if (h->dict.size() >= 0xFFFFFFF0ull) return fail(h, N1K_OOM, "dictionary too large");
     return N1K_OK;
+    });
 }
 
 uint32_t n1k_dict_size(const n1k_handle* h) { return h ? (uint32_t)h->dict.size() : 0; }
 
 n1k_status n1k_dict_get(const n1k_handle* h, uint32_t code, const char** ptr, size_t* len) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !ptr || !len || code >= h->dict.size()) return N1K_INVALID;
     *ptr = h->dict[code].data();
     *len = h->dict[code].size();
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !name) return N1K_INVALID;
     std::string n = name;
     if (n == "agg_mode") h->opt_agg_mode = value;
@@ -1751,14 +1791,18 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     } else
         return fail(h, N1K_INVALID, "unknown option %s", name);
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_push_device_batch(n1k_handle* h, const n1k_batch* batch) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h) return N1K_INVALID;
     return push_device(h, batch);
+    });
 }
 
 n1k_status n1k_extract_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offsets, const char* bytes, n1k_batch* out) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !out || (ndocs && (!offsets || !bytes))) return N1K_INVALID;
     if (h->json_paths_state == 0) {
         h->json_paths.resize(h->plan.paths.size());
@@ -1776,16 +1820,30 @@ n1k_status n1k_extract_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offse
     std::vector<long long> bad(nthreads, -1);
     std::vector<std::thread> workers;
     auto range = [&](uint32_t t) { return std::make_pair(ndocs * t / nthreads, ndocs * (t + 1) / nthreads); };
-    for (uint32_t t = 1; t < nthreads; t++)
-        workers.emplace_back([&, t] {
+    // (a worker that throws — out of memory — reports it through its slot; a thread that cannot be started is replaced
+    //  by the calling thread: no exception may leave a joinable std::thread behind)
+    std::vector<char> threw(nthreads, 0);
+    auto work = [&](uint32_t t) {
+        try {
             auto r = range(t);
             bad[t] = extract_json_range(h->json_paths, offsets, bytes, r.first, r.second, part[t], errs[t]);
-        });
-    {
-        auto r = range(0);
-        bad[0] = extract_json_range(h->json_paths, offsets, bytes, r.first, r.second, part[0], errs[0]);
+        } catch (...) {
+            threw[t] = 1;
+        }
+    };
+    workers.reserve(nthreads);
+    std::vector<uint32_t> inline_ranges{0};
+    for (uint32_t t = 1; t < nthreads; t++) {
+        try {
+            workers.emplace_back(work, t);
+        } catch (...) {
+            inline_ranges.push_back(t);
+        }
     }
+    for (uint32_t t : inline_ranges) work(t);
     for (auto& w : workers) w.join();
+    for (uint32_t t = 0; t < nthreads; t++)
+        if (threw[t]) return fail(h, N1K_OOM, "out of host memory while scanning the documents");
     for (uint32_t t = 0; t < nthreads; t++)
         if (bad[t] >= 0) return fail(h, N1K_INVALID, "document %lld is not valid JSON: %s", bad[t], errs[t].c_str());
     // one dictionary: the threads' local strings get the handle's codes
@@ -1818,16 +1876,20 @@ n1k_status n1k_extract_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offse
     out->ncols = (uint32_t)np;
     out->cols = h->js_cols.data();
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_push_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offsets, const char* bytes) {
+    return guarded(h, [&]() -> n1k_status {
     n1k_batch b{};
     n1k_status st = n1k_extract_json(h, ndocs, offsets, bytes, &b);
     if (st != N1K_OK) return st;
     return n1k_push_batch(h, &b);
+    });
 }
 
 n1k_status n1k_push_batch(n1k_handle* h, const n1k_batch* batch) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h) return N1K_INVALID;
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
     n1k_status st = ensure_device(h);
@@ -1865,9 +1927,11 @@ n1k_status n1k_push_batch(n1k_handle* h, const n1k_batch* batch) {
     n1k_batch db = *batch;
     db.cols = dcols.data();
     return push_device(h, &db);
+    });
 }
 
 n1k_status n1k_sync(n1k_handle* h) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h) return N1K_INVALID;
     if (!h->device_ready) return N1K_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1877,10 +1941,11 @@ n1k_status n1k_sync(n1k_handle* h) {
     drain_events(h);
     if (h->plan.has_group) {
         h->stats.rows_selected = counters[0];
-        h->stats.groups_out = counters[1];  // groups in the table so far
+        h->stats.groups_out = h->pending.count ? h->pending.count : counters[1];  // groups so far (in the table, or in the kept region)
     }
     h->stats.wide_key_values = counters[13];
     return N1K_OK;
+    });
 }
 
 // where the de-duplication kernel counts the new members of each group: by the packed key itself when the plan has one
@@ -2242,6 +2307,7 @@ static n1k_status order_groups(n1k_handle* h, uint64_t& ng) {
 }
 
 n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !out) return N1K_INVALID;
     memset(out, 0, sizeof *out);
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
@@ -2481,9 +2547,11 @@ redo_sets:
     out->rep_row = h->r_rep.data();
     h->stats.groups_out = ng;
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_order_rows(n1k_handle* h, uint64_t ngroups, const n1k_value* keys, const n1k_value* aggs, n1k_result* out) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !out || (ngroups && ((!keys && !h->plan.keys.empty()) || (!aggs && !h->plan.aggs.empty())))) return N1K_INVALID;
     if (!h->plan.has_group) return fail(h, N1K_INVALID, "no groups in a Filter-only plan");
     const size_t nk = h->plan.keys.size(), na = h->plan.aggs.size();
@@ -2507,9 +2575,11 @@ n1k_status n1k_order_rows(n1k_handle* h, uint64_t ngroups, const n1k_value* keys
     out->partials = nullptr;
     out->rep_row = h->r_rep.data();
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_jit_check(n1k_handle* h, const uint32_t* col_kinds, uint32_t ncols, char* log, size_t loglen) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !col_kinds) return N1K_INVALID;
     if (log && loglen) log[0] = 0;
     if (ncols != h->plan.paths.size()) return fail(h, N1K_INVALID, "plan has %zu columns", h->plan.paths.size());
@@ -2535,9 +2605,11 @@ n1k_status n1k_jit_check(n1k_handle* h, const uint32_t* col_kinds, uint32_t ncol
     bool ok = jit_compile_check(sig, &l);
     if (log && loglen) snprintf(log, loglen, "%s", l.c_str());
     return ok ? N1K_OK : fail(h, N1K_DEVICE_ERROR, "run-time compilation failed: %s", l.substr(0, 300).c_str());
+    });
 }
 
 n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !out) return N1K_INVALID;
     // account pushes whose events have completed meanwhile (no waiting: hipEventQuery)
     n1k_handle* m = const_cast<n1k_handle*>(h);
@@ -2551,10 +2623,12 @@ n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
     }
     *out = h->stats;
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uint32_t nparts, uint64_t capacity_rows,
                                       const n1k_col* out_cols, uint64_t* out_counts) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !batch || !out_cols || !out_counts || nparts == 0) return N1K_INVALID;
     if (nparts > kMaxParts) return fail(h, N1K_INVALID, "at most %u destinations per partition call", kMaxParts);
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
@@ -2605,6 +2679,7 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
     h->stats.rows_in += batch->nrows;
     h->stats.batches += 1;
     return N1K_OK;
+    });
 }
 
 uint32_t n1k_partial_words(const n1k_handle* h) { return h ? h->prog.glob_words : 0; }
@@ -2615,6 +2690,7 @@ uint64_t n1k_partial_region_bytes(const n1k_handle* h, uint64_t capacity_groups)
 }
 
 n1k_status n1k_export_partials_async(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !out || nparts == 0 || capacity_groups == 0) return N1K_INVALID;
     if (h->pending.count) {
         n1k_status pst = flush_pending(h);
@@ -2630,9 +2706,11 @@ n1k_status n1k_export_partials_async(n1k_handle* h, uint32_t nparts, uint64_t ca
         HIP_TRY(h, launch_export_partials(h->prog, h->table, nparts, capacity_groups, (uint64_t*)out, region_words,
                                           h->d_errp, h->stream));
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
+    return guarded(h, [&]() -> n1k_status {
     n1k_status st = n1k_export_partials_async(h, nparts, capacity_groups, out);
     if (st != N1K_OK) return st;
     uint32_t err_flags = 0;
@@ -2654,9 +2732,11 @@ n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t c
                     (unsigned long long)capacity_groups);
     }
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_merge_partials_device(n1k_handle* h, uint32_t nregions, uint64_t capacity_groups, const void* in) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !in || nregions == 0 || capacity_groups == 0) return N1K_INVALID;
     if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
     if (!h->layout_fixed) return fail(h, N1K_INVALID, "merge needs the key layout: push a batch (even an empty one) first");
@@ -2677,9 +2757,11 @@ n1k_status n1k_merge_partials_device(n1k_handle* h, uint32_t nregions, uint64_t 
                                      h->d_errp, h->d_counters.p + 1, h->stream));
     h->merged_groups_bound += (uint64_t)nregions * capacity_groups;
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_export_groups(n1k_handle* h, const void** blob, size_t* len) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !blob || !len) return N1K_INVALID;
     n1k_status st = ensure_device(h);
     if (st != N1K_OK) return st;
@@ -2705,9 +2787,11 @@ n1k_status n1k_export_groups(n1k_handle* h, const void** blob, size_t* len) {
     *blob = h->export_blob.data();
     *len = h->export_blob.size();
     return N1K_OK;
+    });
 }
 
 n1k_status n1k_merge_groups(n1k_handle* h, const void* blob, size_t len) {
+    return guarded(h, [&]() -> n1k_status {
     if (!h || !blob || len < 32) return N1K_INVALID;
     uint64_t hdr[2];
     memcpy(hdr, blob, 16);
@@ -2723,11 +2807,13 @@ n1k_status n1k_merge_groups(n1k_handle* h, const void* blob, size_t len) {
     if (st == N1K_OK) HIP_TRY(h, hipStreamSynchronize(h->stream));
     tmp.release();
     return st;
+    });
 }
 
 n1k_status n1k_synth_columns(int device, void* stream, const n1k_synth_spec* spec, uint32_t* cat_codes, uint8_t* price_tags,
                              uint64_t* price_payload, uint8_t* user_tags, uint64_t* user_payload, uint8_t* region_tags,
                              uint64_t* region_payload) {
+    return guarded(nullptr, [&]() -> n1k_status {
     if (!spec) return N1K_INVALID;
     if (hipSetDevice(device) != hipSuccess) return N1K_DEVICE_ERROR;
     SynthArgs a{};
@@ -2746,6 +2832,7 @@ n1k_status n1k_synth_columns(int device, void* stream, const n1k_synth_spec* spe
     a.region_payload = region_payload;
     if (launch_synth(a, (hipStream_t)stream) != hipSuccess) return N1K_DEVICE_ERROR;
     return N1K_OK;
+    });
 }
 
 }  // extern "C"

@@ -39,10 +39,13 @@ bool parse_leaf_path(const std::string& text, JsonPath& out) {
 
 namespace {
 
+constexpr size_t kMaxJsonDepth = 10000;  // Go's encoding/json scanner gives up at the same depth
+
 struct Scanner {
     const char* p;
     const char* end;
     std::string* err;
+    std::string open;  // skip(): brackets still open
     bool fail(const char* m) {
         if (err->empty()) *err = m;
         return false;
@@ -139,46 +142,63 @@ struct Scanner {
         e = p;
         return true;
     }
-    bool skip() {  // any value
+    // Any value, skipped without recursion: a stack of open brackets instead, bounded like Go's encoding/json scanner
+    // (10000 levels; a document nested deeper than that is malformed for the reference too).
+    bool member_name() {
         ws();
-        if (p >= end) return fail("value expected");
-        switch (*p) {
-            case '"': return string(nullptr);
-            case '{': {
-                p++;
-                ws();
-                if (p < end && *p == '}') { p++; return true; }
-                for (;;) {
-                    ws();
+        if (!string(nullptr)) return false;
+        ws();
+        if (p >= end || *p != ':') return fail("':' expected");
+        p++;
+        return true;
+    }
+    bool skip() {
+        open.clear();
+        for (;;) {
+            // a value starts here
+            ws();
+            if (p >= end) return fail("value expected");
+            bool opened = false;
+            switch (*p) {
+                case '"':
                     if (!string(nullptr)) return false;
+                    break;
+                case '{':
+                case '[': {
+                    const char c = *p++;
                     ws();
-                    if (p >= end || *p != ':') return fail("':' expected");
-                    p++;
-                    if (!skip()) return false;
-                    ws();
-                    if (p < end && *p == ',') { p++; continue; }
-                    if (p < end && *p == '}') { p++; return true; }
-                    return fail("',' or '}' expected");
+                    if (p < end && *p == (c == '{' ? '}' : ']')) { p++; break; }
+                    if (open.size() >= kMaxJsonDepth) return fail("nesting too deep");
+                    open.push_back(c);
+                    if (c == '{' && !member_name()) return false;
+                    opened = true;
+                    break;
+                }
+                case 't': if (!literal("true", 4)) return false; break;
+                case 'f': if (!literal("false", 5)) return false; break;
+                case 'n': if (!literal("null", 4)) return false; break;
+                default: {
+                    const char *b, *e;
+                    if (!number(b, e)) return false;
                 }
             }
-            case '[': {
-                p++;
+            if (opened) continue;
+            // a value ended: close what it completes, or move to the next member / element
+            for (;;) {
+                if (open.empty()) return true;
                 ws();
-                if (p < end && *p == ']') { p++; return true; }
-                for (;;) {
-                    if (!skip()) return false;
-                    ws();
-                    if (p < end && *p == ',') { p++; continue; }
-                    if (p < end && *p == ']') { p++; return true; }
-                    return fail("',' or ']' expected");
+                const char top = open.back();
+                if (p < end && *p == ',') {
+                    p++;
+                    if (top == '{' && !member_name()) return false;
+                    break;
                 }
-            }
-            case 't': return literal("true", 4);
-            case 'f': return literal("false", 5);
-            case 'n': return literal("null", 4);
-            default: {
-                const char *b, *e;
-                return number(b, e);
+                if (p < end && *p == (top == '{' ? '}' : ']')) {
+                    p++;
+                    open.pop_back();
+                    continue;
+                }
+                return fail(top == '{' ? "',' or '}' expected" : "',' or ']' expected");
             }
         }
     }
@@ -280,7 +300,7 @@ void quote(const std::string& s, std::string& o) {
 
 // canonical text of the value at sc.p, appended to o
 bool canon(Scanner& sc, std::string& o, int depth) {
-    if (depth > 64) return sc.fail("nesting too deep");
+    if (depth > (int)kMaxJsonDepth) return sc.fail("nesting too deep");
     sc.ws();
     if (sc.p >= sc.end) return sc.fail("value expected");
     switch (*sc.p) {

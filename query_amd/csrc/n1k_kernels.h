@@ -38,6 +38,7 @@ struct SynthArgs {
 
 hipError_t launch_init_table(const Program& P, const GlobalTable& G, uint64_t first, uint64_t count,
                              unsigned long long* counters, hipStream_t st);
+hipError_t launch_restamp_ranks(const Program& P, const GlobalTable& G, hipStream_t st);
 hipError_t launch_rehash(const Program& P, const GlobalTable& oldt, const GlobalTable& newt, uint32_t* err_flags,
                          unsigned long long* ngroups_scratch, hipStream_t st);
 hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTable& G, unsigned long long* ngroups,

@@ -1602,6 +1602,29 @@ __global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(ngroups, (unsigned long long)__popcll(m));
 }
 
+// MIN / MAX over strings keep (rank << 32 | code) so that atomicMin / atomicMax order them bytewise; the ranks belong to
+// the dictionary as it was when the row was seen.  When the dictionary has grown since (new strings between batches)
+// the winners kept so far are re-stamped with their ranks in the new order before any new row is compared with them.
+__global__ void restamp_ranks_kernel(const Program P, const GlobalTable G) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.capacity || G.keys[s] == kEmptyKey) return;
+    for (uint32_t a = 0; a < P.naggs; a++) {
+        const AggSpec& ag = P.aggs[a];
+        if (ag.distinct || (ag.kind != AGG_MIN && ag.kind != AGG_MAX)) continue;
+        uint64_t* w = &G.acc[s * P.glob_words + ag.glob_off];
+        if (w[0] & MM_STRING) {
+            const uint32_t code = (uint32_t)w[3];
+            w[3] = ((uint64_t)P.str_rank[code] << 32) | code;
+        }
+    }
+}
+
+hipError_t launch_restamp_ranks(const Program& P, const GlobalTable& G, hipStream_t st) {
+    if (!G.capacity) return hipSuccess;
+    hipLaunchKernelGGL(restamp_ranks_kernel, dim3((uint32_t)((G.capacity + 255) / 256)), dim3(256), 0, st, P, G);
+    return hipGetLastError();
+}
+
 // grow the global table: re-insert every occupied slot (keys keep their packed form)
 __global__ void rehash_kernel(const Program P, const GlobalTable oldt, const GlobalTable newt, uint32_t* err_flags,
                               unsigned long long* scratch) {

@@ -78,7 +78,9 @@ class FixedGather:
     [count i64][records ...]; if some rank has more records than a slot holds, every rank sees it in the gathered
     headers and all retry with larger slots."""
 
-    def __init__(self, record_bytes: int, capacity: int = 4096):
+    def __init__(self, record_bytes: int, capacity: Optional[int] = None):
+        """capacity: records per slot, THE SAME ON EVERY RANK (a slot's size is part of the collective's shape); None =
+        agreed on at the first call from the largest contribution (one small all-reduce)."""
         self.record_bytes = max(int(record_bytes), 1)
         self.capacity = capacity
         self._bufs = None
@@ -88,6 +90,11 @@ class FixedGather:
         import torch.distributed as dist
         world = dist.get_world_size(group)
         n = int(local.shape[0])
+        if self.capacity is None:
+            # ranks own different numbers of groups after a hash partition: the slot size must not depend on the local one
+            most = torch.tensor([n], dtype=torch.int64, device=device)
+            dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
+            self.capacity = max(1024, int(2 ** int(np.ceil(np.log2(max(2 * int(most.item()), 1))))))
         while True:
             slot = 8 + self.capacity * self.record_bytes
             if self._bufs is None or self._bufs[0].numel() != slot:
@@ -253,7 +260,7 @@ class ShardedFilterGroup:
         rec = np.concatenate([raw["keys"].view(np.uint8).reshape(ng, -1), raw["aggs"].view(np.uint8).reshape(ng, -1)], axis=1) \
             if ng else np.zeros((0, 16 * (nk + na)), np.uint8)
         if self._gather is None:
-            self._gather = FixedGather(16 * (nk + na), capacity=max(1024, 2 * ng))
+            self._gather = FixedGather(16 * (nk + na))  # capacity agreed on across the ranks at the first call
         allg = np.ascontiguousarray(self._gather(rec, device))
         n = allg.shape[0]
         dt = GpuFilterGroup._VALUE_DT

@@ -88,6 +88,12 @@ def _worker(rank, port, result_path):
     fixed = qd.FixedGather(rec.shape[1], capacity=4)(rec, torch.device("cpu"))  # too small on purpose: must retry
     if rank == 0:
         assert fixed.shape == allg.shape and np.array_equal(np.sort(fixed.view(np.int64)[:, 0]), np.sort(allg.view(np.int64)[:, 0]))
+    # ranks that own very different numbers of groups (more than a default slot on one of them, next to none on the
+    # other): the slot size is agreed on across the ranks, never derived from the local count
+    mine = np.arange((5000 if rank == 1 else 3) * 24, dtype=np.uint8).reshape(-1, 24) + np.uint8(rank)
+    both = qd.FixedGather(24)(mine, torch.device("cpu"))
+    assert both.shape == (5003, 24) and np.array_equal(both[:3] if rank == 0 else both[:3], (np.arange(3 * 24, dtype=np.uint8).reshape(-1, 24)))
+    assert np.array_equal(both[3:], np.arange(5000 * 24, dtype=np.uint8).reshape(-1, 24) + np.uint8(1))
     if rank == 0:
         np.save(result_path, allg.view(np.int64))
     dist.barrier()

@@ -470,6 +470,42 @@ def test_wide_key_values_survive_reopen():
     op.done()
 
 
+def test_string_min_max_when_the_dictionary_grows_between_batches():
+    """MIN / MAX over strings compare by bytewise rank (value/string.go:116-130).  The ranks belong to the dictionary
+    of the moment: a batch that brings strings sorting BEFORE the winners kept so far must still be compared in the
+    new order (the kept winners are re-stamped).  Batch 1 knows {m, z}; batch 2 adds {a, b, zz}."""
+    keys, aggs = [D("g")], sorted(["min(%s)" % D("s"), "max(%s)" % D("s"), "count(*)"])
+
+    def batch(groups, strings, dictionary):
+        g = np.array(groups, dtype=np.uint64)
+        codes = np.array([dictionary.index(x) for x in strings], dtype=np.uint64)
+        n = len(groups)
+        return n1o.Table([n1o.Column(D("g"), n1o.COL_TAGGED64, tags=np.full(n, n1o.T_INT, np.uint8), payload=g),
+                          n1o.Column(D("s"), n1o.COL_TAGGED64, tags=np.full(n, n1o.T_STRING, np.uint8), payload=codes)], dictionary)
+
+    d1, d2 = [b"m", b"z"], [b"a", b"b", b"m", b"zz"]
+    b1 = batch([0, 0, 1, 1, 2], [b"z", b"m", b"m", b"m", b"z"], d1)
+    b2 = batch([0, 1, 1, 2, 3], [b"m", b"a", b"zz", b"b", b"a"], d2)
+    union = [b"m", b"z", b"a", b"b", b"zz"]
+    whole = batch([0, 0, 1, 1, 2, 0, 1, 1, 2, 3], [b"z", b"m", b"m", b"m", b"z", b"m", b"a", b"zz", b"b", b"a"], union)
+    ora = n1o.run(whole, None, keys, aggs)
+    for json_docs in (False, True):
+        op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(None, keys, aggs))
+        if json_docs:  # the streaming path of the finding: every n1k_push_json interns the batch's new strings
+            op.process_json([b'{"g": %d, "s": "%s"}' % (g, s) for g, s in zip([0, 0, 1, 1, 2], [b"z", b"m", b"m", b"m", b"z"])])
+            op.process_json([b'{"g": %d, "s": "%s"}' % (g, s) for g, s in zip([0, 1, 1, 2, 3], [b"m", b"a", b"zz", b"b", b"a"])])
+        else:
+            for b in (b1, b2):
+                op.process_items([{c.name: c for c in b.columns}[p] for p in op.column_paths], b.dictionary)
+        rows = op.after_items()
+        op.done()
+        pu.assert_same_groups(rows, ora, aggs=aggs)
+        got = {k[0][1]: a for k, a in zip(rows.keys, rows.aggs)}
+        mx, mn = aggs.index("max(%s)" % D("s")), aggs.index("min(%s)" % D("s"))
+        assert got[0][mn][1] == b"m" and got[0][mx][1] == b"z" and got[1][mn][1] == b"a" and got[1][mx][1] == b"zz"
+        assert got[2][mn][1] == b"b" and got[2][mx][1] == b"z"
+
+
 def _distinct_table(n, nvals, ngroups, seed=3, wide_share=0.1):
     """(g, v): v mostly small ints (one-word members), plus floats / huge ints / strings (two-word pairs)."""
     rng = np.random.default_rng(seed)

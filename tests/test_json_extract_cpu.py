@@ -130,6 +130,27 @@ def test_malformed_documents_are_named():
     op.done()
 
 
+def test_deep_nesting_is_bounded_like_the_reference():
+    """Go's encoding/json scanner accepts 10000 nested levels and rejects more; the scanner here skips unwanted values
+    without recursion (a hostile '[[[[...' document must not overflow a worker thread's stack), and wanted array /
+    object values take the same bound."""
+    def nest(depth, inner=b"1"):
+        return b"[" * depth + inner + b"]" * depth
+    a, = _one(b'{"junk": ' + nest(9_990) + b', "a": 5}', "a")
+    assert a == (n1o.T_INT, 5)
+    a, = _one(b'{"junk": ' + b'{"k":' * 5_000 + b"null" + b"}" * 5_000 + b', "a": "x"}', "a")
+    assert a == (n1o.T_STRING, b"x")
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(None, [D("a")], ["count(*)"]))
+    for hostile in (b'{"junk": ' + nest(10_050) + b', "a": 5}', b'{"junk": ' + b"[" * 200_000 + b', "a": 5}'):
+        with pytest.raises(query_amd.N1kError) as ei:
+            op.extract_json([b'{"a": 1}', hostile])
+        assert ei.value.status == _ffi.INVALID and "document 1" in ei.value.message
+    op.done()
+    # a wanted value nested far deeper than the 64 levels of the first version: canonical text, as the reference would key it
+    a, = _one(b'{"a": ' + nest(500, b'{"b": 1.0}') + b"}", "a")
+    assert a == (n1o.T_ARRAY, nest(500, b'{"b":1}'))
+
+
 def test_threads_agree_and_share_one_dictionary():
     rng = np.random.default_rng(2)
     docs = [json.dumps({"cat": "c%d" % rng.integers(0, 50), "price": float(rng.integers(0, 10000)) / 100,
