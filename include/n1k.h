@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define N1K_ABI_VERSION 1
+#define N1K_ABI_VERSION 2 /* 2: n1k_result.nproj / proj, projection and communicator entry points */
 
 /* ---------------------------------------------------------------- status -- */
 
@@ -138,6 +138,10 @@ typedef struct n1k_result {
                                     first row it met as carrier, execution/group_initial.go:69-72) */
     uint64_t nselected;          /* Filter-only plans: number of rows that passed */
     const uint64_t *selected;    /* Filter-only plans: their row ordinals, ascending */
+    uint32_t nproj;              /* plans with an InitialProject: number of result terms, else 0 */
+    uint32_t reserved1;
+    const n1k_value *proj;       /* [ngroups][nproj]  value of every result term (≙ the "projection" attachment,
+                                    execution/project_initial.go:100-144; a MISSING term is left out of the row) */
 } n1k_result;
 
 typedef struct n1k_stats {
@@ -183,7 +187,13 @@ typedef struct n1k_handle n1k_handle;
  *        {"#operator":"Filter","condition":"…"},                                       HAVING, plan/filter.go
  *        {"#operator":"Order","sort_terms":[{"expr":"…","desc":true}],"offset":"…","limit":"…"},  plan/order.go:51-79
  *        {"#operator":"Offset","expr":"…"}, {"#operator":"Limit","expr":"…"}]}               plan/limit.go:46-53)
+ *        {"#operator":"Parallel","~child":{"#operator":"Sequence","~children":[                   (HAVING and projection
+ *             {"#operator":"Filter",…}, {"#operator":"InitialProject","result_terms":[{"expr":"…","as":"…"}]}]}},    as the planner
+ *        {"#operator":"FinalProject"}]}                                                            nests them, plan/project.go:73-110)
  *     IntermediateGroup / FinalGroup must repeat the InitialGroup's lists (plan/group.go:106-273) and are subsumed;
+ *     the result terms of an InitialProject are expressions over group keys and aggregates (constants, arithmetic,
+ *     round / trunc / abs / ceil / floor / sign / sqrt): n1k_result.proj then holds their values per group, and a sort
+ *     term may name a term's alias (`alias`) or repeat its expression; star / raw / distinct projections are N1K_UNSUPPORTED;
  *     the HAVING condition and the sort terms may name only group keys and aggregates of the plan (by their text);
  *     offset / limit are integer constants.  n1k_finish then returns the groups filtered, ordered and cut.
  * exactly as plan.(*Filter).MarshalJSON (plan/filter.go:46-53),
@@ -217,6 +227,12 @@ uint32_t n1k_num_aggregates(const n1k_handle *h);
 /* agg.String() of aggregate i — the key of the reference's "aggregates"
  * attachment map (execution/group_initial.go:74-79). */
 const char *n1k_aggregate_name(const n1k_handle *h, uint32_t i);
+
+/* Result terms of the plan's InitialProject (0 when it has none): expression text and explicit alias ("" = none; the
+ * caller derives one as algebra.ResultTerm does: the last name of a path, else $1, $2, ...). */
+uint32_t n1k_num_projection_terms(const n1k_handle *h);
+const char *n1k_projection_expr(const n1k_handle *h, uint32_t i);
+const char *n1k_projection_alias(const n1k_handle *h, uint32_t i);
 
 /* ------------------------------------------------------------ dictionary -- */
 

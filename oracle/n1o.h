@@ -46,6 +46,11 @@ typedef struct n1o_result {
     uint64_t rows_filtered_in; /* rows that passed the filter */
     double seconds;            /* wall time of the run proper (no parsing) */
     char err[512];
+    /* values built by the run (ARRAY_AGG arrays): string i is extra_bytes[extra_offsets[i] .. extra_offsets[i+1]),
+     * referred to by the code dict_n + i */
+    char *extra_bytes;
+    uint64_t *extra_offsets;
+    uint32_t extra_n;
 } n1o_result;
 
 /*

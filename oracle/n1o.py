@@ -46,7 +46,8 @@ class _Result(C.Structure):
     _fields_ = [("ngroups", C.c_uint64), ("nkeys", C.c_uint32), ("naggs", C.c_uint32),
                 ("keys", C.POINTER(_Value)), ("aggs", C.POINTER(_Value)),
                 ("nselected", C.c_uint64), ("selected", C.POINTER(C.c_uint64)),
-                ("rows_filtered_in", C.c_uint64), ("seconds", C.c_double), ("err", C.c_char * 512)]
+                ("rows_filtered_in", C.c_uint64), ("seconds", C.c_double), ("err", C.c_char * 512),
+                ("extra_bytes", C.c_void_p), ("extra_offsets", C.POINTER(C.c_uint64)), ("extra_n", C.c_uint32)]
 
 
 def build(force: bool = False) -> str:
@@ -199,13 +200,17 @@ def run(table: Table, condition: Optional[str], keys: Sequence[str], aggs: Seque
     try:
         ng, nk, na = int(res.ngroups), int(res.nkeys), int(res.naggs)
         out = GroupResult(nk, na, [], [], rows_passed=int(res.rows_filtered_in), seconds=float(res.seconds))
+        dictionary = list(table.dictionary)
+        for i in range(int(res.extra_n)):  # values the run built (ARRAY_AGG arrays): codes behind the dictionary's
+            lo, hi = int(res.extra_offsets[i]), int(res.extra_offsets[i + 1])
+            dictionary.append(C.string_at(res.extra_bytes + lo, hi - lo))
         if not has_group:
             out.selected = np.ctypeslib.as_array(res.selected, shape=(int(res.nselected),)).copy() \
                 if res.nselected else np.zeros(0, dtype=np.uint64)
             return out
         for g in range(ng):
-            out.keys.append(tuple(_pyvalue(res.keys[g * nk + k], table.dictionary) for k in range(nk)))
-            out.aggs.append(tuple(_pyvalue(res.aggs[g * na + a], table.dictionary) for a in range(na)))
+            out.keys.append(tuple(_pyvalue(res.keys[g * nk + k], dictionary) for k in range(nk)))
+            out.aggs.append(tuple(_pyvalue(res.aggs[g * na + a], dictionary) for a in range(na)))
         return out
     finally:
         L.n1o_free_result(C.byref(res))

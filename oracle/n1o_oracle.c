@@ -231,7 +231,8 @@ static val num_imod(val a, val b) {
 
 enum {
     E_CONST, E_PATH, E_ADD, E_SUB, E_MULT, E_DIV, E_MOD, E_NEG, E_IDIV, E_IMOD, E_EQ, E_LT, E_LE, E_BETWEEN,
-    E_AND, E_OR, E_NOT, E_ISNULL, E_ISNOTNULL, E_ISMISSING, E_ISNOTMISSING, E_ISVALUED, E_ISNOTVALUED
+    E_AND, E_OR, E_NOT, E_ISNULL, E_ISNOTNULL, E_ISMISSING, E_ISNOTMISSING, E_ISVALUED, E_ISNOTVALUED,
+    E_ROUND, E_TRUNC, E_ABS, E_CEIL, E_FLOOR, E_SIGN, E_SQRT /* expression/func_num.go */
 };
 
 typedef struct node {
@@ -442,7 +443,23 @@ static node *parse_function(parser *p) {
     int kind = -1;
     if (!strcmp(name, "idiv")) kind = E_IDIV;
     else if (!strcmp(name, "imod")) kind = E_IMOD;
-    else {
+    else if (!strcmp(name, "round") || !strcmp(name, "trunc") || !strcmp(name, "abs") || !strcmp(name, "ceil") ||
+             !strcmp(name, "floor") || !strcmp(name, "sign") || !strcmp(name, "sqrt")) {
+        /* numeric functions of one argument; ROUND / TRUNC take an optional digit count */
+        kind = !strcmp(name, "round") ? E_ROUND : !strcmp(name, "trunc") ? E_TRUNC : !strcmp(name, "abs") ? E_ABS
+               : !strcmp(name, "ceil") ? E_CEIL : !strcmp(name, "floor") ? E_FLOOR : !strcmp(name, "sign") ? E_SIGN : E_SQRT;
+        if (!eat_char(p, '(')) { perr(p, "expected ( after %s", name); return NULL; }
+        node *nd = mknode(kind);
+        for (;;) {
+            node *a = parse_expr(p);
+            if (!a) { free_node(nd); return NULL; }
+            addch(nd, a);
+            if (!eat_char(p, ',')) break;
+        }
+        if (!eat_char(p, ')')) { perr(p, "expected )"); free_node(nd); return NULL; }
+        if (nd->nch > ((kind == E_ROUND || kind == E_TRUNC) ? 2 : 1)) { perr(p, "too many arguments to %s", name); free_node(nd); return NULL; }
+        return nd;
+    } else {
         perr(p, "function %s is outside the oracle subset", name);
         return NULL;
     }
@@ -634,7 +651,7 @@ static node *parse_full(const char *s, char *err, size_t errlen) {
 }
 
 /* aggregates: name([distinct ]operand|*)  stringer.go:581-604 */
-enum { A_SUM, A_COUNT, A_COUNTN, A_AVG, A_MIN, A_MAX };
+enum { A_SUM, A_COUNT, A_COUNTN, A_AVG, A_MIN, A_MAX, A_ARRAY };
 typedef struct aggdef {
     int kind;
     int distinct;
@@ -663,6 +680,7 @@ static int parse_aggregate(const char *s, aggdef *a, char *err, size_t errlen) {
     else if (!strcmp(name, "avg")) a->kind = A_AVG;
     else if (!strcmp(name, "min")) a->kind = A_MIN;
     else if (!strcmp(name, "max")) a->kind = A_MAX;
+    else if (!strcmp(name, "array_agg")) a->kind = A_ARRAY;
     else goto bad;
     if (!eat_char(&p, '(')) goto bad;
     a->distinct = eat_word(&p, "distinct");
@@ -757,8 +775,47 @@ static val load_col(const n1o_table *t, int col, uint64_t row) {
     }
 }
 
+/* roundFloat (expression/func_num.go:1715-1736) */
+static double round_float(double x, int prec) {
+    if (isnan(x) || isinf(x)) return x;
+    double sign = 1.0;
+    if (x < 0) { sign = -1.0; x = -x; }
+    double pw = pow(10, (double)prec);
+    double intermed = x * pw + 0.5;
+    double rounder = floor(intermed);
+    if (rounder == intermed && fmod(rounder, 2) != 0) rounder--;
+    return sign * rounder / pw;
+}
+
 static val eval(const node *n, uint64_t row, ectx *cx) {
     switch (n->kind) {
+    case E_ROUND: case E_TRUNC: case E_ABS: case E_CEIL: case E_FLOOR: case E_SIGN: case E_SQRT: {
+        /* Round.Apply func_num.go:1304-1333, Trunc.Apply :1647-1680, Abs :63-71, Ceil :367-375, Floor :774-782,
+         * Sign :1396-1412, Sqrt :1524-1532: MISSING in, MISSING out; a non-number is NULL; the number goes through
+         * float64 (intValue.Actual(), value/integer.go:57-59) and the result through value.NewValue */
+        val a = eval(n->ch[0], row, cx);
+        if (a.type == TY_MISSING) return V_MISSING;
+        if (a.type != TY_NUMBER) return V_NULL;
+        double v = num_actual(a);
+        int prec = 0;
+        if (n->nch == 2) {
+            val pv = eval(n->ch[1], row, cx);
+            if (pv.type == TY_MISSING) return V_MISSING;
+            if (pv.type != TY_NUMBER) return V_NULL;
+            double pf = num_actual(pv);
+            if (pf != trunc(pf)) return V_NULL;
+            prec = (int)pf;
+        }
+        switch (n->kind) {
+        case E_ROUND: return new_value_f64(round_float(v, prec));
+        case E_TRUNC: { double pw = pow(10, (double)prec); return new_value_f64(trunc(v * pw) / pw); } /* truncateFloat :1703-1708 */
+        case E_ABS: return new_value_f64(fabs(v));
+        case E_CEIL: return new_value_f64(ceil(v));
+        case E_FLOOR: return new_value_f64(floor(v));
+        case E_SIGN: return new_value_f64(v < 0.0 ? -1.0 : (v > 0.0 ? 1.0 : 0.0));
+        default: return new_value_f64(sqrt(v));
+        }
+    }
     case E_CONST: return n->cval;
     case E_PATH: return load_col(cx->t, n->col, row);
     case E_ADD: { /* expression/arith_add.go:51-70 */
@@ -1013,7 +1070,17 @@ typedef struct aggstate {
     val avg_count;  /* AVG: count */
     uint8_t is_null;/* AVG: cumulative == NULL_VALUE; DISTINCT: no set yet (ZERO/NULL default) */
     vset *set;
+    val *items;     /* ARRAY_AGG: the cumulative array ([]interface{}), in arrival order until ComputeFinal sorts it */
+    size_t nitems, capitems;
 } aggstate;
+
+static void items_push(aggstate *st, val v) {
+    if (st->nitems == st->capitems) {
+        st->capitems = st->capitems ? st->capitems * 2 : 8;
+        st->items = realloc(st->items, st->capitems * sizeof(val));
+    }
+    st->items[st->nitems++] = v;
+}
 
 /* Default(): algebra/agg_sum.go:77, agg_count.go:95, agg_countn.go:77, agg_avg.go:77, agg_min.go:76, agg_max.go:76,
  * agg_count_distinct.go:76, agg_sum_distinct.go:79 */
@@ -1035,6 +1102,15 @@ static void agg_default(const aggdef *a, aggstate *st) {
 static void agg_cumulate_initial(const aggdef *a, aggstate *st, uint64_t row, ectx *cx) {
     val item = V_NULL;
     if (a->operand) item = eval(a->operand, row, cx);
+    if (a->kind == A_ARRAY) {
+        /* ArrayAgg.CumulateInitial algebra/agg_array.go:86-97 / ArrayAggDistinct agg_array_distinct.go:86-97: every
+         * operand but MISSING (BINARY does not exist on this path) joins; DISTINCT is applied by ComputeFinal here
+         * (value.Set membership: the sorted members that collate equal are one) */
+        if (item.type <= TY_MISSING) return;
+        st->is_null = 0;
+        items_push(st, item);
+        return;
+    }
     if (a->distinct) {
         /* agg_count_distinct.go:84-95 (type <= NULL skipped); agg_countn_distinct.go / agg_sum_distinct.go:85-97 /
          * agg_avg_distinct.go:86-98 (non-NUMBER skipped); setAdd: agg_util.go:30-47 */
@@ -1084,6 +1160,11 @@ static void agg_cumulate_initial(const aggdef *a, aggstate *st, uint64_t row, ec
 
 /* CumulateIntermediate(part, cumulative) */
 static void agg_cumulate_intermediate(const aggdef *a, const aggstate *part, aggstate *cum, ectx *cx) {
+    if (a->kind == A_ARRAY) { /* cumulatePart agg_array.go:118-145: append; cumulateSets for DISTINCT */
+        for (size_t i = 0; i < part->nitems; i++) items_push(cum, part->items[i]);
+        if (part->nitems) cum->is_null = 0;
+        return;
+    }
     if (a->distinct) {
         /* agg_count_distinct.go:103-111; a partial without a set is the ZERO/NULL default. For SUM/AVG DISTINCT the
          * reference would raise "Invalid DISTINCT" on a NULL partial (agg_util.go:87-101); it is treated as the
@@ -1294,11 +1375,13 @@ static void gmap_add(gmap *m, group *g) {
     gmap_insert_raw(m, g);
 }
 static void group_free(group *g, uint32_t naggs) {
-    for (uint32_t i = 0; i < naggs; i++)
+    for (uint32_t i = 0; i < naggs; i++) {
+        free(g->aggs[i].items);
         if (g->aggs[i].set) {
             set_free(g->aggs[i].set);
             free(g->aggs[i].set);
         }
+    }
     free(g->key);
     free(g->keyvals);
     free(g->aggs);
@@ -1404,6 +1487,77 @@ static void out_value(val v, n1k_value *o, int *bad) {
         break;
     default: *bad = 1;
     }
+}
+
+/* ArrayAgg.ComputeFinal (algebra/agg_array.go:105-112): NULL when nothing joined, else the array sorted with
+ * value.NewSorter (Collate).  ArrayAggDistinct.ComputeFinal (agg_array_distinct.go:111-127): the set's members,
+ * sorted; an empty set is NULL.  The array leaves as its canonical JSON text (value.MarshalJSON: numbers as
+ * integer.go:34-37 / float.go:31-48, strings without HTML escaping) in the result's extra strings; its code is
+ * dict_n + index. */
+static int cmp_collate_ctx_unsupported;
+static int cmp_collate(const void *x, const void *y) {
+    return collate(*(const val *)x, *(const val *)y, &cmp_collate_ctx_unsupported);
+}
+static void sb_put_json_string(strbuf *b, const char *s, uint32_t n) {
+    sb_put(b, "\"", 1);
+    for (uint32_t i = 0; i < n; i++) {
+        unsigned char c = (unsigned char)s[i];
+        char esc[8];
+        switch (c) {
+        case '"': sb_put(b, "\\\"", 2); break;
+        case '\\': sb_put(b, "\\\\", 2); break;
+        case '\n': sb_put(b, "\\n", 2); break;
+        case '\r': sb_put(b, "\\r", 2); break;
+        case '\t': sb_put(b, "\\t", 2); break;
+        case '\b': sb_put(b, "\\b", 2); break;
+        case '\f': sb_put(b, "\\f", 2); break;
+        default:
+            if (c < 0x20) { snprintf(esc, sizeof esc, "\\u%04x", c); sb_put(b, esc, 6); }
+            else sb_put(b, &s[i], 1);
+        }
+    }
+    sb_put(b, "\"", 1);
+}
+static void array_agg_final(const aggdef *a, aggstate *st, const n1o_table *t, ectx *cx, strbuf *extra, uint64_t **off,
+                            uint32_t *n, uint32_t *cap, n1k_value *out) {
+    memset(out, 0, sizeof *out);
+    out->tag = N1K_T_NULL;
+    if (st->nitems == 0) return;
+    cmp_collate_ctx_unsupported = 0;
+    /* sort.Sort is not stable, Collate is total on this path's scalars: any stable choice gives the same JSON */
+    qsort(st->items, st->nitems, sizeof(val), cmp_collate);
+    if (cmp_collate_ctx_unsupported) cx->unsupported = 1;
+    if (*n + 2 > *cap) {
+        *cap = *cap ? *cap * 2 : 64;
+        *off = realloc(*off, ((size_t)*cap + 1) * sizeof(uint64_t));
+    }
+    if (*n == 0) (*off)[0] = 0;
+    sb_put(extra, "[", 1);
+    int first = 1;
+    for (size_t i = 0; i < st->nitems; i++) {
+        val v = st->items[i];
+        if (a->distinct && i > 0) {
+            int u = 0;
+            if (collate(st->items[i - 1], v, &u) == 0) continue; /* one member (value/set.go:65-110) */
+        }
+        if (!first) sb_put(extra, ",", 1);
+        first = 0;
+        char num[32];
+        switch (v.type) {
+        case TY_NULL: sb_put(extra, "null", 4); break;
+        case TY_BOOLEAN: if (v.b) sb_put(extra, "true", 4); else sb_put(extra, "false", 5); break;
+        case TY_NUMBER:
+            if (v.isf) format_float_f(v.f, extra);
+            else { int k = snprintf(num, sizeof num, "%lld", (long long)v.i); sb_put(extra, num, (size_t)k); }
+            break;
+        case TY_STRING: sb_put_json_string(extra, v.s, v.slen); break;
+        default: sb_put(extra, v.s, v.slen); break; /* arrays / objects: canonical text */
+        }
+    }
+    sb_put(extra, "]", 1);
+    (*off)[++*n] = extra->n;
+    out->tag = N1K_T_ARRAY;
+    out->v.code = (uint64_t)t->dict_n + (*n - 1);
 }
 
 static double now_s(void) {
@@ -1519,6 +1673,10 @@ int n1o_run(const char *condition, const char *const *keys, uint32_t nkeys, cons
     /* FinalGroup: execution/group_final.go:55-118 — ComputeFinal per aggregate; with no keys and no input one
      * row of Default() values is emitted (:108-117). */
     int bad = 0;
+    strbuf extra;
+    memset(&extra, 0, sizeof extra);
+    uint64_t *extra_off = NULL;
+    uint32_t extra_n = 0, extra_cap = 0;
     uint64_t ng = inter.n;
     int default_row = (nkeys == 0 && ng == 0);
     uint64_t nout = default_row ? 1 : ng;
@@ -1535,10 +1693,19 @@ int n1o_run(const char *condition, const char *const *keys, uint32_t nkeys, cons
         for (uint64_t gi = 0; gi < ng; gi++) {
             group *g = inter.list[gi];
             for (uint32_t k = 0; k < nkeys; k++) out_value(g->keyvals[k], &out->keys[gi * nkeys + k], &bad);
-            for (uint32_t a = 0; a < naggs; a++)
+            for (uint32_t a = 0; a < naggs; a++) {
+                if (pl.aggs[a].kind == A_ARRAY) {
+                    array_agg_final(&pl.aggs[a], &g->aggs[a], t, &cx, &extra, &extra_off, &extra_n, &extra_cap,
+                                    &out->aggs[gi * naggs + a]);
+                    continue;
+                }
                 out_value(agg_compute_final(&pl.aggs[a], &g->aggs[a]), &out->aggs[gi * naggs + a], &bad);
+            }
         }
     }
+    out->extra_bytes = extra.p;
+    out->extra_offsets = extra_off;
+    out->extra_n = extra_n;
     out->seconds = now_s() - t0;
     gmap_free(&inter, naggs, 1);
     plan_free(&pl);
@@ -1553,6 +1720,11 @@ void n1o_free_result(n1o_result *r) {
     free(r->keys);
     free(r->aggs);
     free(r->selected);
+    free(r->extra_bytes);
+    free(r->extra_offsets);
+    r->extra_bytes = NULL;
+    r->extra_offsets = NULL;
+    r->extra_n = 0;
     r->keys = r->aggs = NULL;
     r->selected = NULL;
 }

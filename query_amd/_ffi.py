@@ -51,7 +51,8 @@ class Partial(C.Structure):
 class Result(C.Structure):
     _fields_ = [("ngroups", C.c_uint64), ("nkeys", C.c_uint32), ("naggs", C.c_uint32), ("keys", C.POINTER(Value)),
                 ("aggs", C.POINTER(Value)), ("partials", C.POINTER(Partial)), ("rep_row", C.POINTER(C.c_uint64)),
-                ("nselected", C.c_uint64), ("selected", C.POINTER(C.c_uint64))]
+                ("nselected", C.c_uint64), ("selected", C.POINTER(C.c_uint64)),
+                ("nproj", C.c_uint32), ("reserved1", C.c_uint32), ("proj", C.POINTER(Value))]
 
 
 class Stats(C.Structure):
@@ -70,7 +71,8 @@ class SynthSpec(C.Structure):
 # every symbol include/n1k.h declares (tests check that the .so exports all of them)
 SYMBOLS = [
     "n1k_create", "n1k_destroy", "n1k_reset", "n1k_stop", "n1k_last_error", "n1k_create_error", "n1k_num_columns",
-    "n1k_column_path", "n1k_num_keys", "n1k_num_aggregates", "n1k_aggregate_name", "n1k_dict_intern", "n1k_dict_size",
+    "n1k_column_path", "n1k_num_keys", "n1k_num_aggregates", "n1k_aggregate_name", "n1k_num_projection_terms",
+    "n1k_projection_expr", "n1k_projection_alias", "n1k_dict_intern", "n1k_dict_size",
     "n1k_dict_get", "n1k_set_option", "n1k_push_batch", "n1k_extract_json", "n1k_push_json", "n1k_push_device_batch", "n1k_sync", "n1k_finish",
     "n1k_get_stats", "n1k_partition_device_batch", "n1k_export_groups", "n1k_order_rows", "n1k_merge_groups", "n1k_synth_columns",
     "n1k_jit_check", "n1k_partial_words", "n1k_partial_region_bytes", "n1k_export_partials_device", "n1k_export_partials_async",
@@ -111,7 +113,10 @@ def lib():
     L.n1k_last_error.argtypes = [H]
     L.n1k_create_error.restype = C.c_char_p
     L.n1k_create_error.argtypes = []
-    for f in ("n1k_num_columns", "n1k_num_keys", "n1k_num_aggregates", "n1k_dict_size"):
+    for f in ("n1k_projection_expr", "n1k_projection_alias"):
+        getattr(L, f).restype = C.c_char_p
+        getattr(L, f).argtypes = [H, C.c_uint32]
+    for f in ("n1k_num_columns", "n1k_num_keys", "n1k_num_aggregates", "n1k_dict_size", "n1k_num_projection_terms"):
         getattr(L, f).restype = C.c_uint32
         getattr(L, f).argtypes = [H]
     L.n1k_column_path.restype = C.c_char_p

@@ -204,6 +204,27 @@ N1K_DEV Num num_idiv_imod(Num a, Num b, bool mod) {
     return num_int(mod ? x % d : x / d);
 }
 
+// math.Pow(10, n) for the digit counts ROUND / TRUNC see: exact powers of ten up to 1e22, their correctly rounded
+// reciprocals for negative n (Go's Pow inverts the positive power), the library pow beyond
+N1K_DEV double pow10_go(int n) {
+    const int a = n < 0 ? -n : n;
+    if (a > 22) return pow(10.0, (double)n);
+    double p = 1.0;
+    for (int i = 0; i < a; i++) p *= 10.0;
+    return n < 0 ? 1.0 / p : p;
+}
+// roundFloat (expression/func_num.go:1715-1736): half away from zero, except that an exact .5 goes to the even neighbour
+N1K_DEV double round_float(double x, int prec) {
+    if (x != x || x == __longlong_as_double(0x7FF0000000000000ll) || x == __longlong_as_double((long long)0xFFF0000000000000ull)) return x;
+    double sign = 1.0;
+    if (x < 0) { sign = -1.0; x = -x; }
+    const double pw = pow10_go(prec);
+    const double intermed = x * pw + 0.5;
+    double rounder = floor(intermed);
+    if (rounder == intermed && fmod(rounder, 2.0) != 0.0) rounder -= 1.0;
+    return sign * rounder / pw;
+}
+
 N1K_DEV uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
     x *= 0xff51afd7ed558ccdull;

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -103,6 +104,12 @@ struct n1k_handle {
     DevBuf<uint32_t> d_cand;
     DevBuf<char> d_topk, d_out2;
     uint64_t opt_topk_min_groups = 65536;  // device top-k filter from this many groups on
+    // InitialProject over the final groups: an inner operator that only carries the derived columns of the terms'
+    // expressions (its input columns are group keys / aggregates, like HAVING's)
+    n1k_handle* project = nullptr;
+    std::vector<int> project_cols;        // per inner column: key index k (>= 0) or -(aggregate index) - 1
+    std::vector<Operand> project_ops;     // one per result term, in the inner operator's column space
+    std::vector<n1k_value> r_proj;        // [ngroups][nterms]
     // HAVING: an inner Filter-only operator over the final groups (its columns are group keys / aggregates)
     n1k_handle* having = nullptr;
     std::vector<int> having_cols;        // per inner column: key index k (>= 0) or -(aggregate index) - 1
@@ -136,7 +143,7 @@ struct n1k_handle {
     bool layout_fixed = false;
     uint32_t col_kinds[kMaxCols]{};
     std::vector<std::string> agg_names;
-    bool has_distinct = false, has_minmax = false;
+    bool has_distinct = false, has_minmax = false, has_array_agg = false;
     uint32_t n_distinct = 0;
     // arithmetic operands -> derived columns (input columns first, then one per arithmetic node)
     struct Derived { uint32_t op, nops; Operand ops[4]; };
@@ -259,8 +266,30 @@ bool to_operand(n1k_handle* h, const Expr* e, Operand& o, PlanError& err) {
         }
         return true;
     }
-    // arithmetic node -> derived column evaluated once per batch (expression/arith_*.go)
+    // arithmetic node -> derived column evaluated once per batch (expression/arith_*.go, func_num.go)
     uint32_t op;
+    if (e->kind == EK::Func) {
+        const std::string& f = e->fname;
+        op = f == "round" ? AR_ROUND : f == "trunc" ? AR_TRUNC : f == "abs" ? AR_ABS : f == "ceil" ? AR_CEIL
+             : f == "floor" ? AR_FLOOR : f == "sign" ? AR_SIGN : AR_SQRT;
+        n1k_handle::Derived d{};
+        d.op = op;
+        for (auto& c : e->ch) {
+            Operand x;
+            if (!to_operand(h, c.get(), x, err)) return false;
+            d.ops[d.nops++] = x;
+        }
+        if (h->plan.paths.size() + h->derived.size() >= (size_t)kMaxCols) {
+            err.unsupported = true;
+            err.msg = "too many columns (inputs + arithmetic nodes > 16)";
+            return false;
+        }
+        memset(&o, 0, sizeof o);
+        o.is_const = 0;
+        o.col = (uint32_t)(h->plan.paths.size() + h->derived.size());
+        h->derived.push_back(d);
+        return true;
+    }
     switch (e->kind) {
         case EK::Add: op = AR_ADD; break;
         case EK::Mult: op = AR_MULT; break;
@@ -410,7 +439,10 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
         h->agg_names.push_back(d.text);
         s.lds_off = lds_w;
         s.glob_off = glob_w;
-        if (d.distinct) {
+        if (d.kind == AGG_ARRAY && !d.operand) { err.msg = "array_agg needs an operand"; return false; }
+        if (d.kind == AGG_ARRAY) h->has_array_agg = true;
+        if (d.distinct || d.kind == AGG_ARRAY) {  // (ARRAY_AGG logs its operands the way the DISTINCT aggregates do)
+            s.distinct = 1;
             if (h->n_distinct >= kMaxDistinct) {
                 err.unsupported = true;
                 err.msg = "more than 4 DISTINCT aggregates";
@@ -418,8 +450,8 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
             }
             h->has_distinct = true;
             s.log_index = h->n_distinct++;
-            s.lds_n = kLdsWordsDistinct;
-            lds_w += kLdsWordsDistinct;
+            s.lds_n = d.kind == AGG_ARRAY ? 0 : kLdsWordsDistinct;
+            lds_w += s.lds_n;
             glob_w += (d.kind == AGG_SUM || d.kind == AGG_AVG) ? kGlobWordsDistinctSum : kGlobWordsDistinct;
         } else if (d.kind == AGG_COUNT || d.kind == AGG_COUNTN) {
             lds_w += 1;
@@ -440,6 +472,10 @@ bool compile_plan(n1k_handle* h, PlanError& err) {
     }
     P.lds_words = lds_w;
     P.glob_words = glob_w ? glob_w : 1;
+    if (h->has_array_agg) {
+        if (h->opt_rep_row) { err.unsupported = true; err.msg = "array_agg with representative rows"; return false; }
+        P.emit_packed_key = 1;
+    }
     P.ncols = (uint32_t)(pl.paths.size() + h->derived.size());  // inputs, then derived columns
     return true;
 }
@@ -1458,6 +1494,38 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     return N1K_OK;
 }
 
+// host columns -> the handle's staging buffers on the device (the caller's memory is not retained after return: cgo rule)
+n1k_status stage_host_batch(n1k_handle* h, const n1k_batch* batch, std::vector<n1k_col>& dcols) {
+    uint32_t nc = batch->ncols;
+    h->st_tags.resize(std::max<size_t>(h->st_tags.size(), nc));
+    h->st_payload.resize(std::max<size_t>(h->st_payload.size(), nc));
+    h->st_codes.resize(std::max<size_t>(h->st_codes.size(), nc));
+    // the previous batch's kernels may still read the staging buffers
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    dcols.assign(nc, n1k_col{});
+    uint64_t n = batch->nrows;
+    for (uint32_t c = 0; c < nc; c++) {
+        const n1k_col& col = batch->cols[c];
+        dcols[c] = col;
+        if (col.kind == N1K_COL_DICT32) {
+            HIP_TRY(h, h->st_codes[c].ensure(n));
+            if (n) HIP_TRY(h, hipMemcpyAsync(h->st_codes[c].p, col.codes, n * 4, hipMemcpyHostToDevice, h->stream));
+            dcols[c].codes = h->st_codes[c].p;
+        } else {
+            HIP_TRY(h, h->st_tags[c].ensure(n));
+            HIP_TRY(h, h->st_payload[c].ensure(n));
+            if (n) {
+                HIP_TRY(h, hipMemcpyAsync(h->st_tags[c].p, col.tags, n, hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(h->st_payload[c].p, col.payload, n * 8, hipMemcpyHostToDevice, h->stream));
+            }
+            dcols[c].tags = h->st_tags[c].p;
+            dcols[c].payload = h->st_payload[c].p;
+        }
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return N1K_OK;
+}
+
 void default_value(const AggDef& d, n1k_value& v, n1k_partial& p) {
     memset(&v, 0, sizeof v);
     memset(&p, 0, sizeof p);
@@ -1471,6 +1539,85 @@ void default_value(const AggDef& d, n1k_value& v, n1k_partial& p) {
 }
 
 }  // namespace
+
+// Every aggregate and key text of the plan inside `expr` (longest first) becomes a synthetic leaf path (`$g`.`aN`) /
+// (`$g`.`kN`): an expression over the final groups then reads columns, like any other (HAVING, projection terms).
+static std::string group_paths(const n1k_handle* h, std::string expr) {
+    std::vector<std::pair<std::string, std::string>> subst;
+    for (size_t a = 0; a < h->plan.aggs.size(); a++) subst.emplace_back(h->plan.aggs[a].text, "(`$g`.`a" + std::to_string(a) + "`)");
+    for (size_t k = 0; k < h->plan.key_texts.size(); k++) subst.emplace_back(h->plan.key_texts[k], "(`$g`.`k" + std::to_string(k) + "`)");
+    std::stable_sort(subst.begin(), subst.end(), [](const auto& x, const auto& y) { return x.first.size() > y.first.size(); });
+    for (auto& sb : subst) {
+        if (sb.first.empty()) continue;
+        for (size_t pos = 0; (pos = expr.find(sb.first, pos)) != std::string::npos; pos += sb.second.size())
+            expr.replace(pos, sb.first.size(), sb.second);
+    }
+    return expr;
+}
+
+// (`$g`.`kN`) / (`$g`.`aN`) -> N (keys) or -N - 1 (aggregates); false for any other path
+static bool group_path_index(const n1k_handle* h, const std::string& p, int& out) {
+    int idx = -1;
+    char kind = 0;
+    if (sscanf(p.c_str(), "(`$g`.`%c%d`)", &kind, &idx) != 2 || (kind != 'k' && kind != 'a') || idx < 0 ||
+        (size_t)idx >= (kind == 'k' ? h->plan.key_texts.size() : h->plan.aggs.size()))
+        return false;
+    out = kind == 'k' ? idx : -idx - 1;
+    return true;
+}
+
+// InitialProject over the final groups (execution/project_initial.go:52-144): every result term's expression is
+// compiled over the groups' keys and aggregates; arithmetic and numeric functions become derived columns of an inner
+// operator and are evaluated on the device by the same element-wise kernel as the arithmetic of WHERE / GROUP BY.
+static n1k_status build_projection(n1k_handle* h) {
+    auto* f = new n1k_handle();
+    h->project = f;
+    std::vector<std::unique_ptr<Expr>> trees;
+    PlanError err;
+    for (const ProjectTerm& t : h->plan.project) {
+        auto e = parse_expression(group_paths(h, t.text), err);
+        if (!e) {
+            g_create_error = "projection: " + err.msg;
+            return err.unsupported ? N1K_UNSUPPORTED : N1K_INVALID;
+        }
+        std::vector<std::string> paths;
+        std::function<void(const Expr*)> walk = [&](const Expr* x) {
+            if (x->kind == EK::Path) {
+                if (std::find(f->plan.paths.begin(), f->plan.paths.end(), x->text) == f->plan.paths.end()) f->plan.paths.push_back(x->text);
+                return;
+            }
+            for (auto& c : x->ch) walk(c.get());
+        };
+        walk(e.get());
+        trees.push_back(std::move(e));
+    }
+    for (const std::string& p : f->plan.paths) {
+        int idx;
+        if (!group_path_index(h, p, idx)) {
+            g_create_error = "a projection term refers to " + p + ", which is neither a group key nor an aggregate of the plan";
+            return N1K_UNSUPPORTED;
+        }
+        h->project_cols.push_back(idx);
+    }
+    if (f->plan.paths.size() > (size_t)kMaxCols) {
+        g_create_error = "projection over more than 16 keys / aggregates";
+        return N1K_UNSUPPORTED;
+    }
+    for (auto& e : trees) {
+        Operand o;
+        if (!to_operand(f, e.get(), o, err)) {
+            g_create_error = "projection: " + err.msg;
+            return err.unsupported ? N1K_UNSUPPORTED : N1K_INVALID;
+        }
+        if (o.is_const && o.ctag == T_STRING) {
+            g_create_error = "a string constant as a projection term does not run on the device";
+            return N1K_UNSUPPORTED;
+        }
+        h->project_ops.push_back(o);
+    }
+    f->prog.ncols = (uint32_t)(f->plan.paths.size() + f->derived.size());
+    return N1K_OK;
+}
 
 // ================================================================== C ABI
 
@@ -1564,6 +1711,15 @@ n1k_status n1k_create(const char* plan_json, size_t len, n1k_handle** out) {
             h->having_cols.push_back(kind == 'k' ? idx : -idx - 1);
         }
     }
+    if (h->plan.has_project) {
+        n1k_status pst = build_projection(h);
+        if (pst != N1K_OK) {
+            if (h->having) n1k_destroy(h->having);
+            h->having = nullptr;
+            delete h;
+            return pst;
+        }
+    }
     g_create_error.clear();
     *out = h;
     return N1K_OK;
@@ -1581,6 +1737,8 @@ void n1k_destroy(n1k_handle* h) {
 static void destroy_handle(n1k_handle* h) {
     if (h->having) n1k_destroy(h->having);
     h->having = nullptr;
+    if (h->project) n1k_destroy(h->project);
+    h->project = nullptr;
     if (h->device_ready) {
         (void)hipSetDevice(h->device);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -1696,6 +1854,14 @@ uint32_t n1k_num_keys(const n1k_handle* h) { return h ? (uint32_t)h->plan.keys.s
 uint32_t n1k_num_aggregates(const n1k_handle* h) { return h ? (uint32_t)h->plan.aggs.size() : 0; }
 const char* n1k_aggregate_name(const n1k_handle* h, uint32_t i) {
     return (h && i < h->agg_names.size()) ? h->agg_names[i].c_str() : nullptr;
+}
+
+uint32_t n1k_num_projection_terms(const n1k_handle* h) { return h ? (uint32_t)h->plan.project.size() : 0; }
+const char* n1k_projection_expr(const n1k_handle* h, uint32_t i) {
+    return (h && i < h->plan.project.size()) ? h->plan.project[i].text.c_str() : nullptr;
+}
+const char* n1k_projection_alias(const n1k_handle* h, uint32_t i) {
+    return (h && i < h->plan.project.size()) ? h->plan.project[i].as.c_str() : nullptr;
 }
 
 n1k_status n1k_dict_intern(n1k_handle* h, uint32_t n, const uint64_t* offsets, const char* bytes, uint32_t* out_codes) {
@@ -1896,34 +2062,9 @@ n1k_status n1k_push_batch(n1k_handle* h, const n1k_batch* batch) {
     if (st != N1K_OK) return st;
     st = validate_batch(h, batch);
     if (st != N1K_OK) return st;
-    uint32_t nc = batch->ncols;
-    h->st_tags.resize(std::max<size_t>(h->st_tags.size(), nc));
-    h->st_payload.resize(std::max<size_t>(h->st_payload.size(), nc));
-    h->st_codes.resize(std::max<size_t>(h->st_codes.size(), nc));
-    // the previous batch's kernels may still read the staging buffers
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::vector<n1k_col> dcols(nc);
-    uint64_t n = batch->nrows;
-    for (uint32_t c = 0; c < nc; c++) {
-        const n1k_col& col = batch->cols[c];
-        dcols[c] = col;
-        if (col.kind == N1K_COL_DICT32) {
-            HIP_TRY(h, h->st_codes[c].ensure(n));
-            if (n) HIP_TRY(h, hipMemcpyAsync(h->st_codes[c].p, col.codes, n * 4, hipMemcpyHostToDevice, h->stream));
-            dcols[c].codes = h->st_codes[c].p;
-        } else {
-            HIP_TRY(h, h->st_tags[c].ensure(n));
-            HIP_TRY(h, h->st_payload[c].ensure(n));
-            if (n) {
-                HIP_TRY(h, hipMemcpyAsync(h->st_tags[c].p, col.tags, n, hipMemcpyHostToDevice, h->stream));
-                HIP_TRY(h, hipMemcpyAsync(h->st_payload[c].p, col.payload, n * 8, hipMemcpyHostToDevice, h->stream));
-            }
-            dcols[c].tags = h->st_tags[c].p;
-            dcols[c].payload = h->st_payload[c].p;
-        }
-    }
-    // cgo rule: caller memory is not retained after return
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<n1k_col> dcols;
+    st = stage_host_batch(h, batch, dcols);
+    if (st != N1K_OK) return st;
     n1k_batch db = *batch;
     db.cols = dcols.data();
     return push_device(h, &db);
@@ -2190,9 +2331,15 @@ static int host_collate(const n1k_handle* h, const n1k_value& a, const n1k_value
             return x.size() < y.size() ? -1 : (x.size() > y.size() ? 1 : 0);
         }
         case 5:
-        case 6:
-            if (a.v.code != b.v.code) *unsupported = true;
-            return 0;
+        case 6: {
+            // arrays element by element, objects by size and sorted names (value/array.go, value/object.go:511-556): on
+            // the host, over the canonical texts the dictionary holds
+            if (a.v.code == b.v.code) return 0;
+            int c = 0;
+            if (a.v.code >= h->dict.size() || b.v.code >= h->dict.size() || !json_text_collate(h->dict[a.v.code], h->dict[b.v.code], c))
+                *unsupported = true;
+            return c;
+        }
         default: return 0;
     }
 }
@@ -2258,20 +2405,92 @@ static n1k_status having_groups(n1k_handle* h, uint64_t& ng) {
     return N1K_OK;
 }
 
+// InitialProject over the final groups (execution/project_initial.go:100-144): the value of every result term per
+// group.  Terms that are a key, an aggregate or a constant are copied; the others were compiled into derived columns of
+// the inner operator and are evaluated on the device over the groups as one column batch.
+static n1k_status project_groups(n1k_handle* h, uint64_t ng) {
+    n1k_handle* f = h->project;
+    const size_t nk = h->plan.keys.size(), na = h->plan.aggs.size(), nc = h->project_cols.size(), nt = h->project_ops.size();
+    h->r_proj.assign((size_t)ng * nt, n1k_value{});
+    if (ng == 0 || nt == 0) return N1K_OK;
+    auto source = [&](size_t c, uint64_t g) -> const n1k_value& {
+        const int src = h->project_cols[c];
+        return src >= 0 ? h->r_keys[g * nk + (size_t)src] : h->r_aggs[g * na + (size_t)(-src - 1)];
+    };
+    std::vector<std::vector<uint8_t>> dt(f->derived.size());
+    std::vector<std::vector<uint64_t>> dp(f->derived.size());
+    if (!f->derived.empty()) {
+        std::vector<std::vector<uint8_t>> tags(nc, std::vector<uint8_t>((size_t)ng));
+        std::vector<std::vector<uint64_t>> pay(nc, std::vector<uint64_t>((size_t)ng));
+        for (size_t c = 0; c < nc; c++)
+            for (uint64_t g = 0; g < ng; g++) {
+                const n1k_value& v = source(c, g);
+                tags[c][g] = v.tag;
+                pay[c][g] = v.v.code;  // (strings keep this operator's codes: arithmetic over a non-number is NULL anyway)
+            }
+        std::vector<n1k_col> cols(nc ? nc : 1);
+        for (size_t c = 0; c < nc; c++) {
+            cols[c].kind = N1K_COL_TAGGED64;
+            cols[c].tags = tags[c].data();
+            cols[c].payload = pay[c].data();
+        }
+        n1k_batch b{};
+        b.nrows = ng;
+        b.ncols = (uint32_t)nc;
+        b.cols = cols.data();
+        if (f->device < 0 && !f->device_ready) f->device = h->device;
+        n1k_status st = ensure_device(f);
+        if (st == N1K_OK) st = validate_batch(f, &b);
+        std::vector<n1k_col> dcols;
+        if (st == N1K_OK) st = stage_host_batch(f, &b, dcols);
+        if (st == N1K_OK) {
+            n1k_batch db = b;
+            db.cols = dcols.data();
+            st = bind_columns(f, &db);  // launches the element-wise kernel of every derived column
+        }
+        if (st != N1K_OK) return fail(h, st, "projection: %s", n1k_last_error(f));
+        for (size_t d = 0; d < f->derived.size(); d++) {
+            dt[d].resize((size_t)ng);
+            dp[d].resize((size_t)ng);
+            HIP_TRY(h, hipMemcpyAsync(dt[d].data(), f->dv_tags[d].p, (size_t)ng, hipMemcpyDeviceToHost, f->stream));
+            HIP_TRY(h, hipMemcpyAsync(dp[d].data(), f->dv_payload[d].p, (size_t)ng * 8, hipMemcpyDeviceToHost, f->stream));
+        }
+        HIP_TRY(h, hipStreamSynchronize(f->stream));
+    }
+    for (size_t t = 0; t < nt; t++) {
+        const Operand& o = h->project_ops[t];
+        for (uint64_t g = 0; g < ng; g++) {
+            n1k_value& v = h->r_proj[g * nt + t];
+            if (o.is_const) {
+                v.tag = (uint8_t)o.ctag;
+                v.v.code = o.cpayload;
+            } else if (o.col < nc) {
+                v = source(o.col, g);
+            } else {
+                v.tag = dt[o.col - nc][g];
+                v.v.code = dp[o.col - nc][g];
+            }
+        }
+    }
+    return N1K_OK;
+}
+
 // Order / Offset / Limit over the final groups (execution/order.go:121-169: term by term Collate, DESC flips it;
 // order_limit.go keeps offset + limit rows; offset.go / limit.go then cut).  sort.Sort is not stable, so the order
 // among rows that tie on every term is unspecified in the reference too; here ties keep table order.
 static n1k_status order_groups(n1k_handle* h, uint64_t& ng) {
     const ParsedPlan& pl = h->plan;
-    const size_t nk = pl.keys.size(), na = pl.aggs.size();
+    const size_t nk = pl.keys.size(), na = pl.aggs.size(), np = h->r_proj.empty() ? 0 : h->project_ops.size();
     std::vector<uint32_t> perm((size_t)ng);
     for (size_t i = 0; i < perm.size(); i++) perm[i] = (uint32_t)i;
     bool unsupported = false;
     if (pl.has_order) {
         auto less = [&](uint32_t x, uint32_t y) {
             for (const OrderTerm& t : pl.order) {
-                const n1k_value& a = t.key_index >= 0 ? h->r_keys[x * nk + t.key_index] : h->r_aggs[x * na + t.agg_index];
-                const n1k_value& b = t.key_index >= 0 ? h->r_keys[y * nk + t.key_index] : h->r_aggs[y * na + t.agg_index];
+                const n1k_value& a = t.proj_index >= 0 ? h->r_proj[x * np + t.proj_index]
+                                     : t.key_index >= 0 ? h->r_keys[x * nk + t.key_index] : h->r_aggs[x * na + t.agg_index];
+                const n1k_value& b = t.proj_index >= 0 ? h->r_proj[y * np + t.proj_index]
+                                     : t.key_index >= 0 ? h->r_keys[y * nk + t.key_index] : h->r_aggs[y * na + t.agg_index];
                 const int c = host_collate(h, a, b, &unsupported);
                 if (c) return t.desc ? c > 0 : c < 0;
             }
@@ -2289,8 +2508,10 @@ static n1k_status order_groups(n1k_handle* h, uint64_t& ng) {
     std::vector<n1k_value> keys((last - first) * nk), aggs((last - first) * na);
     std::vector<n1k_partial> parts((last - first) * na);
     std::vector<uint64_t> rep(last - first);
+    std::vector<n1k_value> proj((last - first) * np);
     for (uint64_t i = first; i < last; i++) {
         const uint32_t g = perm[i];
+        for (size_t t = 0; t < np; t++) proj[(i - first) * np + t] = h->r_proj[g * np + t];
         for (size_t k = 0; k < nk; k++) keys[(i - first) * nk + k] = h->r_keys[g * nk + k];
         for (size_t a = 0; a < na; a++) {
             aggs[(i - first) * na + a] = h->r_aggs[g * na + a];
@@ -2302,7 +2523,74 @@ static n1k_status order_groups(n1k_handle* h, uint64_t& ng) {
     h->r_aggs.swap(aggs);
     h->r_parts.swap(parts);
     h->r_rep.swap(rep);
+    if (np) h->r_proj.swap(proj);
     ng = last - first;
+    return N1K_OK;
+}
+
+// ARRAY_AGG / ARRAY_AGG(DISTINCT) (algebra/agg_array.go:86-145, agg_array_distinct.go:86-127): the scan logged every
+// operand that is not MISSING with its group's packed key; FinalGroup wrote each group's packed key into the
+// representative-row slot.  Here the operands are handed to their groups, sorted by value.Collate (ComputeFinal sorts
+// with value.NewSorter), de-duplicated for DISTINCT (value.Set: integral floats join the ints), and the array's
+// canonical JSON text becomes a dictionary entry: the aggregate's value is an ARRAY like any other on this path.
+static n1k_status array_agg_groups(n1k_handle* h, uint64_t ng, const unsigned long long* counters) {
+    const size_t na = h->plan.aggs.size();
+    std::unordered_map<uint64_t, uint64_t> group_of;
+    group_of.reserve((size_t)ng * 2);
+    for (uint64_t g = 0; g < ng; g++) group_of.emplace(h->r_rep[g], g);
+    for (size_t a = 0; a < na; a++) {
+        const AggSpec& ag = h->prog.aggs[a];
+        if (ag.kind != AGG_ARRAY) continue;
+        const uint64_t n = std::min<uint64_t>(counters[8 + ag.log_index], h->log_capacity);
+        std::vector<uint64_t> keys((size_t)n), vals((size_t)n);
+        std::vector<uint8_t> tags((size_t)n);
+        if (n) {
+            HIP_TRY(h, hipMemcpyAsync(keys.data(), h->d_log_key[ag.log_index].p, n * 8, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(vals.data(), h->d_log_val[ag.log_index].p, n * 8, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(tags.data(), h->d_log_cls[ag.log_index].p, n, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+        std::vector<std::vector<n1k_value>> members((size_t)ng);
+        for (uint64_t i = 0; i < n; i++) {
+            auto it = group_of.find(keys[i]);
+            if (it == group_of.end()) continue;  // (a group the top-k filter left on the device)
+            n1k_value v{};
+            v.tag = tags[i];
+            v.v.code = vals[i];
+            members[(size_t)it->second].push_back(v);
+        }
+        bool unsupported = false;
+        std::string text;
+        for (uint64_t g = 0; g < ng; g++) {
+            auto& m = members[(size_t)g];
+            n1k_value& out = h->r_aggs[g * na + a];
+            memset(&out, 0, sizeof out);
+            out.tag = N1K_T_NULL;  // Default(): NULL (agg_array.go:77); an empty DISTINCT set is NULL too
+            if (m.empty()) continue;
+            std::stable_sort(m.begin(), m.end(), [&](const n1k_value& x, const n1k_value& y) { return host_collate(h, x, y, &unsupported) < 0; });
+            if (h->plan.aggs[a].distinct)
+                m.erase(std::unique(m.begin(), m.end(), [&](const n1k_value& x, const n1k_value& y) { return host_collate(h, x, y, &unsupported) == 0; }),
+                        m.end());
+            text.assign("[");
+            for (size_t i = 0; i < m.size(); i++) {
+                if (i) text.push_back(',');
+                switch (m[i].tag) {
+                    case N1K_T_NULL: text += "null"; break;
+                    case N1K_T_FALSE: text += "false"; break;
+                    case N1K_T_TRUE: text += "true"; break;
+                    case N1K_T_INT: text += std::to_string((long long)m[i].v.i); break;
+                    case N1K_T_FLOAT: format_float(m[i].v.f, text); break;
+                    case N1K_T_STRING: json_quote(h->dict[(size_t)m[i].v.code], text); break;
+                    default: text += h->dict[(size_t)m[i].v.code]; break;  // arrays / objects: their canonical text
+                }
+            }
+            text.push_back(']');
+            out.tag = N1K_T_ARRAY;
+            out.v.code = intern(h, text);
+        }
+        if (unsupported) return fail(h, N1K_UNSUPPORTED_DATA, "array_agg over values whose collation is outside the subset");
+    }
+    for (uint64_t g = 0; g < ng; g++) h->r_rep[g] = ~0ull;  // (the slot carried the packed keys)
     return N1K_OK;
 }
 
@@ -2389,7 +2677,7 @@ redo_sets:
         if (h->wregion_used) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 20, 0, 8, h->stream));
         for (uint32_t a = 0; a < na; a++) {
             const AggSpec& ag = h->prog.aggs[a];
-            if (!ag.distinct) continue;
+            if (!ag.distinct || ag.kind == AGG_ARRAY) continue;  // (ARRAY_AGG: after FinalGroup, array_agg_groups)
             const uint64_t npairs = std::min<uint64_t>(counters[8 + ag.log_index], h->log_capacity);
             const uint64_t nwords = h->distinct_words[ag.log_index] ? std::min<uint64_t>(counters[16 + ag.log_index], h->log_capacity) : 0;
             DistinctArgs D{};
@@ -2450,7 +2738,8 @@ redo_sets:
             const uint64_t keep = pl.limit >= 0 ? (uint64_t)pl.offset + (uint64_t)pl.limit : ng;
             size_t copy_bytes = total;
             const char* src = d;
-            if (pl.has_order && pl.limit >= 0 && !pl.has_having && keep > 0 && keep < ng && ng >= h->opt_topk_min_groups && ng < (1ull << 32)) {
+            if (pl.has_order && pl.limit >= 0 && !pl.has_having && pl.order[0].proj_index < 0 && keep > 0 && keep < ng &&
+                ng >= h->opt_topk_min_groups && ng < (1ull << 32)) {
                 // ORDER BY ... LIMIT: only the groups that can be among the first offset+limit rows leave the device
                 const OrderTerm& t0 = pl.order[0];
                 HIP_TRY(h, h->d_images.ensure(ng));
@@ -2510,6 +2799,10 @@ redo_sets:
             p.distinct = parts[i].distinct;
         }
     }
+    if (ng > 0 && h->has_array_agg && !(err_flags & ERR_TABLE_FULL)) {
+        n1k_status ast = array_agg_groups(h, ng, counters);
+        if (ast != N1K_OK) return ast;
+    }
     if (err_flags & ERR_TABLE_FULL)
         return fail(h, N1K_OOM, "group table capacity exceeded: raise the max_groups option (now %llu)",
                     (unsigned long long)h->opt_max_groups);
@@ -2536,10 +2829,17 @@ redo_sets:
         n1k_status st = having_groups(h, ng);
         if (st != N1K_OK) return st;
     }
+    h->r_proj.clear();
+    if (pl.has_project) {
+        n1k_status st = project_groups(h, ng);
+        if (st != N1K_OK) return st;
+    }
     if (pl.has_order || pl.limit >= 0 || pl.offset > 0) {
         n1k_status st = order_groups(h, ng);
         if (st != N1K_OK) return st;
     }
+    out->nproj = pl.has_project ? (uint32_t)h->project_ops.size() : 0;
+    out->proj = out->nproj ? h->r_proj.data() : nullptr;
     out->ngroups = ng;
     out->keys = h->r_keys.data();
     out->aggs = h->r_aggs.data();
@@ -2566,9 +2866,14 @@ n1k_status n1k_order_rows(n1k_handle* h, uint64_t ngroups, const n1k_value* keys
     h->r_aggs.assign(aggs, aggs + ngroups * na);
     h->r_parts.clear();
     h->r_rep.assign((size_t)ngroups, ~0ull);
+    h->r_proj.clear();
     uint64_t ng = ngroups;
-    n1k_status st = order_groups(h, ng);
+    n1k_status st = h->plan.has_project ? project_groups(h, ng) : N1K_OK;  // (sort terms may name projection aliases)
     if (st != N1K_OK) return st;
+    st = order_groups(h, ng);
+    if (st != N1K_OK) return st;
+    out->nproj = h->plan.has_project ? (uint32_t)h->project_ops.size() : 0;
+    out->proj = out->nproj ? h->r_proj.data() : nullptr;
     out->ngroups = ng;
     out->keys = h->r_keys.data();
     out->aggs = h->r_aggs.data();

@@ -15,7 +15,7 @@ namespace n1k {
 
 bool parse_leaf_path(const std::string& text, JsonPath& out) {
     out.names.clear();
-    std::vector<std::string> parts;
+    std::vector<JsonStep> parts;
     size_t i = 0;
     const size_t n = text.size();
     while (i < n) {
@@ -24,15 +24,27 @@ bool parse_leaf_path(const std::string& text, JsonPath& out) {
             i++;
             continue;
         }
+        JsonStep st;
+        if (c == '[') {  // [-?digits]
+            size_t j = i + 1;
+            if (j < n && text[j] == '-') j++;
+            const size_t d0 = j;
+            while (j < n && text[j] >= '0' && text[j] <= '9') j++;
+            if (j == d0 || j - d0 > 18 || j >= n || text[j] != ']' || parts.empty()) return false;
+            st.is_index = true;
+            st.index = strtoll(text.c_str() + i + 1, nullptr, 10);
+            i = j + 1;
+            parts.push_back(st);
+            continue;
+        }
         if (c != '`') return false;
-        std::string name;
         i++;
-        while (i < n && text[i] != '`') name.push_back(text[i++]);
+        while (i < n && text[i] != '`') st.name.push_back(text[i++]);
         if (i >= n) return false;
         i++;
-        parts.push_back(name);
+        parts.push_back(st);
     }
-    if (parts.size() < 2) return false;  // alias alone names the whole document
+    if (parts.size() < 2 || parts[0].is_index) return false;  // alias alone names the whole document
     out.names.assign(parts.begin() + 1, parts.end());
     return true;
 }
@@ -241,6 +253,8 @@ void type_number(const char* b, const char* e, uint8_t& tag, uint64_t& payload) 
     memcpy(&payload, &d, 8);
 }
 
+}  // namespace
+
 // strconv.FormatFloat(f, 'f', -1, 64) (value/float.go:31-48): shortest digits that round-trip, positional notation
 void format_float(double f, std::string& o) {
     if (f != f) { o += "\"NaN\""; return; }
@@ -275,7 +289,7 @@ void format_float(double f, std::string& o) {
     }
 }
 
-void quote(const std::string& s, std::string& o) {
+void json_quote(const std::string& s, std::string& o) {
     o.push_back('"');
     for (unsigned char c : s) {
         switch (c) {
@@ -297,6 +311,9 @@ void quote(const std::string& s, std::string& o) {
     }
     o.push_back('"');
 }
+
+namespace {
+void quote(const std::string& s, std::string& o) { json_quote(s, o); }
 
 // canonical text of the value at sc.p, appended to o
 bool canon(Scanner& sc, std::string& o, int depth) {
@@ -421,7 +438,80 @@ bool decode(Scanner& sc, Interner& in, std::string& tmp, uint8_t& tag, uint64_t&
     }
 }
 
-// One object level: sc.p just after '{'.  `want` lists (path index, depth) pairs whose next name is looked up here;
+bool object_level(Scanner& sc, const std::vector<JsonPath>& paths, std::vector<uint32_t>& want, uint32_t depth, Interner& in,
+                  std::string& tmp, std::string& name, uint8_t* tags, uint64_t* pay);
+
+// sc.p at the start of a value that the paths in `hit` reach after `depth` steps: the paths that end here take the
+// value; the others go on — through its fields when it is an object, through its elements when it is an array
+// (a field of a non-object and an element of a non-array are MISSING: value/parsed.go:159-163, :236-243).
+bool value_level(Scanner& sc, const std::vector<JsonPath>& paths, const std::vector<uint32_t>& hit, uint32_t depth, Interner& in,
+                 std::string& tmp, uint8_t* tags, uint64_t* pay) {
+    std::vector<uint32_t> by_name, by_index;
+    bool leaf = false;
+    for (uint32_t h : hit) {
+        if (paths[h].names.size() == depth) leaf = true;
+        else if (paths[h].names[depth].is_index) by_index.push_back(h);
+        else by_name.push_back(h);
+    }
+    sc.ws();
+    const char* start = sc.p;
+    const char* after = nullptr;
+    if (leaf) {
+        uint8_t t;
+        uint64_t v;
+        if (!decode(sc, in, tmp, t, v)) return false;
+        for (uint32_t h : hit)
+            if (paths[h].names.size() == depth) { tags[h] = t; pay[h] = v; }
+        after = sc.p;
+        if (by_name.empty() && by_index.empty()) return true;
+        sc.p = start;
+    }
+    if (sc.p < sc.end && *sc.p == '{' && !by_name.empty()) {
+        sc.p++;
+        std::string nm;
+        if (!object_level(sc, paths, by_name, depth, in, tmp, nm, tags, pay)) return false;
+    } else if (sc.p < sc.end && *sc.p == '[' && !by_index.empty()) {
+        // element starts, then the wanted elements (a negative index needs the length)
+        sc.p++;
+        std::vector<const char*> starts;
+        sc.ws();
+        if (sc.p < sc.end && *sc.p == ']') sc.p++;
+        else
+            for (;;) {
+                sc.ws();
+                starts.push_back(sc.p);
+                if (!sc.skip()) return false;
+                sc.ws();
+                if (sc.p < sc.end && *sc.p == ',') { sc.p++; continue; }
+                if (sc.p < sc.end && *sc.p == ']') { sc.p++; break; }
+                return sc.fail("',' or ']' expected");
+            }
+        const char* end_of_array = sc.p;
+        std::vector<uint32_t> same;
+        while (!by_index.empty()) {
+            const long long want_ix = paths[by_index[0]].names[depth].index;
+            same.clear();
+            for (size_t i = 0; i < by_index.size();) {
+                if (paths[by_index[i]].names[depth].index == want_ix) {
+                    same.push_back(by_index[i]);
+                    by_index[i] = by_index.back();
+                    by_index.pop_back();
+                } else
+                    i++;
+            }
+            long long ix = want_ix < 0 ? want_ix + (long long)starts.size() : want_ix;
+            if (ix < 0 || ix >= (long long)starts.size()) continue;  // MISSING (value/array.go:204-214)
+            sc.p = starts[(size_t)ix];
+            if (!value_level(sc, paths, same, depth + 1, in, tmp, tags, pay)) return false;
+        }
+        sc.p = end_of_array;
+    } else if (!leaf && !sc.skip())
+        return false;
+    if (after) sc.p = after;
+    return true;
+}
+
+// One object level: sc.p just after '{'.  `want` lists the paths whose step `depth` is a field name looked up here;
 // the FIRST field of that name counts (go_json.FirstFind, value/parsed.go:189-193).
 bool object_level(Scanner& sc, const std::vector<JsonPath>& paths, std::vector<uint32_t>& want, uint32_t depth, Interner& in,
                   std::string& tmp, std::string& name, uint8_t* tags, uint64_t* pay) {
@@ -437,7 +527,7 @@ bool object_level(Scanner& sc, const std::vector<JsonPath>& paths, std::vector<u
         // which wanted paths continue through this field?
         std::vector<uint32_t> hit;
         for (size_t i = 0; i < want.size();) {
-            if (paths[want[i]].names[depth] == name) {
+            if (paths[want[i]].names[depth].name == name) {
                 hit.push_back(want[i]);
                 want[i] = want.back();
                 want.pop_back();
@@ -446,34 +536,8 @@ bool object_level(Scanner& sc, const std::vector<JsonPath>& paths, std::vector<u
         }
         if (hit.empty()) {
             if (!sc.skip()) return false;
-        } else {
-            std::vector<uint32_t> deeper;
-            bool leaf = false;
-            for (uint32_t h : hit) {
-                if (paths[h].names.size() == depth + 1) leaf = true;
-                else deeper.push_back(h);
-            }
-            sc.ws();
-            const char* start = sc.p;
-            if (leaf) {
-                uint8_t t;
-                uint64_t v;
-                if (!decode(sc, in, tmp, t, v)) return false;
-                for (uint32_t h : hit)
-                    if (paths[h].names.size() == depth + 1) { tags[h] = t; pay[h] = v; }
-            }
-            if (!deeper.empty()) {
-                const char* after = leaf ? sc.p : nullptr;
-                sc.p = start;
-                if (sc.p < sc.end && *sc.p == '{') {
-                    sc.p++;
-                    std::string nm;
-                    if (!object_level(sc, paths, deeper, depth + 1, in, tmp, nm, tags, pay)) return false;
-                } else if (!leaf && !sc.skip())
-                    return false;  // a field of a non-object is MISSING (value/parsed.go:159-163)
-                if (after) sc.p = after;
-            }
-        }
+        } else if (!value_level(sc, paths, hit, depth + 1, in, tmp, tags, pay))
+            return false;
         sc.ws();
         if (sc.p < sc.end && *sc.p == ',') { sc.p++; continue; }
         if (sc.p < sc.end && *sc.p == '}') { sc.p++; return true; }
@@ -498,14 +562,10 @@ long long extract_json_range(const std::vector<JsonPath>& paths, const uint64_t*
     for (uint64_t d = first; d < last; d++) {
         Scanner sc{bytes + offsets[d], bytes + offsets[d + 1], &err};
         for (size_t i = 0; i < np; i++) { t[i] = T_MISSING; v[i] = 0; }
-        sc.ws();
-        if (sc.p < sc.end && *sc.p == '{') {
-            sc.p++;
-            want.clear();
-            for (uint32_t i = 0; i < np; i++) want.push_back(i);
-            if (!object_level(sc, paths, want, 0, in, tmp, name, t.data(), v.data())) return (long long)d;
-        } else if (!sc.skip())
-            return (long long)d;  // a scalar / array document has no fields: every path is MISSING
+        want.clear();
+        for (uint32_t i = 0; i < np; i++) want.push_back(i);
+        // (a scalar document has no fields and no elements: every path is MISSING)
+        if (!value_level(sc, paths, want, 0, in, tmp, t.data(), v.data())) return (long long)d;
         sc.ws();
         if (sc.p != sc.end) {
             err = "trailing bytes after the document";

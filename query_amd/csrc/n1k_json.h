@@ -10,12 +10,17 @@
 
 namespace n1k {
 
+struct JsonStep {
+    std::string name;     // field navigation (expression/nav_field.go:134-160)
+    long long index = 0;  // element navigation with a constant integer index (expression/nav_element.go:49-65; negative
+    bool is_index = false;  // counts from the end, value/array.go:204-214)
+};
 struct JsonPath {
-    std::vector<std::string> names;  // field names below the keyspace alias: (`default`.`a`.`b`) -> {"a", "b"}
+    std::vector<JsonStep> names;  // steps below the keyspace alias: ((`default`.`a`)[1]) -> {a, [1]}
 };
 
-// (`alias`.`f1`...`fn`) / nested parenthesised forms of expression.Stringer -> names; false when the path holds
-// anything but field navigation
+// (`alias`.`f1`...`fn`), ((`alias`.`f`)[i]) / nested parenthesised forms of expression.Stringer -> steps; false when the
+// path holds anything but field names and constant integer indices
 bool parse_leaf_path(const std::string& text, JsonPath& out);
 
 struct JsonColumns {
@@ -27,5 +32,10 @@ struct JsonColumns {
 // Parses documents [first, last) of the batch.  Returns -1 on success, else the index of the first malformed document.
 long long extract_json_range(const std::vector<JsonPath>& paths, const uint64_t* offsets, const char* bytes, uint64_t first,
                              uint64_t last, JsonColumns& out, std::string& err);
+
+// value.MarshalJSON pieces shared with the engine (ARRAY_AGG builds canonical array text): a float as
+// strconv.FormatFloat(f, 'f', -1, 64) prints it (value/float.go:31-48), a string as a JSON string without HTML escaping
+void format_float(double f, std::string& o);
+void json_quote(const std::string& s, std::string& o);
 
 }  // namespace n1k

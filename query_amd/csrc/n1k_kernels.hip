@@ -228,6 +228,39 @@ __global__ void arith_kernel(const ArithArgs A) {
     } else if (A.op == AR_NEG) {
         if (is_num(tg[0])) { Num r = num_neg(Num{tg[0], pv[0]}); rt = r.tag; rp = r.p; }
         else rt = tg[0] == T_MISSING ? (uint32_t)T_MISSING : (uint32_t)T_NULL;
+    } else if (A.op >= AR_ROUND) {
+        // expression/func_num.go: the argument goes through float64 (intValue.Actual() is float64(this),
+        // value/integer.go:57-59) and the result through value.NewValue (integral results fold back to int)
+        if (tg[0] == T_MISSING) rt = T_MISSING;
+        else if (is_num(tg[0])) {
+            const double v = num_actual(tg[0], pv[0]);
+            int prec = 0;
+            bool ok = true;
+            if ((A.op == AR_ROUND || A.op == AR_TRUNC) && A.nops == 2) {  // Round.Apply / Trunc.Apply: the digits argument
+                if (tg[1] == T_MISSING) { rt = T_MISSING; ok = false; }
+                else if (!is_num(tg[1])) ok = false;  // NULL
+                else {
+                    const double pf = num_actual(tg[1], pv[1]);
+                    if (pf != trunc(pf)) ok = false;  // NULL
+                    else prec = pf > 400.0 ? 400 : (pf < -400.0 ? -400 : (int)pf);
+                }
+            }
+            if (ok) {
+                double r;
+                switch (A.op) {
+                    case AR_ROUND: r = round_float(v, prec); break;
+                    case AR_TRUNC: { const double pw = pow10_go(prec); r = trunc(v * pw) / pw; break; }  // truncateFloat
+                    case AR_ABS: r = fabs(v); break;
+                    case AR_CEIL: r = ceil(v); break;
+                    case AR_FLOOR: r = floor(v); break;
+                    case AR_SIGN: r = v < 0.0 ? -1.0 : (v > 0.0 ? 1.0 : 0.0); break;
+                    default: r = sqrt(v); break;
+                }
+                Num n = num_new_value(r);
+                rt = n.tag;
+                rp = n.p;
+            }
+        }
     } else {
         bool both = is_num(tg[0]) && is_num(tg[1]);
         if (tg[0] == T_MISSING || tg[1] == T_MISSING) rt = T_MISSING;
@@ -861,6 +894,15 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
                     cls[j] = 0;
                     val[j] = 0;
                     nar[j] = false;
+                    if (ag.kind == AGG_ARRAY) {
+                        // ArrayAgg.CumulateInitial (algebra/agg_array.go:86-97): every operand but MISSING joins the
+                        // group's array; here it is logged (key, payload, TAG) and the arrays are put together at finish
+                        q[j] = pass[j] && vt[j] != T_MISSING;
+                        cls[j] = vt[j];
+                        val[j] = vp[j];
+                        if (q[j]) mine++;
+                        continue;
+                    }
                     q[j] = pass[j] && distinct_classify(ag.kind, vt[j], vp[j], cls[j], val[j]);
                     if (!q[j]) continue;
                     uint64_t word;
@@ -1653,6 +1695,11 @@ N1K_DEV void finalize_agg(const Program& P, const AggSpec& ag, const uint64_t* g
     const uint64_t* w = g + ag.glob_off;
     OutPartial pt;
     pt.count = 0; pt.isum = 0; pt.fsum = 0.0; pt.flags = 0; pt.ext_tag = T_NULL; pt.ext_payload = 0; pt.distinct = 0;
+    if (ag.kind == AGG_ARRAY) {  // the host builds the array from the logged operands (n1k_finish); NULL when there are none
+        put_value(fin, T_NULL, 0);
+        *part = pt;
+        return;
+    }
     if (ag.distinct) {
         pt.distinct = (int64_t)w[0];
         if (ag.kind == AGG_COUNT || ag.kind == AGG_COUNTN) {
@@ -1806,7 +1853,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const Program P, const Gl
         const uint64_t* g = &G.acc[(size_t)s * P.glob_words];
         for (uint32_t a = 0; a < P.naggs; a++)
             finalize_agg(P, P.aggs[a], g, &out_aggs[idx * P.naggs + a], &out_parts[idx * P.naggs + a], err_flags);
-        if (out_rep) out_rep[idx] = G.rep_row ? G.rep_row[s] : ~0ull;
+        if (out_rep) out_rep[idx] = P.emit_packed_key ? key : (G.rep_row ? G.rep_row[s] : ~0ull);
     }
 }
 

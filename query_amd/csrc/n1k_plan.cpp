@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 
@@ -338,6 +339,45 @@ struct EParser {
                     e->ch.push_back(std::move(b));
                     return e;
                 }
+                if (w == "cover" && lx.toks[p + 1].kind == TK::LParen) {
+                    // cover (expr): the value of a covered expression comes out of the index entry (expression/cover.go); for
+                    // this path it is a leaf like any other — the caller evaluates it per row and hands over the column
+                    const size_t b = t.begin;
+                    p += 2;
+                    auto inner = primary();
+                    if (!inner) return nullptr;
+                    if (cur().kind != TK::RParen) return bad("expected ) after cover");
+                    const size_t e_end = cur().end;
+                    p++;
+                    auto e = mk(EK::Path);
+                    e->text = src.substr(b, e_end - b);
+                    return e;
+                }
+                if (w == "meta" && lx.toks[p + 1].kind == TK::LParen && lx.toks[p + 2].kind == TK::Ident &&
+                    lx.toks[p + 3].kind == TK::RParen) {  // meta(`alias`): the document's meta data, a leaf root (expression/func_meta.go)
+                    auto e = mk(EK::Path);
+                    e->text = src.substr(t.begin, lx.toks[p + 3].end - t.begin);
+                    p += 4;
+                    return e;
+                }
+                if ((w == "round" || w == "trunc" || w == "abs" || w == "ceil" || w == "floor" || w == "sign" || w == "sqrt") &&
+                    lx.toks[p + 1].kind == TK::LParen) {  // expression/func_num.go; stringer: name(arg, arg)
+                    p += 2;
+                    auto e = mk(EK::Func);
+                    e->fname = w;
+                    for (;;) {
+                        auto a = primary();
+                        if (!a) return nullptr;
+                        e->ch.push_back(std::move(a));
+                        if (cur().kind == TK::Comma) { p++; continue; }
+                        break;
+                    }
+                    if (cur().kind != TK::RParen) return bad("expected ) in " + w);
+                    p++;
+                    const size_t maxargs = (w == "round" || w == "trunc") ? 2 : 1;
+                    if (e->ch.empty() || e->ch.size() > maxargs) return bad(w + " takes 1" + (maxargs == 2 ? " or 2" : "") + " arguments");
+                    return e;
+                }
                 return unsupported("function or keyword '" + w + "'");
             }
             case TK::LBrack: return unsupported("array constructor");
@@ -610,9 +650,14 @@ bool plan_node(const JVal& node, ParsedPlan& out, PlanError& err, int depth) {
                 if (out.key_texts[i] == ot.text) ot.key_index = (int)i;
             for (size_t i = 0; i < out.aggs.size() && ot.key_index < 0 && ot.agg_index < 0; i++)
                 if (out.aggs[i].text == ot.text) ot.agg_index = (int)i;
-            if (ot.key_index < 0 && ot.agg_index < 0) {
+            // after an InitialProject the sort term may name a projection alias (the projected item carries the alias as
+            // a field, execution/project_initial.go:118-121) or repeat a term's expression
+            for (size_t i = 0; i < out.project.size() && ot.key_index < 0 && ot.agg_index < 0 && ot.proj_index < 0; i++)
+                if ((!out.project[i].as.empty() && ot.text == "`" + out.project[i].as + "`") || out.project[i].text == ot.text)
+                    ot.proj_index = (int)i;
+            if (ot.key_index < 0 && ot.agg_index < 0 && ot.proj_index < 0) {
                 err.unsupported = true;
-                err.msg = "sort term is neither a group key nor an aggregate of the plan: " + ot.text;
+                err.msg = "sort term is neither a group key, an aggregate nor a projection term of the plan: " + ot.text;
                 return false;
             }
             out.order.push_back(ot);
@@ -620,6 +665,44 @@ bool plan_node(const JVal& node, ParsedPlan& out, PlanError& err, int depth) {
         out.has_order = true;
         if (node.get("offset") && !const_count(node.get("offset"), "offset", out.offset)) return false;
         if (node.get("limit") && !const_count(node.get("limit"), "limit", out.limit)) return false;
+        return true;
+    }
+    if (name == "InitialProject") {  // plan/project.go:73-110: result_terms [{expr, as?, star?}], raw?, distinct?
+        if (!out.has_group || out.has_project || out.has_order || out.limit >= 0 || out.offset > 0) {
+            err.unsupported = true;
+            err.msg = "InitialProject runs on the device only over the final groups, before Order / Offset / Limit";
+            return false;
+        }
+        for (const char* flag : {"raw", "distinct"})
+            if (const JVal* f = node.get(flag))
+                if (f->type == JVal::Bool && f->b) {
+                    err.unsupported = true;
+                    err.msg = std::string("InitialProject with ") + flag + " does not run on the device";
+                    return false;
+                }
+        const JVal* ts = node.get("result_terms");
+        if (!ts || ts->type != JVal::Arr) { err.msg = "InitialProject without result_terms"; return false; }
+        for (auto& t : ts->arr) {
+            if (t.type != JVal::Obj) { err.msg = "result term is not an object"; return false; }
+            const JVal* star = t.get("star");
+            if (star && star->type == JVal::Bool && star->b) {
+                err.unsupported = true;
+                err.msg = "a star projection does not run on the device";
+                return false;
+            }
+            const JVal* e = t.get("expr");
+            if (!e || e->type != JVal::Str) { err.msg = "result term without expr"; return false; }
+            ProjectTerm pt;
+            pt.text = e->str;
+            const JVal* as = t.get("as");
+            if (as && as->type == JVal::Str) pt.as = as->str;
+            out.project.push_back(std::move(pt));
+        }
+        out.has_project = true;
+        return true;
+    }
+    if (name == "FinalProject") {  // plan/project.go:171-181: no data; the projection attachment becomes the row
+        if (!out.has_project) { err.unsupported = true; err.msg = "FinalProject without an InitialProject over the groups"; return false; }
         return true;
     }
     if (name == "Limit" || name == "Offset") {  // plan/limit.go:46-53, plan/offset.go
@@ -632,6 +715,56 @@ bool plan_node(const JVal& node, ParsedPlan& out, PlanError& err, int depth) {
 }
 
 }  // namespace
+
+// value.Collate over parsed JSON (value/array.go arrayCollate: element by element, then the shorter first;
+// value/object.go:511-556 objectCollate: fewer fields first, then name by name over the sorted union of the names — a
+// name the other lacks makes this one larger — then the values; scalars by type order, value/value.go:69-79)
+static int jval_collate(const JVal& a, const JVal& b) {
+    auto cls = [](const JVal& v) { return v.type == JVal::Null ? 1 : v.type == JVal::Bool ? 2 : v.type == JVal::Num ? 3 : v.type == JVal::Str ? 4 : v.type == JVal::Arr ? 5 : 6; };
+    const int ca = cls(a), cb = cls(b);
+    if (ca != cb) return ca < cb ? -1 : 1;
+    switch (a.type) {
+        case JVal::Null: return 0;
+        case JVal::Bool: return (int)a.b - (int)b.b;
+        case JVal::Num: return a.num < b.num ? -1 : (a.num > b.num ? 1 : 0);
+        case JVal::Str: {
+            const int c = a.str.compare(b.str);  // bytewise, like Go strings (value/string.go:116-130)
+            return c < 0 ? -1 : (c > 0 ? 1 : 0);
+        }
+        case JVal::Arr:
+            for (size_t i = 0; i < a.arr.size(); i++) {
+                if (i >= b.arr.size()) return 1;
+                const int c = jval_collate(a.arr[i], b.arr[i]);
+                if (c) return c;
+            }
+            return a.arr.size() < b.arr.size() ? -1 : 0;
+        default: {
+            if (a.obj.size() != b.obj.size()) return a.obj.size() < b.obj.size() ? -1 : 1;
+            std::vector<std::string> names;
+            for (auto& kv : a.obj) names.push_back(kv.first);
+            for (auto& kv : b.obj) names.push_back(kv.first);
+            std::sort(names.begin(), names.end());
+            names.erase(std::unique(names.begin(), names.end()), names.end());
+            for (auto& n : names) {
+                const JVal* x = a.get(n.c_str());
+                const JVal* y = b.get(n.c_str());
+                if (!x) return 1;
+                if (!y) return -1;
+                const int c = jval_collate(*x, *y);
+                if (c) return c;
+            }
+            return 0;
+        }
+    }
+}
+
+bool json_text_collate(const std::string& a, const std::string& b, int& out) {
+    JParser pa{a.c_str(), a.size(), 0, ""}, pb{b.c_str(), b.size(), 0, ""};
+    JVal va, vb;
+    if (!pa.value(va) || !pb.value(vb)) return false;
+    out = jval_collate(va, vb);
+    return true;
+}
 
 std::unique_ptr<Expr> parse_expression(const std::string& s, PlanError& err) {
     EParser ep(s, err);
@@ -655,6 +788,7 @@ bool parse_aggregate(const std::string& s, AggDef& out, PlanError& err) {
     else if (name == "avg") out.kind = AGG_AVG;
     else if (name == "min") out.kind = AGG_MIN;
     else if (name == "max") out.kind = AGG_MAX;
+    else if (name == "array_agg") out.kind = AGG_ARRAY;  // algebra/agg_array.go, agg_array_distinct.go
     else {
         err.unsupported = true;
         err.msg = "aggregate " + name + " is outside the device subset";

@@ -21,7 +21,8 @@ struct PlanError {
 // expression tree (subset of expression/*.go)
 enum class EK {
     Const, Path, Add, Sub, Mult, Div, Mod, Neg, IDiv, IMod, Eq, LT, LE, Between, And, Or, Not,
-    IsNull, IsNotNull, IsMissing, IsNotMissing, IsValued, IsNotValued
+    IsNull, IsNotNull, IsMissing, IsNotMissing, IsValued, IsNotValued,
+    Func  // numeric functions of one or two arguments (expression/func_num.go): fname
 };
 
 struct Expr {
@@ -33,6 +34,8 @@ struct Expr {
     std::string cstr;        // STRING constant bytes
     // Path
     std::string text;        // exact stringer text, e.g. (`default`.`price`)
+    // Func
+    std::string fname;       // round | trunc | abs | ceil | floor | sign | sqrt
 };
 
 struct AggDef {
@@ -49,6 +52,14 @@ struct OrderTerm {
     bool desc = false;
     int key_index = -1;  // >= 0: group key
     int agg_index = -1;  // >= 0: aggregate
+    int proj_index = -1; // >= 0: a projection term (by its alias, or by its expression text)
+};
+
+// one result term of the InitialProject after the group operators (plan/project.go:73-110): its expression reads group
+// keys and aggregates (algebra/aggregate.go:97-118 looks an aggregate up by its text in the "aggregates" attachment)
+struct ProjectTerm {
+    std::string text;  // expression.Stringer text
+    std::string as;    // explicit alias ("" = none: the caller derives one as algebra.ResultTerm does)
 };
 
 struct ParsedPlan {
@@ -68,6 +79,9 @@ struct ParsedPlan {
     // HAVING: a Filter after the group operators (planner/build_select_sub.go:295), over group keys and aggregates
     bool has_having = false;
     std::string having_text;
+    // InitialProject / FinalProject over the final groups (execution/project_initial.go:52-144, project_final.go:51-59)
+    bool has_project = false;
+    std::vector<ProjectTerm> project;
 };
 
 // Parse plan JSON (Sequence / Parallel / Filter / InitialGroup nodes, optionally followed by IntermediateGroup /
@@ -77,5 +91,9 @@ bool parse_plan_json(const char* json, size_t len, ParsedPlan& out, PlanError& e
 // Parse one stringified expression / aggregate.
 std::unique_ptr<Expr> parse_expression(const std::string& s, PlanError& err);
 bool parse_aggregate(const std::string& s, AggDef& out, PlanError& err);
+
+// value.Collate of two arrays / objects given as canonical JSON text (numbers through float64); false when a text does
+// not parse
+bool json_text_collate(const std::string& a, const std::string& b, int& out);
 
 }  // namespace n1k

@@ -102,7 +102,8 @@ struct KeySpec {
     uint32_t pad;
 };
 
-enum : uint32_t { AGG_SUM = 0, AGG_COUNT, AGG_COUNTN, AGG_AVG, AGG_MIN, AGG_MAX };
+enum : uint32_t { AGG_SUM = 0, AGG_COUNT, AGG_COUNTN, AGG_AVG, AGG_MIN, AGG_MAX,
+                  AGG_ARRAY };  // ARRAY_AGG: every operand but MISSING is logged per group, the arrays are built at finish
 struct AggSpec {
     uint32_t kind;
     uint32_t distinct;
@@ -149,7 +150,9 @@ enum : uint32_t {
 };
 
 struct Program {
-    uint32_t ncols, nterms, nlogic, nkeys, naggs, pad0;
+    uint32_t ncols, nterms, nlogic, nkeys, naggs;
+    uint32_t emit_packed_key;  // FinalGroup writes the packed group key where the representative row would go (ARRAY_AGG: the host
+                               // matches the logged operands to the groups by it)
     uint32_t lds_words;     // words per LDS slot (key + accumulators)
     uint32_t glob_words;    // words per global row (accumulators only)
     uint32_t want_rep_row;  // keep min row ordinal per group
@@ -359,7 +362,9 @@ struct FastArgs {
 
 // derived columns: arithmetic nodes of the plan are evaluated once per batch by an element-wise kernel into a
 // temporary TAGGED64 column; the scan kernels then see them as ordinary columns
-enum : uint32_t { AR_ADD = 0, AR_MULT, AR_SUB, AR_DIV, AR_MOD, AR_NEG, AR_IDIV, AR_IMOD };
+enum : uint32_t { AR_ADD = 0, AR_MULT, AR_SUB, AR_DIV, AR_MOD, AR_NEG, AR_IDIV, AR_IMOD,
+                  // expression/func_num.go: ROUND / TRUNC (value [, digits]), ABS, CEIL, FLOOR, SIGN, SQRT
+                  AR_ROUND, AR_TRUNC, AR_ABS, AR_CEIL, AR_FLOOR, AR_SIGN, AR_SQRT };
 struct ArithArgs {
     uint32_t op, nops;
     Operand ops[4];

@@ -41,6 +41,7 @@ class GroupRows:
     partials: List[tuple]
     rep_row: Optional[np.ndarray] = None
     selected: Optional[np.ndarray] = None
+    proj: Optional[List[tuple]] = None  # plans with an InitialProject: per group the values of the result terms
 
 
 def _np_col(col) -> dict:
@@ -77,6 +78,13 @@ class GpuFilterGroup:
     def aggregate_names(self) -> List[str]:
         n = self._lib.n1k_num_aggregates(self._h)
         return [self._lib.n1k_aggregate_name(self._h, i).decode() for i in range(n)]
+
+    @property
+    def projection_terms(self) -> List[tuple]:
+        """(expression text, explicit alias or '') of the plan's InitialProject result terms."""
+        n = self._lib.n1k_num_projection_terms(self._h)
+        return [(self._lib.n1k_projection_expr(self._h, i).decode(), self._lib.n1k_projection_alias(self._h, i).decode())
+                for i in range(n)]
 
     @property
     def num_keys(self) -> int:
@@ -234,6 +242,9 @@ class GpuFilterGroup:
                "partials": arr(res.partials, ng * na, self._PARTIAL_DT).reshape(ng, na) if na else None,
                "rep_row": arr(res.rep_row, ng, np.dtype("<u8")) if ng else None,
                "selected": arr(res.selected, int(res.nselected), np.dtype("<u8"))}
+        npj = int(res.nproj)
+        out["nproj"] = npj
+        out["proj"] = arr(res.proj, ng * npj, self._VALUE_DT).reshape(ng, npj) if npj else None
         return out
 
     def order_rows(self, keys: np.ndarray, aggs: np.ndarray) -> dict:
@@ -289,6 +300,8 @@ class GpuFilterGroup:
         out = GroupRows(nk, na, self._py_values(raw["keys"], cache) if ng else [],
                         self._py_values(raw["aggs"], cache) if ng else [], [])
         out.selected = raw["selected"]
+        if raw.get("nproj"):
+            out.proj = self._py_values(raw["proj"], cache) if ng else []
         if ng and na:
             p = raw["partials"]
             for g in range(ng):

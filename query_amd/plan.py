@@ -113,6 +113,27 @@ class Offset:
         return {"#operator": "Offset", "expr": str(int(self.expr))}
 
 
+@dataclass
+class InitialProject:
+    """plan/project.go:73-110: result_terms [{expr, as?}] (star / raw / distinct projections are not built here)."""
+    result_terms: Sequence[tuple]  # (expression text, alias or None)
+
+    def marshal(self) -> dict:
+        terms = []
+        for expr, alias in self.result_terms:
+            t = {"expr": expr}
+            if alias:
+                t["as"] = alias
+            terms.append(t)
+        return {"#operator": "InitialProject", "result_terms": terms}
+
+
+@dataclass
+class FinalProject:
+    def marshal(self) -> dict:
+        return {"#operator": "FinalProject"}
+
+
 def marshal_json(op) -> str:
     return json.dumps(op.marshal(), sort_keys=True)
 
@@ -120,7 +141,8 @@ def marshal_json(op) -> str:
 def filter_group_plan(condition: Optional[str], group_keys: Optional[Sequence[str]],
                       aggregates: Optional[Sequence[str]], *, filter_only: bool = False,
                       order: Optional[Sequence[tuple]] = None, limit: Optional[int] = None,
-                      offset: Optional[int] = None, having: Optional[str] = None) -> str:
+                      offset: Optional[int] = None, having: Optional[str] = None,
+                      project: Optional[Sequence[tuple]] = None) -> str:
     """Plan JSON of Parallel{Sequence[Filter?, InitialGroup?]} as the planner emits it
     (planner/build_select_sub.go:209-211, 276-296).  With `order` / `limit` / `offset` the whole grouped tail
     follows: IntermediateGroup, FinalGroup, Order (which carries offset and limit, plan/order.go:51-79), Offset,
@@ -131,11 +153,16 @@ def filter_group_plan(condition: Optional[str], group_keys: Optional[Sequence[st
     if not filter_only:
         children.append(InitialGroup(list(group_keys or []), list(aggregates or [])))
     par = Parallel(Sequence(children))
-    if order is None and limit is None and offset is None and having is None:
+    if order is None and limit is None and offset is None and having is None and project is None:
         return marshal_json(par)
     tail: List[object] = [par, IntermediateGroup(list(group_keys or []), list(aggregates or [])),
                           FinalGroup(list(group_keys or []), list(aggregates or []))]
-    if having is not None:  # HAVING is a Filter over the final groups (planner/build_select_sub.go:295)
+    if project is not None:
+        # HAVING and the projection share the Parallel after FinalGroup (planner/build_select_sub.go:217-235, :295);
+        # `project` = [(expression text, alias or None)]
+        sub: List[object] = ([Filter(having)] if having is not None else []) + [InitialProject(list(project))]
+        tail.append(Parallel(Sequence(sub)))
+    elif having is not None:  # HAVING is a Filter over the final groups (planner/build_select_sub.go:295)
         tail.append(Filter(having))
     if order:
         tail.append(Order(list(order), offset, limit))
@@ -144,4 +171,6 @@ def filter_group_plan(condition: Optional[str], group_keys: Optional[Sequence[st
             tail.append(Offset(offset))
         if limit is not None:
             tail.append(Limit(limit))
+    if project is not None:
+        tail.append(FinalProject())
     return marshal_json(Sequence(tail))

@@ -66,7 +66,77 @@ def F(alias, *path):
     return s
 
 
+def explain_plans():
+    """Every Filter / InitialGroup / grouped-tail subtree of the EXPLAIN results the reference's case files hold, verbatim
+    (tests/golden/plans.json): what n1k_create is handed at the boundary.  Per plan tree:
+      * each Filter node and each InitialGroup node on its own;
+      * each Parallel whose child Sequence holds a Filter and / or an InitialGroup, as it stands;
+      * each run [Parallel{..InitialGroup..}, IntermediateGroup, FinalGroup, ...rest of that Sequence], and the same run
+        continued by the Order / Offset / Limit / FinalProject siblings that follow the Sequence one level up (the glue
+        concatenates them the same way)."""
+    files = sorted(glob.glob(os.path.join(REF, "test", "**", "*.json"), recursive=True))
+    out, seen = [], set()
+
+    def emit(src, kind, node):
+        text = json.dumps(node, sort_keys=True)
+        if text in seen:
+            return
+        seen.add(text)
+        out.append({"source": src, "kind": kind, "plan": node})
+
+    def has_group(par):
+        ch = par.get("~child", {})
+        kids = ch.get("~children", []) if ch.get("#operator") == "Sequence" else [ch]
+        return any(k.get("#operator") == "InitialGroup" for k in kids if isinstance(k, dict))
+
+    def has_path_node(par):
+        ch = par.get("~child", {})
+        kids = ch.get("~children", []) if ch.get("#operator") == "Sequence" else [ch]
+        return any(k.get("#operator") in ("InitialGroup", "Filter") for k in kids if isinstance(k, dict))
+
+    def walk(src, node, after):
+        """after: the siblings that follow `node` in its parent Sequence"""
+        if isinstance(node, list):
+            for x in node:
+                walk(src, x, [])
+            return
+        if not isinstance(node, dict):
+            return
+        op = node.get("#operator")
+        if op in ("Filter", "InitialGroup"):
+            emit(src, op, node)
+        if op == "Parallel" and has_path_node(node):
+            emit(src, "Parallel", node)
+        if op == "Sequence":
+            kids = node.get("~children", [])
+            for i, k in enumerate(kids):
+                if isinstance(k, dict) and k.get("#operator") == "Parallel" and has_group(k) and i + 2 < len(kids) and \
+                        kids[i + 1].get("#operator") == "IntermediateGroup" and kids[i + 2].get("#operator") == "FinalGroup":
+                    run = kids[i:]
+                    emit(src, "grouped tail", {"#operator": "Sequence", "~children": run})
+                    tail = [a for a in after if a.get("#operator") in ("Order", "Offset", "Limit", "FinalProject")]
+                    if tail:
+                        emit(src, "grouped tail + order", {"#operator": "Sequence", "~children": run + tail})
+            for i, k in enumerate(kids):
+                walk(src, k, [x for x in kids[i + 1:] if isinstance(x, dict)])
+            return
+        for k, v in node.items():
+            if isinstance(v, (dict, list)):
+                walk(src, v, [])
+
+    for f in files:
+        try:
+            doc = json.load(open(f))
+        except Exception:
+            continue
+        walk(os.path.relpath(f, REF), doc, [])
+    with open(os.path.join(OUT, "plans.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("wrote %d EXPLAIN plan subtrees from %d files" % (len(out), len({p["source"] for p in out})))
+
+
 def main():
+    explain_plans()
     data = {}
     for ks in ("catalog", "orders", "user_profile", "jobs", "tags", "contacts", "game"):
         data[ks] = load_keyspace(ks)
@@ -134,6 +204,17 @@ def main():
     add(g1, gbh, 11, "jobs",
         {"condition": None, "group_keys": [F("jobs", "join_yr")], "aggregates": ["count(distinct %s)" % jt]},
         {"project": [{"as": "distinct_title_count", "agg": 0}, {"as": "join_yr", "key": 0}],
+         "order": [[{"key": 0}, "asc"]]})
+    # ARRAY_AGG (algebra/agg_array.go, agg_array_distinct.go): cases 4, 12, 14
+    add(g1, gbh, 4, "catalog", {"condition": None, "group_keys": [], "aggregates": ["array_agg(%s)" % F("catalog", "asin")]},
+        {"project": [{"as": "agg", "agg": 0}]})
+    add(g1, gbh, 12, "jobs",
+        {"condition": None, "group_keys": [F("jobs", "join_yr")], "aggregates": ["array_agg(distinct %s)" % jt]},
+        {"project": [{"as": "distinct_titles", "agg": 0}, {"as": "join_yr", "key": 0}], "order": [[{"key": 0}, "asc"]]})
+    a14 = sorted(["array_agg(distinct %s)" % jt, "array_agg(%s)" % jt])
+    add(g1, gbh, 14, "jobs", {"condition": None, "group_keys": [F("jobs", "join_yr")], "aggregates": a14},
+        {"project": [{"as": "distinct_titles", "agg": a14.index("array_agg(distinct %s)" % jt)},
+                     {"as": "titles", "agg": a14.index("array_agg(%s)" % jt)}, {"as": "join_yr", "key": 0}],
          "order": [[{"key": 0}, "asc"]]})
     a13 = sorted(["count(distinct %s)" % jt, "count(%s)" % jt])
     add(g1, gbh, 13, "jobs", {"condition": None, "group_keys": [F("jobs", "join_yr")], "aggregates": a13},
@@ -205,6 +286,12 @@ def main():
     # ---------------------------------------------------------------- G3: multistore integers
     g3 = "multistore/integers/case_select.json"
     ifilter = '((%s = "select_big_int") and (%s = "aggr"))' % (F("orders", "test_id"), F("orders", "type"))
+    # 1-3: the 64-bit integers as leaf values of the documents (Filter + projection of document fields; 2 and 3 RAW)
+    vfilter = '((%s = "select_big_int") and (%s = "value"))' % (F("orders", "test_id"), F("orders", "type"))
+    add(g3, ms_int, 1, "ms_int_orders", {"condition": vfilter, "filter_only": True},
+        {"project": [{"as": "big", "doc": ["big"]}, {"as": "little", "doc": ["little"]}]})
+    add(g3, ms_int, 2, "ms_int_orders", {"condition": vfilter, "filter_only": True}, {"raw": {"doc": ["big"]}})
+    add(g3, ms_int, 3, "ms_int_orders", {"condition": vfilter, "filter_only": True}, {"raw": {"doc": ["little"]}})
     add(g3, ms_int, 4, "ms_int_orders",
         {"condition": ifilter, "group_keys": [F("orders", "type")], "aggregates": ["sum(%s)" % F("orders", "num")]},
         {"project": [{"as": "total", "agg": 0}, {"as": "type", "key": 0}]})
@@ -222,6 +309,10 @@ def main():
              "order": [[{"doc": list(order)}, "asc"]]})
 
     bo = F("tags", "banned-on")
+    # (case 3: an array-element leaf, expression/nav_element.go:49-65.  Cases 4-7, 10-13, 24-30 use LIKE, LENGTH, ANY /
+    #  EVERY ... SATISFIES or array / object constructors: outside the path's expression subset)
+    fo(3, "catalog", '((%s[0]) = "Jessica Chastain")' % F("catalog", "details", "actors"), [("details", "actors")], ("details", "actors"))
+    cases[-1]["post"]["project"][0]["as"] = "actors"
     fo(0, "tags", "(%s is not missing)" % bo, [("banned-on",)], ("banned-on",))
     fo(1, "tags", "(%s is not null)" % bo, [("banned-on",)], ("banned-on",))
     fo(2, "tags", "(%s is null)" % bo, [("banned-on",)], ("banned-on",))
@@ -239,6 +330,23 @@ def main():
     fo(22, "game", "(10 <= %s)" % F("game", "score"), [("score",)], ("score",))
     fo(23, "contacts", '((%s = "dave") or (%s = "earl"))' % (F("contacts", "name"), F("contacts", "name")),
        [("name",)], ("name",))
+    # ---------------------------------------------------------------- G6: filestore case_integer.json (constant expressions)
+    # SELECTs without FROM: no Filter / Group operator runs, but the results pin the number semantics the path's
+    # expressions share (value/integer.go:266-352: 2^53+1 stays an exact int through + * - and unary minus; IDIV / IMOD
+    # by zero are NULL; DIV is float).  Kept as expression cases: text in expression.Stringer syntax -> expected value.
+    g6 = "filestore/case_integer.json"
+    cint = cases_of(os.path.join(FS, "cases/case_integer.json"))
+
+    def ex(idx, pairs):
+        c = cint[idx]
+        cases.append({"id": "%s#%d" % (g6, idx), "source": g6, "index": idx, "statement": c["statements"], "keyspace": "game",
+                      "plan": {"exprs": [[a, t] for a, t in pairs]}, "post": {}, "results": c["results"]})
+
+    ex(0, [("float64", "9007199254740992"), ("int64", "9007199254740993")])  # the float literal prints as float64 holds it
+    ex(1, [("float64", "9007199254740992"), ("int64", "9007199254740993"), ("add", "(9007199254740993 + 0)"),
+           ("mult", "(9007199254740993 * 1)"), ("neg", "(-9007199254740993)"), ("sub", "(9007199254740993 - 0)")])
+    ex(2, [("idiv", "idiv(5, 2)"), ("div", "(5 / 2)"), ("imod", "imod(5, 2)"), ("idiv_zero", "idiv(5, 0)"),
+           ("imod_zero", "imod(5, 0)")])
     # contact alias differs in case 8 ("FROM default:contacts AS contact")
     used = sorted({c["keyspace"] for c in cases})
     with open(os.path.join(OUT, "cases.json"), "w") as fh:

@@ -391,9 +391,53 @@ def replay_post(case: dict, groups: Sequence[tuple], having_done: bool = False) 
     return out
 
 
+def project_terms(case: dict) -> List[tuple]:
+    """The case's SELECT list as InitialProject result terms [(expression.Stringer text, alias)] over the plan's group
+    keys and aggregates (plan/project.go:73-110); ROUND(agg, n) prints as round(<agg>, n) (expression/stringer.go)."""
+    p = case["plan"]
+    out = []
+    for t in case["post"]["project"]:
+        text = p["group_keys"][t["key"]] if "key" in t else p["aggregates"][t["agg"]]
+        if "round" in t:
+            text = "round(%s, %d)" % (text, t["round"])
+        out.append((text, t["as"]))
+    return out
+
+
+def order_terms(case: dict) -> Optional[List[tuple]]:
+    """The case's ORDER BY as Order sort terms [(text, descending)]: a term that the SELECT list aliases is named by its
+    alias (`alias`), as the planner leaves it; any other by the key's / aggregate's own text."""
+    post, p = case["post"], case["plan"]
+    if "order" not in post:
+        return None
+    out = []
+    for spec, direction in post["order"]:
+        alias = next((t["as"] for t in post["project"] if all(t.get(k) == spec.get(k) for k in ("key", "agg"))
+                      and not t["as"].startswith("$")), None)
+        text = "`%s`" % alias if alias else (p["group_keys"][spec["key"]] if "key" in spec else p["aggregates"][spec["agg"]])
+        out.append((text, direction == "desc"))
+    return out
+
+
+def rows_from_projection(case: dict, res) -> List[dict]:
+    """Result rows of a device run whose plan carried the InitialProject: {alias: value}, MISSING terms left out
+    (execution/project_initial.go:118-121 sets a field only for a value; a MISSING field does not marshal)."""
+    out = []
+    for vals in res.proj:
+        r = {}
+        for t, tv in zip(case["post"]["project"], vals):
+            v = decode_value(tv)
+            if v is not MISSING:
+                r[t["as"]] = v
+        out.append(r)
+    return out
+
+
 def replay_filter_post(case: dict, docs: Sequence[dict], selected: Sequence[int]) -> List[dict]:
     post = case["post"]
     rows = [docs[int(i)]["doc"] for i in selected]
+    if "raw" in post:  # SELECT RAW expr: the bare values
+        return [v for v in (_term(post["raw"], None, None, d) for d in rows) if v is not MISSING]
     if "order" in post:
         def cmp(d1, d2):
             for spec, direction in post["order"]:

@@ -19,10 +19,10 @@ ABS_TOL = 0.0
 
 def run_gpu(table: n1o.Table, condition: Optional[str], keys: Sequence[str], aggs: Sequence[str], *,
             filter_only: bool = False, batches: int = 1, device_resident: bool = False, order=None, limit=None,
-            offset=None, having=None, **options):
+            offset=None, having=None, project=None, **options):
     """Run through libn1k.so.  The table's columns are matched to the plan's leaf paths by name."""
     pj = qplan.filter_group_plan(condition, keys, aggs, filter_only=filter_only, order=order, limit=limit, offset=offset,
-                                 having=having)
+                                 having=having, project=project)
     op = query_amd.GpuFilterGroup(pj, **options)
     try:
         by_name = {c.name: c for c in table.columns}

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_ffi.LIB_PATH)
     for s in sorted(declared):
         assert hasattr(L, s), "libn1k.so does not export " + s
-    assert _ffi.lib().n1k_abi_version() == 1
+    assert _ffi.lib().n1k_abi_version() == 2
 
 
 def test_plan_json_binding_and_names():
@@ -45,7 +45,8 @@ def test_golden_explain_plan_shape_is_accepted():
 @pytest.mark.parametrize("pj,status", [
     ('{"#operator":"Filter","condition":"(length((`a`.`b`)) < 3)"}', _ffi.UNSUPPORTED),
     ('{"#operator":"Fetch","keyspace":"x"}', _ffi.UNSUPPORTED),
-    ('{"#operator":"InitialGroup","group_keys":[],"aggregates":["array_agg((`a`.`b`))"]}', _ffi.UNSUPPORTED),
+    ('{"#operator":"InitialGroup","group_keys":[],"aggregates":["median((`a`.`b`))"]}', _ffi.UNSUPPORTED),
+    ('{"#operator":"InitialGroup","group_keys":[],"aggregates":["min(distinct (`a`.`b`))"]}', _ffi.INVALID),
     ('{"#operator":"Filter","condition":"(any x in (`a`.`b`) satisfies x end)"}', _ffi.UNSUPPORTED),
     ('{"#operator":"Filter","condition":"((`a`.`b`) <"}', _ffi.INVALID),
     ('not json', _ffi.INVALID),

@@ -120,7 +120,7 @@ def test_partial_groups_export_merge_roundtrip():
     buf = torch.zeros(region * nparts, dtype=torch.uint8, device="cuda")
     op._check(lib.n1k_export_partials_device(op._h, nparts, cap, buf.data_ptr()))
     counts = [int(buf[d * region: d * region + 8].view(torch.int64).item()) for d in range(nparts)]
-    assert sum(counts) == 302 or sum(counts) <= 302  # 300 categories (+ none missing here)
+    assert sum(counts) == len(n1o.run(t, COND, KEYS, aggs).keys)  # every group sits in exactly one region
     with pytest.raises(query_amd.N1kError):  # too small a region is reported, not truncated
         small = torch.zeros(int(lib.n1k_partial_region_bytes(op._h, 8)) * nparts, dtype=torch.uint8, device="cuda")
         op._check(lib.n1k_export_partials_device(op._h, nparts, 8, small.data_ptr()))

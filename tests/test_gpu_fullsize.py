@@ -72,7 +72,7 @@ def close(a, b, rel=1e-9):
 
 def test_full_size_properties(columns):
     whole, st = run(columns, COND, KEYS, AGGS, [(0, ROWS)])
-    assert st["spec_kernel"] == 0 or True
+    assert st["spec_kernel"] == 2  # no prebuilt kernel has this shape: the plan-specialised scan is built at run time
     d_whole = as_dict(whole)
     assert whole["ngroups"] == K_CAT
     ci = AGGS.index("count(*)")
