@@ -72,7 +72,9 @@ def close(a, b, rel=1e-9):
 
 def test_full_size_properties(columns):
     whole, st = run(columns, COND, KEYS, AGGS, [(0, ROWS)])
-    assert st["spec_kernel"] == 2  # no prebuilt kernel has this shape: the plan-specialised scan is built at run time
+    # 13 accumulator words x 1002 slots = 104 KB of LDS table: beyond what the plan-specialised kernels take (64 KB), so
+    # the bounded-shape kernel ran, with the perfect-hash table
+    assert st["spec_kernel"] == 0 and st["agg_mode"] == _ffi.MODE_LDS_DIRECT
     d_whole = as_dict(whole)
     assert whole["ngroups"] == K_CAT
     ci = AGGS.index("count(*)")
