@@ -28,6 +28,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 SEED = 0x5EED0001
+METRIC = "rows/sec filter+group-by on 100M synthetic JSON docs; achieved HBM GB/s"  # BASELINE.json's metric, verbatim
+DTYPE = "int64/f64 tagged scalars (u8 tag + 8 B payload), u32 dictionary codes"
 
 
 def D(*names):
@@ -138,17 +140,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling)")
+    ap.add_argument("--total-rows", type=int, default=0, help="multi-GPU: rows in all, split over the ranks (strong scaling: "
+                    "BASELINE config 4 = 100 M, config 5 = 1 B over 8 GPUs); 0 = --rows per GPU")
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--kcat", type=int, default=None, help="distinct cat values (default: 1000; 100000 for config5*, as BASELINE.json names them)")
     ap.add_argument("--zipf", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "partials", "rows"],
-                    help="multi-GPU: what crosses xGMI.  auto = per-GPU partial groups, all-gathered while they are few "
-                         "and hash-partitioned (all-to-all) beyond that, rows when the plan has DISTINCT; "
-                         "partials = always the hash-partitioned partial groups; rows = always the filtered rows")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "partials", "gathered"],
+                    help="multi-GPU: what crosses xGMI.  auto = rows (the configuration north_star names: filtered rows "
+                         "hash-partitioned on the group key by one RCCL all-to-all); partials = per-GPU partial groups "
+                         "hash-partitioned to owners; gathered = partial groups all-gathered while they are few (the "
+                         "ablation: G groups travel instead of the rows); plans with DISTINCT always exchange rows")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank")
     args = ap.parse_args()
     if args.kcat is None:
@@ -206,7 +211,7 @@ def main():
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
     out = {
-        "metric": "rows/sec filter+group-by on 100M synthetic JSON docs; achieved HBM GB/s",
+        "metric": METRIC,
         "value": args.rows * args.steps / elapsed,
         "unit": "rows/s",
         "n_gpus": 1,
@@ -216,7 +221,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "int64/f64 tagged scalars (u8 tag + 8 B payload), u32 dictionary codes",
+        "dtype": DTYPE,
         "data": "synthetic",
         "config": {"workload": "%s: %s @ %d rows, K_cat=%d%s, columns resident in HBM" %
                                (args.workload, wl["sql"], args.rows, args.kcat, " zipf" if args.zipf else ""),

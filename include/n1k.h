@@ -374,6 +374,47 @@ n1k_status n1k_export_groups(n1k_handle *h, const void **blob, size_t *len);
 n1k_status n1k_order_rows(n1k_handle *h, uint64_t ngroups, const n1k_value *keys, const n1k_value *aggs, n1k_result *out);
 n1k_status n1k_merge_groups(n1k_handle *h, const void *blob, size_t len);
 
+/* ------------------------------------------ multi-GPU: RCCL collectives behind the ABI -- */
+
+/*
+ * One communicator per rank, one rank per GPU (no reference analogue: the reference is single-process and fans its
+ * Parallel copies in through one in-memory queue, execution/exchange.go:161-251).  Rank 0 makes an id
+ * (n1k_comm_unique_id, N1K_COMM_ID_BYTES bytes = ncclUniqueId), hands it to the other ranks by whatever channel the
+ * host has, and every rank calls n1k_comm_create — a collective, like ncclCommInitRank.
+ *
+ * The exchange calls are collectives too: every rank makes the same call.  They are enqueued on the sending handle's
+ * stream with no host synchronisation; the receiving handle's n1k_finish is the step's one wait.  A sender whose
+ * fixed-capacity region overflows says so inside the region headers, so every receiver's n1k_finish fails the same
+ * way (N1K_OOM) and all ranks can retry in step with a larger capacity.
+ *
+ * n1k_exchange_partials: per-GPU partial groups (≙ the Initial -> Intermediate hand-over, algebra/aggregate.go:25-40):
+ *   the sender's groups are exported (n1k_export_partials_async), moved by ONE collective — all-gather when `gathered`
+ *   (every rank merges every rank's groups and ends with the whole result), else all-to-all of regions hash-partitioned
+ *   on the group key (each key is merged and finished by one owner) — and merged into the receiver
+ *   (n1k_merge_partials_device).  Not for plans with DISTINCT aggregates (sets do not travel).
+ * n1k_exchange_rows: the sender evaluates its Filter over `batch` (device-resident) and scatters the survivors' columns
+ *   by a hash of the group key VALUES into one packed region per destination rank ([count][verdict] header + every
+ *   column's rows); ONE all-to-all moves counts and rows together; the receiver — a handle of the same plan without the
+ *   Filter — runs InitialGroup over each received region, whose row count stays on the device.  Each group then
+ *   lives on exactly one rank: COUNT(DISTINCT) needs no set merge.  capacity_rows: rows a region takes.
+ * n1k_gather_groups: every rank's finished groups (`local`, its n1k_finish result) to every rank with one all-gather of
+ *   fixed-size slots (the slot size only changes on counts every rank reads in the gathered headers), then the handle's Order / Offset / Limit / projection over the union
+ *   (≙ n1k_order_rows).  `out` belongs to the handle like n1k_finish's.
+ */
+#define N1K_COMM_ID_BYTES 128
+typedef struct n1k_comm n1k_comm;
+n1k_status n1k_comm_unique_id(void *id);
+n1k_status n1k_comm_create(const void *id, int rank, int world, int device, n1k_comm **out);
+void n1k_comm_destroy(n1k_comm *c);
+const char *n1k_comm_last_error(const n1k_comm *c);
+int n1k_comm_rank(const n1k_comm *c);
+int n1k_comm_world(const n1k_comm *c);
+/* largest `value` over the ranks (a collective; waits): how the ranks agree on a region capacity from what each one holds */
+n1k_status n1k_comm_max_u64(n1k_comm *c, n1k_handle *h, uint64_t value, uint64_t *out);
+n1k_status n1k_exchange_partials(n1k_comm *c, n1k_handle *sender, n1k_handle *receiver, uint64_t capacity_groups, int gathered);
+n1k_status n1k_exchange_rows(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver, uint64_t capacity_rows);
+n1k_status n1k_gather_groups(n1k_comm *c, n1k_handle *h, const n1k_result *local, n1k_result *out);
+
 /* ------------------------------------------------------------- utilities -- */
 
 /* Device-side synthetic column generator of SURVEY.md §8(d) (bench/test input;

@@ -23,6 +23,7 @@ T_MISSING, T_NULL, T_FALSE, T_TRUE, T_INT, T_FLOAT, T_STRING, T_ARRAY, T_OBJECT 
 COL_TAGGED64, COL_DICT32 = 0, 1
 CODE_MISSING = 0xFFFFFFFF
 CODE_NULL = 0xFFFFFFFE
+COMM_ID_BYTES = 128
 MODE_AUTO, MODE_LDS_HASH, MODE_LDS_DIRECT, MODE_GLOBAL = range(4)
 
 
@@ -77,6 +78,8 @@ SYMBOLS = [
     "n1k_get_stats", "n1k_partition_device_batch", "n1k_export_groups", "n1k_order_rows", "n1k_merge_groups", "n1k_synth_columns",
     "n1k_jit_check", "n1k_partial_words", "n1k_partial_region_bytes", "n1k_export_partials_device", "n1k_export_partials_async",
     "n1k_merge_partials_device",
+    "n1k_comm_unique_id", "n1k_comm_create", "n1k_comm_destroy", "n1k_comm_last_error", "n1k_comm_rank", "n1k_comm_world",
+    "n1k_comm_max_u64", "n1k_exchange_partials", "n1k_exchange_rows", "n1k_gather_groups",
     "n1k_abi_version", "n1k_device_count",
 ]
 
@@ -163,6 +166,26 @@ def lib():
     L.n1k_export_partials_async.argtypes = [H, C.c_uint32, C.c_uint64, C.c_void_p]
     L.n1k_merge_partials_device.restype = C.c_int
     L.n1k_merge_partials_device.argtypes = [H, C.c_uint32, C.c_uint64, C.c_void_p]
+    L.n1k_comm_unique_id.restype = C.c_int
+    L.n1k_comm_unique_id.argtypes = [C.c_void_p]
+    L.n1k_comm_create.restype = C.c_int
+    L.n1k_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(H)]
+    L.n1k_comm_destroy.restype = None
+    L.n1k_comm_destroy.argtypes = [H]
+    L.n1k_comm_last_error.restype = C.c_char_p
+    L.n1k_comm_last_error.argtypes = [H]
+    L.n1k_comm_rank.restype = C.c_int
+    L.n1k_comm_rank.argtypes = [H]
+    L.n1k_comm_world.restype = C.c_int
+    L.n1k_comm_world.argtypes = [H]
+    L.n1k_comm_max_u64.restype = C.c_int
+    L.n1k_comm_max_u64.argtypes = [H, H, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.n1k_exchange_partials.restype = C.c_int
+    L.n1k_exchange_partials.argtypes = [H, H, H, C.c_uint64, C.c_int]
+    L.n1k_exchange_rows.restype = C.c_int
+    L.n1k_exchange_rows.argtypes = [H, H, C.POINTER(Batch), H, C.c_uint64]
+    L.n1k_gather_groups.restype = C.c_int
+    L.n1k_gather_groups.argtypes = [H, H, C.POINTER(Result), C.POINTER(Result)]
     L.n1k_synth_columns.restype = C.c_int
     L.n1k_synth_columns.argtypes = [C.c_int, C.c_void_p, C.POINTER(SynthSpec)] + [C.c_void_p] * 7
     L.n1k_abi_version.restype = C.c_int

@@ -40,7 +40,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
            "-Wall", "-Wno-unused-function", "-o", LIB]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-lhiprtc", "-ldl", "-pthread"]  # run-time instantiation of the plan-specialised kernel (n1k_jit.cpp)
+    cmd += ["-lhiprtc", "-lrccl", "-ldl", "-pthread"]  # hiprtc: run-time instantiation of the plan-specialised kernel
+    # (n1k_jit.cpp); rccl: the multi-GPU exchange behind the ABI (n1k_comm_*, n1k_exchange_*)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -28,6 +28,8 @@
 #include "n1k_kernels.h"
 #include "n1k_plan.h"
 
+#include <rccl/rccl.h>
+
 using namespace n1k;
 
 static_assert(sizeof(n1k_value) == 16, "n1k_value layout");
@@ -181,6 +183,7 @@ struct n1k_handle {
     DevBuf<unsigned long long> d_counters;  // [0] rows_selected [1] ngroups [2] out_count [3] filter total [4] rehash scratch
                                             // [5] distinct region words [8..11] pair-log cursors
     uint64_t row_base = 0;
+    const unsigned long long* push_nrows_dev = nullptr;  // the batch being pushed holds min(nrows, *this) rows (n1k_exchange_rows)
     uint64_t merged_groups_bound = 0;  // groups that may have arrived through merges (bounds the table like rows do)
 
     // staging for host batches
@@ -827,6 +830,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     if (st != N1K_OK) return st;
     ScanArgs A{};
     A.nrows = b->nrows;
+    A.nrows_dev = h->push_nrows_dev;
     A.row_base = h->row_base;
     if (h->has_distinct) {
         // every qualifying operand appends one (group key, value, class) pair: at most one per row and aggregate
@@ -951,7 +955,8 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
         }
         h->stats.spec_kernel = spec ? 1u : (jit ? 2u : 0u);
-        if ((F.hashed || ndist) && !spec && !jit) goto interpreter;  // the bounded-shape kernel is DIRECT only, no DISTINCT
+        if ((F.hashed || ndist || h->push_nrows_dev) && !spec && !jit) goto interpreter;  // the bounded-shape kernel is DIRECT only, no DISTINCT
+        F.nrows_dev = h->push_nrows_dev;
         WordLogArgs L;
         memset(&L, 0, sizeof L);
         if (ndist) {
@@ -1031,9 +1036,10 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             if (spec || jit) {
                 // WIDE launch over the even prefix (2 adjacent rows per lane and load), scalar launch for an odd last row
                 bool wide = aligned && h->opt_wide && n >= 2;
-                uint64_t n_main = wide ? (n & ~1ull) : n;
+                // (a row count that lives on the device may be odd: the kernel masks the last item's second row itself)
+                uint64_t n_main = wide && !h->push_nrows_dev ? (n & ~1ull) : n;
                 F.nrows = (uint32_t)n_main;
-                uint64_t items = wide ? n_main / 2 : n_main;
+                uint64_t items = wide ? (n_main + 1) / 2 : n_main;
                 uint32_t rpl = wide ? 2 : 4;
                 uint64_t tiles = (items + (uint64_t)fblock * rpl - 1) / ((uint64_t)fblock * rpl);
                 if (ndist) tiles = (tiles + 3) / 4;  // a workgroup reserves chunks in every hash region: give it a few tiles to fill them
@@ -1421,7 +1427,7 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     if (st != N1K_OK) return st;
     const bool first_rows = h->row_base == 0 && h->merged_groups_bound == 0;  // nothing in the handle yet
     PartitionPlan pp;
-    const bool can_partition = h->plan.has_group && partition_eligible(h, pp);
+    const bool can_partition = h->plan.has_group && !h->push_nrows_dev && partition_eligible(h, pp);
     uint64_t head = b->nrows;
     bool decide = false;
     if (can_partition && h->opt_agg_mode == N1K_MODE_PARTITIONED) head = 0;
@@ -3112,6 +3118,384 @@ n1k_status n1k_merge_groups(n1k_handle* h, const void* blob, size_t len) {
     if (st == N1K_OK) HIP_TRY(h, hipStreamSynchronize(h->stream));
     tmp.release();
     return st;
+    });
+}
+
+// ---------------------------------------------------------------- multi-GPU: RCCL behind the C ABI
+//
+// One communicator per rank (one rank per GPU; on one node every GPU pair has its own xGMI link, so the grouped
+// send / recv of an all-to-all keeps all of a GPU's links busy at once).  Everything below is ordered on the sending
+// handle's stream; the receiving handle's stream waits on an event; nothing waits on the host before n1k_finish.
+
+}  // extern "C" (the communicator struct is C++)
+
+struct n1k_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    DevBuf<char> send, recv, gsend, grecv;
+    DevBuf<unsigned long long> scalar;
+    hipEvent_t ev = nullptr;
+    std::string last_error;
+    uint64_t gather_cap = 1024;    // records per slot of n1k_gather_groups (the same on every rank, see there)
+    std::vector<char> ghost;       // gathered records on the host
+    std::vector<n1k_value> gkeys, gaggs;
+};
+
+namespace {
+
+n1k_status cfail(n1k_comm* c, n1k_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->last_error = buf;
+    g_create_error = buf;
+    return st;
+}
+
+#define NCCL_TRY(c, expr)                                                                                   \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess) return cfail(c, N1K_DEVICE_ERROR, "%s failed: %s", #expr, ncclGetErrorString(_r)); \
+    } while (0)
+#define CHIP_TRY(c, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return cfail(c, _e == hipErrorOutOfMemory ? N1K_OOM : N1K_DEVICE_ERROR, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// all-to-all of equal regions: region p of `send` goes to rank p, region s of `recv` comes from rank s.  This rank's own
+// region is not copied: the caller reads it where it lies (`self` returns its address).
+n1k_status all_to_all_regions(n1k_comm* c, const char* send, char* recv, size_t region, hipStream_t st, const char** self) {
+    NCCL_TRY(c, ncclGroupStart());
+    for (int p = 0; p < c->world; p++) {
+        if (p == c->rank) continue;
+        NCCL_TRY(c, ncclSend(send + (size_t)p * region, region, ncclChar, p, c->comm, st));
+        NCCL_TRY(c, ncclRecv(recv + (size_t)p * region, region, ncclChar, p, c->comm, st));
+    }
+    NCCL_TRY(c, ncclGroupEnd());
+    *self = send + (size_t)c->rank * region;
+    return N1K_OK;
+}
+
+int sender_column(const n1k_handle* snd, const std::string& path) {
+    for (size_t j = 0; j < snd->plan.paths.size(); j++)
+        if (snd->plan.paths[j] == path) return (int)j;
+    return -1;
+}
+
+// the receiving handle learns the key layout (column kinds) and the dictionary from the sending one: both were built
+// from the same plan, in one process
+n1k_status prepare_receiver(n1k_handle* snd, n1k_handle* rcv) {
+    if (!snd->layout_fixed) return fail(snd, N1K_INVALID, "the sender has seen no batch yet");
+    for (size_t i = rcv->dict.size(); i < snd->dict.size(); i++)
+        if (intern(rcv, snd->dict[i]) != (uint32_t)i) return fail(rcv, N1K_INVALID, "sender and receiver dictionaries differ");
+    n1k_status st = ensure_device(rcv);
+    if (st != N1K_OK) return st;
+    if (!rcv->layout_fixed) {
+        // (the receiver has no Filter: its columns are the sender's in another order — matched by their path text)
+        std::vector<n1k_col> cols(std::max<size_t>(1, rcv->plan.paths.size()));
+        for (size_t i = 0; i < rcv->plan.paths.size(); i++) {
+            const int j = sender_column(snd, rcv->plan.paths[i]);
+            if (j < 0) return fail(rcv, N1K_INVALID, "the receiver's column %s is not a column of the sender", rcv->plan.paths[i].c_str());
+            cols[i].kind = snd->col_kinds[j];
+        }
+        n1k_batch b{};
+        b.ncols = (uint32_t)rcv->plan.paths.size();
+        b.cols = cols.data();
+        st = push_device(rcv, &b);  // an empty batch: fixes the layout, runs nothing
+    }
+    return st;
+}
+
+n1k_status order_streams(n1k_comm* c, n1k_handle* snd, n1k_handle* rcv) {
+    if (snd->stream == rcv->stream) return N1K_OK;
+    CHIP_TRY(c, hipEventRecord(c->ev, snd->stream));
+    CHIP_TRY(c, hipStreamWaitEvent(rcv->stream, c->ev, 0));
+    return N1K_OK;
+}
+
+// layout of one packed row region for `cap` rows of the plan's input columns: [count][verdict] + padding to 128 bytes,
+// then per column its arrays, each starting on a 16-byte boundary
+size_t row_region_layout(const n1k_handle* h, uint64_t cap, std::vector<size_t>& off_a, std::vector<size_t>& off_b) {
+    size_t at = 128;
+    const size_t nc = h->plan.paths.size();
+    off_a.assign(nc, 0);
+    off_b.assign(nc, 0);
+    auto pad = [](size_t x) { return (x + 15) / 16 * 16; };
+    for (size_t i = 0; i < nc; i++) {
+        if (h->col_kinds[i] == N1K_COL_DICT32) {
+            off_a[i] = at;
+            at = pad(at + cap * 4);
+        } else {
+            off_a[i] = at;  // payload
+            at = pad(at + cap * 8);
+            off_b[i] = at;  // tags
+            at = pad(at + cap);
+        }
+    }
+    return (at + 127) / 128 * 128;
+}
+
+}  // namespace
+
+extern "C" {
+
+n1k_status n1k_comm_unique_id(void* id) {
+    return guarded(nullptr, [&]() -> n1k_status {
+        if (!id) return N1K_INVALID;
+        static_assert(sizeof(ncclUniqueId) == N1K_COMM_ID_BYTES, "N1K_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+        ncclUniqueId u;
+        NCCL_TRY(nullptr, ncclGetUniqueId(&u));
+        memcpy(id, &u, sizeof u);
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_comm_create(const void* id, int rank, int world, int device, n1k_comm** out) {
+    return guarded(nullptr, [&]() -> n1k_status {
+        if (out) *out = nullptr;
+        if (!id || !out || world < 1 || rank < 0 || rank >= world || world > (int)kMaxParts) return cfail(nullptr, N1K_INVALID, "bad communicator arguments");
+        auto* c = new n1k_comm();
+        c->rank = rank;
+        c->world = world;
+        c->device = device;
+        auto bail = [&](n1k_status st) {
+            delete c;
+            return st;
+        };
+        if (hipSetDevice(device) != hipSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "no HIP device %d", device));
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof u);
+        ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+        if (r != ncclSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "ncclCommInitRank failed: %s", ncclGetErrorString(r)));
+        if (hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "hipEventCreate failed"));
+        *out = c;
+        return N1K_OK;
+    });
+}
+
+void n1k_comm_destroy(n1k_comm* c) {
+    if (!c) return;
+    try {
+        (void)hipSetDevice(c->device);
+        if (c->comm) (void)ncclCommDestroy(c->comm);
+        if (c->ev) (void)hipEventDestroy(c->ev);
+        c->send.release();
+        c->recv.release();
+        c->gsend.release();
+        c->grecv.release();
+        c->scalar.release();
+        delete c;
+    } catch (...) {
+    }
+}
+
+const char* n1k_comm_last_error(const n1k_comm* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
+int n1k_comm_rank(const n1k_comm* c) { return c ? c->rank : -1; }
+int n1k_comm_world(const n1k_comm* c) { return c ? c->world : 0; }
+
+n1k_status n1k_comm_max_u64(n1k_comm* c, n1k_handle* h, uint64_t value, uint64_t* out) {
+    return guarded(h, [&]() -> n1k_status {
+        if (!c || !h || !out) return N1K_INVALID;
+        n1k_status st = ensure_device(h);
+        if (st != N1K_OK) return st;
+        HIP_TRY(h, c->scalar.ensure(4));
+        unsigned long long v = value, m = 0;
+        HIP_TRY(h, hipMemcpyAsync(c->scalar.p, &v, 8, hipMemcpyHostToDevice, h->stream));
+        NCCL_TRY(c, ncclAllReduce(c->scalar.p, c->scalar.p + 1, 1, ncclUint64, ncclMax, c->comm, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(&m, c->scalar.p + 1, 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        *out = m;
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_exchange_partials(n1k_comm* c, n1k_handle* sender, n1k_handle* receiver, uint64_t capacity_groups, int gathered) {
+    return guarded(sender, [&]() -> n1k_status {
+        if (!c || !sender || !receiver || capacity_groups == 0) return N1K_INVALID;
+        n1k_status st = prepare_receiver(sender, receiver);
+        if (st != N1K_OK) return st == N1K_INVALID && sender->last_error.empty() ? fail(sender, st, "%s", receiver->last_error.c_str()) : st;
+        const size_t region = (size_t)n1k_partial_region_bytes(sender, capacity_groups);
+        const uint32_t nsend = gathered ? 1u : (uint32_t)c->world;
+        HIP_TRY(sender, c->send.ensure(region * nsend));
+        HIP_TRY(sender, c->recv.ensure(region * (size_t)c->world));
+        st = n1k_export_partials_async(sender, nsend, capacity_groups, c->send.p);
+        if (st != N1K_OK) return st;
+        if (gathered) {
+            // every rank ends with every rank's partial groups: no second collective for the result
+            NCCL_TRY(c, ncclAllGather(c->send.p, c->recv.p, region, ncclChar, c->comm, sender->stream));
+        } else {
+            const char* self = nullptr;
+            st = all_to_all_regions(c, c->send.p, c->recv.p, region, sender->stream, &self);
+            if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+            // (this rank's own region joins the received ones by a device copy of G groups, not through the fabric)
+            HIP_TRY(sender, hipMemcpyAsync(c->recv.p + (size_t)c->rank * region, self, region, hipMemcpyDeviceToDevice, sender->stream));
+        }
+        st = order_streams(c, sender, receiver);
+        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+        st = n1k_merge_partials_device(receiver, (uint32_t)c->world, capacity_groups, c->recv.p);
+        if (st != N1K_OK) return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, uint64_t capacity_rows) {
+    return guarded(sender, [&]() -> n1k_status {
+        if (!c || !sender || !receiver || !batch || capacity_rows == 0) return N1K_INVALID;
+        if (!sender->plan.has_group) return fail(sender, N1K_INVALID, "the row exchange partitions on group keys");
+        if (sender->stop_flag.load()) return fail(sender, N1K_STOPPED, "operator was stopped");
+        n1k_status st = ensure_device(sender);
+        if (st != N1K_OK) return st;
+        st = validate_batch(sender, batch);
+        if (st != N1K_OK) return st;
+        if (!sender->layout_fixed) {
+            st = fix_layout(sender, batch);
+            if (st != N1K_OK) return st;
+        }
+        st = prepare_receiver(sender, receiver);
+        if (st != N1K_OK) return st;
+        const uint64_t cap = (capacity_rows + 15) / 16 * 16;
+        std::vector<size_t> off_a, off_b;
+        const size_t region = row_region_layout(sender, cap, off_a, off_b);
+        const uint32_t P = (uint32_t)c->world;
+        HIP_TRY(sender, c->send.ensure(region * P));
+        HIP_TRY(sender, c->recv.ensure(region * P));
+        // 1. Filter + hash partition on the group key values into the packed regions (headers zeroed first)
+        for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * region, 0, 128, sender->stream));
+        Program& Pg = sender->prog;
+        st = bind_columns(sender, batch);
+        if (st != N1K_OK) return st;
+        st = ensure_rank(sender);
+        if (st != N1K_OK) return st;
+        PartArgs A{};
+        A.nrows = batch->nrows;
+        A.capacity = cap;
+        A.nparts = P;
+        A.ncopy = (uint32_t)sender->plan.paths.size();
+        A.counts = (unsigned long long*)c->send.p;
+        A.count_stride = (uint32_t)(region / 8);
+        A.region_bytes = region;
+        A.err_flags = sender->d_errp;
+        for (uint32_t i = 0; i < A.ncopy; i++) {
+            if (sender->col_kinds[i] == N1K_COL_DICT32) A.out_codes[i] = (uint32_t*)(c->send.p + off_a[i]);
+            else {
+                A.out_payload[i] = (uint64_t*)(c->send.p + off_a[i]);
+                A.out_tags[i] = (uint8_t*)(c->send.p + off_b[i]);
+            }
+        }
+        if (batch->nrows) {
+            const uint64_t ntiles = (batch->nrows + 2047) / 2048;
+            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)sender->num_cus * 4, ntiles));
+            hipEvent_t e0 = get_event(sender), e1 = get_event(sender);
+            if (e0) (void)hipEventRecord(e0, sender->stream);
+            HIP_TRY(sender, launch_partition(Pg, A, grid, sender->stream));
+            if (e1) (void)hipEventRecord(e1, sender->stream);
+            sender->events.emplace_back(e0, e1);
+        }
+        sender->stats.rows_in += batch->nrows;
+        sender->stats.batches += 1;
+        // 2. ONE all-to-all: counts, verdicts and rows of every column travel in the same region
+        const char* self = nullptr;
+        st = all_to_all_regions(c, c->send.p, c->recv.p, region, sender->stream, &self);
+        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+        st = order_streams(c, sender, receiver);
+        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+        // 3. the owner's InitialGroup over what it received: one batch per source, each with its row count on the device.
+        //    (Headers are checked first: a sender that overflowed voids the step on every rank.)
+        std::vector<const char*> src(P);
+        for (uint32_t sidx = 0; sidx < P; sidx++) src[sidx] = (int)sidx == c->rank ? self : c->recv.p + (size_t)sidx * region;
+        if (P > 1) {
+            // the headers live in two buffers (own region, received regions): gather them for the check
+            HIP_TRY(sender, c->scalar.ensure(2 * (size_t)P + 2));
+            for (uint32_t sidx = 0; sidx < P; sidx++)
+                HIP_TRY(receiver, hipMemcpyAsync(c->scalar.p + 2 * sidx, src[sidx], 16, hipMemcpyDeviceToDevice, receiver->stream));
+            HIP_TRY(receiver, launch_exchange_verdict(c->scalar.p, P, 2, receiver->d_errp, receiver->stream));
+        } else {
+            HIP_TRY(receiver, launch_exchange_verdict((unsigned long long*)src[0], 1, region / 8, receiver->d_errp, receiver->stream));
+        }
+        for (uint32_t sidx = 0; sidx < P; sidx++) {
+            const uint32_t rnc = (uint32_t)receiver->plan.paths.size();
+            std::vector<n1k_col> cols(std::max<size_t>(1, rnc));
+            for (uint32_t i = 0; i < rnc; i++) {
+                const int j = sender_column(sender, receiver->plan.paths[i]);  // (prepare_receiver checked that it exists)
+                cols[i].kind = sender->col_kinds[j];
+                if (cols[i].kind == N1K_COL_DICT32) cols[i].codes = (const uint32_t*)(src[sidx] + off_a[j]);
+                else {
+                    cols[i].payload = (const uint64_t*)(src[sidx] + off_a[j]);
+                    cols[i].tags = (const uint8_t*)(src[sidx] + off_b[j]);
+                }
+            }
+            n1k_batch rb{};
+            rb.nrows = cap;
+            rb.ncols = rnc;
+            rb.cols = cols.data();
+            receiver->push_nrows_dev = P > 1 ? c->scalar.p + 2 * sidx : (const unsigned long long*)src[sidx];
+            st = push_device(receiver, &rb);
+            receiver->push_nrows_dev = nullptr;
+            if (st != N1K_OK) return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
+        }
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_gather_groups(n1k_comm* c, n1k_handle* h, const n1k_result* local, n1k_result* out) {
+    return guarded(h, [&]() -> n1k_status {
+        if (!c || !h || !local || !out) return N1K_INVALID;
+        if (h->has_array_agg) return fail(h, N1K_UNSUPPORTED, "array_agg values are interned per rank: gather the rows on the host");
+        n1k_status st = ensure_device(h);
+        if (st != N1K_OK) return st;
+        const size_t nk = h->plan.keys.size(), na = h->plan.aggs.size();
+        const size_t rec = (nk + na) * sizeof(n1k_value);
+        // ONE all-gather of fixed-size slots [count][records]: the slot size is part of the collective's shape, so it is the
+        // same on every rank by construction — it starts at 1024 records and only ever changes on what ALL ranks read in
+        // the gathered headers (a count beyond the slot: everybody doubles to fit the largest and gathers again)
+        unsigned long long mine = local->ngroups;
+        std::vector<char> stage;
+        size_t slot = 0;
+        for (;;) {
+            const uint64_t capg = c->gather_cap;
+            slot = 16 + (size_t)capg * rec;
+            stage.assign(slot, 0);
+            memcpy(stage.data(), &mine, 8);
+            for (uint64_t g = 0; g < std::min<uint64_t>(local->ngroups, capg); g++) {
+                char* p = stage.data() + 16 + (size_t)g * rec;
+                if (nk) memcpy(p, local->keys + g * nk, nk * sizeof(n1k_value));
+                if (na) memcpy(p + nk * sizeof(n1k_value), local->aggs + g * na, na * sizeof(n1k_value));
+            }
+            HIP_TRY(h, c->gsend.ensure(slot));
+            HIP_TRY(h, c->grecv.ensure(slot * (size_t)c->world));
+            HIP_TRY(h, hipMemcpyAsync(c->gsend.p, stage.data(), slot, hipMemcpyHostToDevice, h->stream));
+            NCCL_TRY(c, ncclAllGather(c->gsend.p, c->grecv.p, slot, ncclChar, c->comm, h->stream));
+            c->ghost.resize(slot * (size_t)c->world);
+            HIP_TRY(h, hipMemcpyAsync(c->ghost.data(), c->grecv.p, c->ghost.size(), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            unsigned long long most = 0;
+            for (int r = 0; r < c->world; r++) {
+                unsigned long long n = 0;
+                memcpy(&n, c->ghost.data() + (size_t)r * slot, 8);
+                most = std::max(most, n);
+            }
+            if (most <= capg) break;
+            while (c->gather_cap < most) c->gather_cap *= 2;
+        }
+        // 3. the union, in rank order; the plan's grouped tail (ORDER BY / OFFSET / LIMIT, projection) over it
+        c->gkeys.clear();
+        c->gaggs.clear();
+        for (int r = 0; r < c->world; r++) {
+            const char* base = c->ghost.data() + (size_t)r * slot;
+            unsigned long long n = 0;
+            memcpy(&n, base, 8);
+            for (unsigned long long g = 0; g < n; g++) {
+                const n1k_value* v = (const n1k_value*)(base + 16 + (size_t)g * rec);
+                c->gkeys.insert(c->gkeys.end(), v, v + nk);
+                c->gaggs.insert(c->gaggs.end(), v + nk, v + nk + na);
+            }
+        }
+        const uint64_t total = nk ? c->gkeys.size() / nk : (na ? c->gaggs.size() / na : 0);
+        return n1k_order_rows(h, total, c->gkeys.data(), c->gaggs.data(), out);
     });
 }
 

@@ -810,7 +810,8 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
     uint32_t unsupported = 0, unpackable = 0;
     unsigned long long selected = 0;
     const uint64_t tile_rows = (uint64_t)BLOCK * R;
-    const uint64_t ntiles = (A.nrows + tile_rows - 1) / tile_rows;
+    const uint64_t nrows = A.nrows_dev && *A.nrows_dev < A.nrows ? *A.nrows_dev : A.nrows;
+    const uint64_t ntiles = (nrows + tile_rows - 1) / tile_rows;
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t row[R];
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(BLOCK) void scan_group_kernel(const Program P, cons
 #pragma unroll
         for (int j = 0; j < R; j++) {
             row[j] = tile * tile_rows + (uint64_t)j * BLOCK + tid;
-            valid[j] = row[j] < A.nrows;
+            valid[j] = row[j] < nrows;
         }
         eval_predicate<R>(P, row, valid, pass, unsupported);
 
@@ -1352,7 +1353,7 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
         __syncthreads();
         for (uint32_t d = tid; d < A.nparts; d += BLOCK) {
             uint32_t n = s_cnt[d];
-            s_base[d] = n ? atomicAdd(&A.counts[d], (unsigned long long)n) : 0ull;
+            s_base[d] = n ? atomicAdd(&A.counts[(size_t)d * (A.count_stride ? A.count_stride : 1u)], (unsigned long long)n) : 0ull;
         }
         __syncthreads();
 #pragma unroll
@@ -1360,10 +1361,12 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
             if (!pass[j]) continue;
             uint64_t r = s_base[dest[j]] + pos[j];
             if (r >= A.capacity) {
-                atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                if (!(atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL) & ERR_TABLE_FULL) && A.region_bytes)
+                    for (uint32_t q = 0; q < A.nparts; q++)  // every receiver reads the verdict in the header it gets
+                        atomicOr(&A.counts[(size_t)q * A.count_stride + 1], 1ull);
                 pass[j] = false;
             }
-            pos[j] = (uint64_t)dest[j] * A.capacity + r;
+            pos[j] = A.region_bytes ? r : (uint64_t)dest[j] * A.capacity + r;
         }
         __syncthreads();
         for (uint32_t d = tid; d < A.nparts; d += BLOCK) s_cnt[d] = 0;
@@ -1378,11 +1381,12 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 if (!pass[j]) continue;
+                const size_t shift = (size_t)dest[j] * A.region_bytes;  // (0 without packed regions)
                 if (P.cols[c].kind == COLK_DICT32) {
-                    A.out_codes[c][pos[j]] = (uint32_t)vp[j];
+                    ((uint32_t*)((char*)A.out_codes[c] + shift))[pos[j]] = (uint32_t)vp[j];
                 } else {
-                    A.out_tags[c][pos[j]] = (uint8_t)vt[j];
-                    A.out_payload[c][pos[j]] = vp[j];
+                    ((uint8_t*)((char*)A.out_tags[c] + shift))[pos[j]] = (uint8_t)vt[j];
+                    ((uint64_t*)((char*)A.out_payload[c] + shift))[pos[j]] = vp[j];
                 }
             }
         }
@@ -2636,6 +2640,21 @@ hipError_t launch_arith(const ArithArgs& A, hipStream_t st) {
     if (A.nrows == 0) return hipSuccess;
     uint32_t blocks = (uint32_t)((A.nrows + 255) / 256);
     hipLaunchKernelGGL(arith_kernel, dim3(blocks), dim3(256), 0, st, A);
+    return hipGetLastError();
+}
+
+// Received row regions ([count][verdict]... per source): a sender whose region overflowed said so in every header — the
+// receiver then aggregates nothing (all counts to zero) and its n1k_finish reports it, on every rank alike.
+__global__ void exchange_verdict_kernel(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint32_t* err_flags) {
+    unsigned long long v = 0;
+    for (uint32_t r = 0; r < nregions; r++) v |= headers[(size_t)r * stride_words + 1];
+    if (!v) return;
+    atomicOr(err_flags, (uint32_t)ERR_EXCHANGE_OVERFLOW);
+    for (uint32_t r = threadIdx.x; r < nregions; r += blockDim.x) headers[(size_t)r * stride_words] = 0;
+}
+
+hipError_t launch_exchange_verdict(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint32_t* err_flags, hipStream_t st) {
+    hipLaunchKernelGGL(exchange_verdict_kernel, dim3(1), dim3(64), 0, st, headers, nregions, stride_words, err_flags);
     return hipGetLastError();
 }
 

@@ -421,7 +421,10 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     __syncthreads();
 
     uint32_t unpackable = 0, selected = 0;
-    const uint32_t nitems = WIDE ? F.nrows / 2u : F.nrows;  // the engine passes an even row count to WIDE launches
+    // (the engine passes an even row count to WIDE launches; a row count that lives on the device may be odd: the second
+    //  row of the last item is then masked)
+    const uint32_t nrows = F.nrows_dev ? (uint32_t)(*F.nrows_dev < (unsigned long long)F.nrows ? *F.nrows_dev : F.nrows) : F.nrows;
+    const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
     const uint32_t tile = BLOCK * R;
 
     for (uint32_t base = blockIdx.x * tile; base < nitems; base += gridDim.x * tile) {
@@ -482,7 +485,8 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
                 uint32_t bins[kSpecDistinct];
 #pragma unroll
                 for (int d = 0; d < (int)kSpecDistinct; d++) { words[d] = kEmptyKey; bins[d] = 0; }
-                if (valid[j]) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins);
+                const bool row_ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nrows);
+                if (row_ok) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins);
 #pragma unroll
                 for (int d = 0; d < (int)kSpecDistinct; d++) { mw[d][j * (int)kRowsPerItem + h] = words[d]; mb[d][j * (int)kRowsPerItem + h] = bins[d]; }
             }

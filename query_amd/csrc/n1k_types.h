@@ -204,6 +204,7 @@ struct ScanArgs {
     uint32_t dcache_slots;  // per DISTINCT aggregate: slots (power of two) of the workgroup's "already logged" cache, 0 = none
     uint32_t dcache_aggs;   // number of such caches (== DISTINCT aggregates of the plan)
     unsigned long long* word_hist;  // kMaxDistinct x 256 counters: first radix digit of the logged words (n1k_finish's first pass)
+    const unsigned long long* nrows_dev;  // see FastArgs::nrows_dev
 };
 
 // COUNT(DISTINCT) inside the plan-specialised scan (n1k_spec.h): the member words of aggregate d are scattered by the
@@ -358,6 +359,9 @@ struct FastArgs {
     unsigned long long* rows_selected;
     uint64_t* slabs;  // when non-null: workgroup b stores its LDS table at slabs[b * lds_words * S ..] instead of merging
     unsigned long long* block_selected;  // with slabs: per-workgroup survivor counts (summed by the merge kernel)
+    // when non-null: the batch really holds min(nrows, *nrows_dev) rows (a region received from another GPU: its row count
+    // arrived with it and never visits the host)
+    const unsigned long long* nrows_dev;
 };
 
 // derived columns: arithmetic nodes of the plan are evaluated once per batch by an element-wise kernel into a
@@ -379,7 +383,14 @@ struct PartArgs {
     uint64_t nrows;
     uint64_t capacity;  // rows per destination region
     uint32_t nparts, ncopy;      // ncopy: number of (input) columns shipped
-    unsigned long long* counts;  // nparts counters (rows written per destination)
+    unsigned long long* counts;  // nparts counters (rows written per destination), count_stride words apart
+    // Packed regions (n1k_exchange_rows): destination d's rows of every column live inside ONE region of region_bytes
+    // bytes (so that one send per peer moves them): out_* then point at the column's place inside region 0 and row r of
+    // destination d is element r of the array that starts d * region_bytes further on.  0 = one array per column with
+    // `capacity` rows per destination.  With regions the count sits in the region header ([count][verdict]), and an
+    // overflow raises verdict bit 0 in EVERY region (each receiver learns it from the exchange itself).
+    uint64_t region_bytes;
+    uint32_t count_stride, pad0;
     uint32_t* err_flags;
     uint8_t* out_tags[kMaxCols];
     uint64_t* out_payload[kMaxCols];

@@ -1,18 +1,21 @@
-"""Multi-GPU Filter -> Group -> Aggregate: one process per GPU, torch.distributed over RCCL/xGMI.
+"""Multi-GPU Filter -> Group -> Aggregate: one process per GPU; the collectives run inside libn1k.so (RCCL over xGMI).
 
 The reference has no distributed query path (README.md:61-65); inside one process it fans Parallel copies into
-one serial IntermediateGroup through an in-memory queue (execution/exchange.go:161-251).  Here every rank
+one serial IntermediateGroup through an in-memory queue (execution/exchange.go:161-251).  Here every rank holds a row
+shard and the ranks meet in ONE exchange step, behind the C ABI (include/n1k.h, "multi-GPU"):
 
-  1. filters its own row shard and hash-partitions the survivors on the group key
-     (n1k_partition_device_batch: hash(key) % world, one region per destination rank),
-  2. exchanges the regions with ONE all-to-all per column buffer (RCCL all_to_all_single with split sizes; on an
-     8-GPU node every GPU pair has its own xGMI link, so all 7 links of a GPU carry traffic at once),
-  3. runs InitialGroup/FinalGroup on the rows it received (it owns those groups entirely, so no partial states
-     cross the fabric and COUNT(DISTINCT) needs no set merge),
-  4. gathers the finished groups on rank 0 (the only serial step, G rows).
+  * n1k_exchange_rows      Filter + hash partition of the survivors on the group key into one packed region per
+                           destination, ONE all-to-all (counts, verdicts and every column's rows travel together),
+                           InitialGroup .. FinalGroup on the owner: a group lives on exactly one rank, COUNT(DISTINCT)
+                           needs no set merge;
+  * n1k_exchange_partials  every rank aggregates its shard first and only the partial groups travel — all-gathered
+                           (every rank merges all of them and holds the result) or hash-partitioned to owners;
+  * n1k_gather_groups      the owners' finished groups to every rank, then the plan's ORDER BY / LIMIT over the union.
 
-The exchange code is backend-agnostic (it moves torch tensors with all_to_all_single / all_gather), so the same
-functions run under gloo on CPU tensors in tests/test_distributed_cpu.py.
+This module is the thin Python caller (bench.py, tests): torch.distributed only carries the communicator id at start-up
+and the bench's barriers — no row and no group crosses it.  The functions at the top (exchange_counts, exchange_rows,
+gather_groups, FixedGather) are the same protocol spelt with torch collectives, so that it can be rehearsed under gloo
+on CPU tensors (tests/test_distributed_cpu.py, world_size 2); the GPU path does not use them.
 """
 from __future__ import annotations
 
@@ -116,237 +119,194 @@ class FixedGather:
             self.capacity = int(2 ** int(np.ceil(np.log2(counts.max()))))
 
 
+class Comm:
+    """n1k_comm: one per rank.  The id travels through torch.distributed (bootstrap only)."""
+
+    def __init__(self, rank: int, world: int, device: int):
+        import torch
+        import torch.distributed as dist
+        from query_amd import _ffi
+        self._lib = _ffi.lib()
+        dev = torch.device("cuda", device)
+        ident = torch.zeros(_ffi.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * _ffi.COMM_ID_BYTES)()
+            st = self._lib.n1k_comm_unique_id(buf)
+            if st != 0:
+                raise RuntimeError("n1k_comm_unique_id failed: %d" % st)
+            ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+        ident = ident.to(dev)
+        if world > 1:
+            dist.broadcast(ident, src=0)
+        raw = bytes(ident.cpu().numpy().tobytes())
+        self._h = C.c_void_p()
+        st = self._lib.n1k_comm_create(raw, rank, world, device, C.byref(self._h))
+        if st != 0:
+            raise RuntimeError("n1k_comm_create failed: %s" % (self._lib.n1k_comm_last_error(None) or b"").decode())
+        self.rank, self.world = rank, world
+
+    def done(self):
+        if self._h:
+            self._lib.n1k_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.done()
+        except Exception:
+            pass
+
+
 class ShardedFilterGroup:
-    """One rank's share of the distributed operator (device path through libn1k.so)."""
+    """One rank's share of the distributed operator: a sender handle (Filter + InitialGroup over the shard), a receiver
+    handle (the same grouping without the Filter: it merges partial groups or aggregates received rows, applies HAVING
+    and keeps its first offset+limit rows), and a merger handle that carries the exact grouped tail over the union."""
 
     def __init__(self, condition: Optional[str], keys: Sequence[str], aggs: Sequence[str], dictionary: Sequence[bytes],
-                 rank: int, world: int, device: int, order=None, limit=None, offset=None, having=None, **options):
+                 rank: int, world: int, device: int, order=None, limit=None, offset=None, having=None, comm: Optional[Comm] = None,
+                 **options):
         import query_amd
         from query_amd import plan
         self.rank, self.world, self.device = rank, world, device
+        self.comm = comm if comm is not None else Comm(rank, world, device)
         self.tail = order is not None or limit is not None or offset is not None or having is not None
-        # sender: Filter + key evaluation; receiver: the same grouping without the Filter (it was applied already)
-        import torch
-        # one stream for both handles and for torch (RCCL work is ordered against it by c10d's events)
-        self.stream = torch.cuda.Stream(device=torch.device("cuda", device))
-        self.sender = query_amd.GpuFilterGroup(plan.filter_group_plan(condition, keys, aggs), device=device,
-                                               stream=self.stream.cuda_stream)
-        # The grouped tail (HAVING, ORDER BY, OFFSET, LIMIT) belongs to whoever holds COMPLETE groups: `receiver` is the
-        # owner of a hash range (row / partial-group exchange) and keeps its first offset+limit rows after HAVING;
-        # `merger` holds the exact tail: it merges all ranks' partial groups in the gathered mode, and orders the
-        # union of the owners' rows otherwise (n1k_order_rows).
+        self.sender = query_amd.GpuFilterGroup(plan.filter_group_plan(condition, keys, aggs), device=device)
         owner_limit = None if limit is None else int(limit) + int(offset or 0)
         self.receiver = query_amd.GpuFilterGroup(
             plan.filter_group_plan(None, keys, aggs, order=order, limit=owner_limit, having=having) if self.tail
-            else plan.filter_group_plan(None, keys, aggs), device=device, stream=self.stream.cuda_stream, **options)
+            else plan.filter_group_plan(None, keys, aggs), device=device, **options)
         self.merger = query_amd.GpuFilterGroup(
             plan.filter_group_plan(None, keys, aggs, order=order, limit=limit, offset=offset, having=having),
-            device=device, stream=self.stream.cuda_stream, **options) if self.tail else self.receiver
-        self._recv_ready = set()
-        self._sbatch = None
-        self._cap_known = False
-        self._gather = None
-        self.sender.intern(list(dictionary))
-        self.receiver.intern(list(dictionary))
-        if self.merger is not self.receiver:
-            self.merger.intern(list(dictionary))
+            device=device, **options) if self.tail else self.receiver
+        for h in {id(self.sender): self.sender, id(self.receiver): self.receiver, id(self.merger): self.merger}.values():
+            h.intern(list(dictionary))
         self.send_paths = self.sender.column_paths
-        self.recv_paths = self.receiver.column_paths
-        self._bufs = None
         self.has_distinct = any("(distinct " in a.lower() for a in aggs)
-        self.partial_capacity = int(options.get("partial_capacity", 4096)) if options else 4096
-        self._pbuf = None
+        self.partial_capacity = None  # groups per region: agreed on in the first step
+        self.row_capacity = None      # rows per region
+        self._sbatch = None
+
+    GATHER_LIMIT = 32 << 20  # partial groups of ALL ranks within this many bytes per rank: all-gather them
+
+    def _batch(self, nrows: int, cols_by_path: Dict[str, tuple]):
+        if self._sbatch is None or self._sbatch[0] is not cols_by_path or self._sbatch[1] != nrows:
+            self._sbatch = (cols_by_path, nrows, self.sender.make_device_batch(nrows, [cols_by_path[p] for p in self.send_paths]))
+        return self._sbatch[2]
+
+    def _max(self, handle, value: int) -> int:
+        out = C.c_uint64()
+        handle._check(handle._lib.n1k_comm_max_u64(self.comm._h, handle._h, int(value), C.byref(out)))
+        return int(out.value)
 
     # ------------------------------------------------------------------ exchange of partial groups
-    # partial groups of ALL ranks fit this many bytes per rank -> gather them instead of partitioning them
-    GATHER_LIMIT = 32 << 20
-
-    def run_gathered(self, nrows: int, cols_by_path: Dict[str, tuple], want_rows_selected: bool = True) -> Tuple[dict, dict]:
-        """Few groups: every rank aggregates its shard, ONE all_gather moves the per-GPU partial groups and every
-        rank merges all of them (≙ IntermediateGroup + FinalGroup, replicated): each rank ends with the complete
-        result, so no second collective is needed.  Falls over to the hash-partitioned exchange (run_partials) when
-        world x region outgrows GATHER_LIMIT."""
-        return self.run_partials(nrows, cols_by_path, want_rows_selected, replicate=True)
-
-    def run_partials(self, nrows: int, cols_by_path: Dict[str, tuple], want_rows_selected: bool = True,
-                     replicate: bool = False) -> Tuple[dict, dict]:
-        """Few groups next to rows: aggregate the local shard first (same kernels as on one GPU), then move only
-        the partial groups: ONE all_to_all_single of fixed-size regions, hash-partitioned on the group key, merged
-        by the owner (≙ IntermediateGroup) and finalised there.
-
-        The whole step is stream-ordered — scan, export, all-to-all, merge, finalize — with a single host
-        synchronisation at the end (n1k_finish's copy of the groups).  A sender that cannot export (a region
-        overflowed; keys coded by device-local value tables) says so in every region header, the merge on each
-        receiver then does nothing and n1k_finish reports it: all ranks take the same retry branch without an
-        extra collective."""
-        import torch
-        import torch.distributed as dist
+    def run_partials(self, nrows: int, cols_by_path: Dict[str, tuple], replicate: bool = False) -> Tuple[dict, dict]:
+        """Every rank aggregates its shard (the single-GPU kernels), then n1k_exchange_partials moves the partial groups:
+        one all-gather (replicate and few groups) or one all-to-all of hash-partitioned regions; the receiver merges and
+        n1k_finish is the step's one wait.  A region that overflows fails the step on every rank alike: retry x4."""
         from query_amd import _ffi
         from query_amd.gpu_operator import N1kError
-        snd = self.sender  # Filter + InitialGroup over the shard
-        lib = snd._lib
-        dev = torch.device("cuda", self.device)
-        with torch.cuda.stream(self.stream):
-            while True:
-                cap = self.partial_capacity
-                region = int(lib.n1k_partial_region_bytes(snd._h, cap))
-                # the same on every rank: capacities only change on verdicts that all ranks see
-                gathered = replicate and region * self.world <= self.GATHER_LIMIT
-                rcv = self.merger if gathered else self.receiver  # merge + FinalGroup (+ the grouped tail)
-                if id(rcv) not in self._recv_ready:  # the merging handle needs the key layout (column kinds) first
-                    rcv.process_device_items(0, [cols_by_path[p] for p in self.recv_paths])
-                    self._recv_ready.add(id(rcv))
-                nsend = 1 if gathered else self.world
-                if self._pbuf is None or self._pbuf[0].numel() != region * nsend or self._pbuf[1].numel() != region * self.world:
-                    self._pbuf = (torch.empty(region * nsend, dtype=torch.uint8, device=dev),
-                                  torch.empty(region * self.world, dtype=torch.uint8, device=dev))
-                send, recv = self._pbuf
-                snd.reopen()
-                if self._sbatch is None or self._sbatch[0] is not cols_by_path or self._sbatch[1] != nrows:
-                    # the n1k_batch of a shard that stays where it is (same dict object, same rows) is built once
-                    self._sbatch = (cols_by_path, nrows, snd.make_device_batch(nrows, [cols_by_path[p] for p in self.send_paths]))
-                snd.process_device_batch(self._sbatch[2])
-                if not self._cap_known:
-                    # first step: size the regions from the number of groups the shards really hold (one small
-                    # all-reduce) instead of climbing there by x4 retries that each repeat the scan
-                    snd.sync()
-                    ng = torch.tensor([int(snd.stats()["groups_out"])], dtype=torch.int64, device=dev)
-                    dist.all_reduce(ng, op=dist.ReduceOp.MAX)
-                    ng = int(ng.item())
-                    self._cap_known = True
-                    full = 1 << max(12, int(np.ceil(np.log2(ng * 1.25 + 64))))
-                    if replicate and int(lib.n1k_partial_region_bytes(snd._h, full)) * self.world <= self.GATHER_LIMIT:
-                        want = full
-                    else:
-                        want = 1 << max(12, int(np.ceil(np.log2(ng / self.world * 1.5 + 64))))
-                    if want != cap:
-                        self.partial_capacity = want
-                        continue
-                snd._check(lib.n1k_export_partials_async(snd._h, nsend, cap, send.data_ptr()))
-                if gathered:
-                    dist.all_gather_into_tensor(recv, send)  # region r = rank r's partial groups, on every rank
+        snd, lib = self.sender, self.sender._lib
+        while True:
+            snd.reopen()
+            snd.process_device_batch(self._batch(nrows, cols_by_path))
+            if self.partial_capacity is None:
+                snd.sync()  # first step only: size the regions from the groups the shards really hold
+                ng = self._max(snd, int(snd.stats()["groups_out"]))
+                full = 1 << max(10, int(np.ceil(np.log2(ng * 1.25 + 64))))
+                if replicate and int(lib.n1k_partial_region_bytes(snd._h, full)) * self.world <= self.GATHER_LIMIT:
+                    self.partial_capacity = full
                 else:
-                    dist.all_to_all_single(recv, send)  # equal splits: region d goes to rank d
-                rcv.reopen()
-                rcv._check(lib.n1k_merge_partials_device(rcv._h, self.world, cap, recv.data_ptr()))
-                try:
-                    raw = rcv.after_items_raw()  # the step's one host synchronisation
-                except N1kError as e:
-                    if e.status == _ffi.OOM and "region" in e.message:
-                        self.partial_capacity *= 4
-                        continue
-                    if e.status == _ffi.UNSUPPORTED:
-                        snd.reopen()  # drop the abandoned export's groups and flags
-                        raw, info = self.run(nrows, cols_by_path)
-                        info["mode"] = "rows (wide key values)"
-                        return raw, info
-                    raise
-                break
-            if want_rows_selected:
-                snd.sync()  # one more small copy: the Filter's survivor count lives in the sender's counters
-            stats = snd.stats()  # scan time from the completed HIP events (no waiting)
-        return raw, {"mode": "gathered partials" if gathered else "partials", "region_bytes": region,
-                     "rows_selected": int(stats["rows_selected"]) if want_rows_selected else None,
-                     "scan_ms": float(stats["device_ms"]), "spec_kernel": int(stats["spec_kernel"])}
+                    self.partial_capacity = 1 << max(10, int(np.ceil(np.log2(ng / self.world * 1.5 + 64))))
+            cap = self.partial_capacity
+            region = int(lib.n1k_partial_region_bytes(snd._h, cap))
+            gathered = replicate and region * self.world <= self.GATHER_LIMIT
+            rcv = self.merger if gathered else self.receiver
+            rcv.reopen()
+            snd._check(lib.n1k_exchange_partials(self.comm._h, snd._h, rcv._h, cap, 1 if gathered else 0))
+            try:
+                raw = rcv.after_items_raw()
+            except N1kError as e:
+                if e.status == _ffi.OOM and "region" in e.message:
+                    self.partial_capacity *= 4
+                    continue
+                if e.status == _ffi.UNSUPPORTED:  # wide key values are coded per handle: such groups travel as rows
+                    raw, info = self.run_rows(nrows, cols_by_path)
+                    info["mode"] = "rows (wide key values)"
+                    return raw, info
+                raise
+            break
+        stats = snd.stats()
+        info = {"mode": "gathered partials" if gathered else "partials", "region_bytes": region,
+                "scan_ms": float(stats["device_ms"]), "spec_kernel": int(stats["spec_kernel"])}
+        return (raw, info) if gathered else (self._gather(rcv, raw), info)
 
-    def combine(self, raw: dict, info: dict, device) -> Tuple[np.ndarray, np.ndarray]:
-        """The job's result on every rank as (keys, aggs) structured arrays: in the gathered mode the merging handle
-        already holds it; otherwise the owners' rows are gathered (one all-gather) and, when the plan has a grouped
-        tail, ordered and cut by the merger handle (n1k_order_rows)."""
+    def run_gathered(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
+        return self.run_partials(nrows, cols_by_path, replicate=True)
+
+    # ------------------------------------------------------------------ exchange of rows
+    def run_rows(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
+        """n1k_exchange_rows: Filter + hash partition + ONE all-to-all + InitialGroup on the owner, then the gather.  The
+        first step ships regions sized for the whole shard; later steps for what the owners really received (+ 30 %)."""
+        from query_amd import _ffi
+        from query_amd.gpu_operator import N1kError
+        snd, rcv, lib = self.sender, self.receiver, self.sender._lib
+        batch = self._batch(nrows, cols_by_path)
+        while True:
+            cap = self.row_capacity if self.row_capacity is not None else max(4096, int(nrows * 1.1 / self.world) + 4096)
+            rcv.reopen()
+            snd.reopen()  # (the sender holds no groups in this mode; its counters and timers start over)
+            snd._check(lib.n1k_exchange_rows(self.comm._h, snd._h, C.byref(batch[0]), rcv._h, cap))
+            try:
+                raw = rcv.after_items_raw()
+            except N1kError as e:
+                if e.status == _ffi.OOM and "region" in e.message:
+                    self.row_capacity = cap * 2
+                    continue
+                raise
+            break
+        if self.row_capacity is None:
+            got = self._max(rcv, int(rcv.stats()["rows_selected"]))
+            self.row_capacity = min(cap, max(4096, int(got / self.world * 1.3) + 4096)) if self.world > 1 else max(4096, int(got * 1.02) + 4096)
+        stats = snd.stats()
+        return self._gather(rcv, raw), {"mode": "rows", "region_rows": cap, "scan_ms": float(stats["device_ms"]),
+                                        "recv_rows": int(rcv.stats()["rows_selected"])}
+
+    def _gather(self, rcv, raw: dict) -> dict:
+        """n1k_gather_groups: the owners' finished groups on every rank, the grouped tail applied over the union."""
+        from query_amd import _ffi
         from query_amd.gpu_operator import GpuFilterGroup
-        if info.get("mode") == "gathered partials":
-            return raw["keys"], raw["aggs"]
-        nk, na, ng = raw["nkeys"], raw["naggs"], raw["ngroups"]
-        rec = np.concatenate([raw["keys"].view(np.uint8).reshape(ng, -1), raw["aggs"].view(np.uint8).reshape(ng, -1)], axis=1) \
-            if ng else np.zeros((0, 16 * (nk + na)), np.uint8)
-        if self._gather is None:
-            self._gather = FixedGather(16 * (nk + na))  # capacity agreed on across the ranks at the first call
-        allg = np.ascontiguousarray(self._gather(rec, device))
-        n = allg.shape[0]
         dt = GpuFilterGroup._VALUE_DT
-        keys = np.ascontiguousarray(allg[:, :16 * nk]).view(dt).reshape(n, nk)
-        aggs = np.ascontiguousarray(allg[:, 16 * nk:]).view(dt).reshape(n, na)
-        if self.tail:
-            r = self.merger.order_rows(keys, aggs)
-            return r["keys"], r["aggs"]
-        return keys, aggs
+        ng, nk, na = raw["ngroups"], raw["nkeys"], raw["naggs"]
+        keys = np.ascontiguousarray(raw["keys"]) if nk else np.zeros((ng, 0), dt)
+        aggs = np.ascontiguousarray(raw["aggs"]) if na else np.zeros((ng, 0), dt)
+        local = _ffi.Result()
+        local.ngroups, local.nkeys, local.naggs = ng, nk, na
+        local.keys = C.cast(keys.ctypes.data, C.POINTER(_ffi.Value)) if keys.size else None
+        local.aggs = C.cast(aggs.ctypes.data, C.POINTER(_ffi.Value)) if aggs.size else None
+        out = _ffi.Result()
+        m = self.merger
+        m._check(m._lib.n1k_gather_groups(self.comm._h, m._h, C.byref(local), C.byref(out)))
+        n = int(out.ngroups)
 
-    def _alloc(self, capacity: int, kinds: Sequence[int]):
-        import torch
-        from query_amd import _ffi
-        dev = torch.device("cuda", self.device)
-        bufs = []
-        for k in kinds:
-            if k == _ffi.COL_DICT32:
-                bufs.append({"codes": torch.empty(capacity * self.world, dtype=torch.int32, device=dev)})
-            else:
-                bufs.append({"tags": torch.empty(capacity * self.world, dtype=torch.uint8, device=dev),
-                             "payload": torch.empty(capacity * self.world, dtype=torch.int64, device=dev)})
-        counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
-        return bufs, counts
+        def arr(ptr, count):
+            if not count or not ptr:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer(bytearray(C.string_at(ptr, count * dt.itemsize)), dtype=dt)
 
-    def run(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
-        """cols_by_path: path -> (kind, tags_ptr, payload_ptr, codes_ptr) device addresses of this rank's shard.
-        Returns (local final groups as numpy record arrays, timing/volume info)."""
-        import torch
-        with torch.cuda.stream(self.stream):
-            return self._run_rows(nrows, cols_by_path)
+        return {"ngroups": n, "nkeys": nk, "naggs": na,
+                "keys": arr(out.keys, n * nk).reshape(n, nk) if nk else np.zeros((n, 0), dt),
+                "aggs": arr(out.aggs, n * na).reshape(n, na) if na else np.zeros((n, 0), dt)}
 
-    def _run_rows(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
-        import torch
-        import torch.distributed as dist
-        from query_amd import _ffi
-        cols = [cols_by_path[p] for p in self.send_paths]
-        kinds = [c[0] for c in cols]
-        if self._bufs is None or self._bufs[2] < nrows:
-            self._bufs = self._alloc(nrows, kinds) + (nrows,)
-        bufs, counts, cap = self._bufs
-        # 1. filter + hash partition on the group key
-        batch, keep = self.sender._make_batch(nrows, cols)
-        out_arr = (_ffi.Col * len(cols))()
-        for i, (k, b) in enumerate(zip(kinds, bufs)):
-            out_arr[i].kind = k
-            if k == _ffi.COL_DICT32:
-                out_arr[i].codes = b["codes"].data_ptr()
-            else:
-                out_arr[i].tags = b["tags"].data_ptr()
-                out_arr[i].payload = b["payload"].data_ptr()
-        torch.cuda.synchronize()
-        st = self.sender._lib.n1k_partition_device_batch(self.sender._h, C.byref(batch), self.world, cap, out_arr,
-                                                        counts.data_ptr())
-        self.sender._check(st)
-        # 2. all-to-all over xGMI: counts, then one collective per column buffer
-        recv_counts = exchange_counts(counts)
-        sc = counts.cpu().tolist()
-        rc = recv_counts.cpu().tolist()
-        send_cols, layout = [], []
-        for k, b in zip(kinds, bufs):
-            for name in (("codes",) if k == _ffi.COL_DICT32 else ("tags", "payload")):
-                t = b[name]
-                send_cols.append(torch.cat([t[d * cap: d * cap + sc[d]] for d in range(self.world)]))
-                layout.append(name)
-        recv = exchange_rows(send_cols, sc, rc)
-        # 3. local InitialGroup .. FinalGroup on the rows this rank owns
-        received = {}
-        it = iter(recv)
-        for p, k in zip(self.send_paths, kinds):
-            if k == _ffi.COL_DICT32:
-                t = next(it)
-                received[p] = (k, None, None, t.data_ptr(), t)
-            else:
-                tg, pl = next(it), next(it)
-                received[p] = (k, tg.data_ptr(), pl.data_ptr(), None, (tg, pl))
-        nrecv = int(sum(rc))
-        self.receiver.reopen()
-        torch.cuda.synchronize()
-        self.receiver.process_device_items(nrecv, [received[p][:4] for p in self.recv_paths])
-        raw = self.receiver.after_items_raw()
-        info = {"sent_rows": int(sum(sc)), "recv_rows": nrecv}
-        return raw, info
+    def done(self):
+        for h in (self.sender, self.receiver, self.merger):
+            h.done()
+        self.comm.done()
 
 
 def bench_main(args, rank: int, world: int, local_rank: int):
-    """bench.py --gpus N (N > 1): weak scaling, every rank owns `--rows` rows of the global data set."""
+    """bench.py --gpus N (N > 1, or --force-dist): the hot path sharded over N ranks.  Weak scaling by default (every rank
+    owns --rows rows of one global synthetic data set); --total-rows T = strong scaling (T rows in all: config 4 is
+    100 M, config 5 is 1 B over 8 GPUs)."""
     import torch
     import torch.distributed as dist
     import bench
@@ -355,44 +315,46 @@ def bench_main(args, rank: int, world: int, local_rank: int):
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # bootstrap + the bench's barriers only
     wl = bench.workloads()[args.workload]
-    total_rows = args.rows * world
-    cols = bench.DeviceColumns(args.rows, args.kcat, bool(args.zipf), rank * args.rows, total_rows, local_rank)
+    strong = bool(args.total_rows)
+    total_rows = args.total_rows if strong else args.rows * world
+    first = total_rows * rank // world
+    rows = total_rows * (rank + 1) // world - first
+    cols = bench.DeviceColumns(rows, args.kcat, bool(args.zipf), first, total_rows, local_rank)
     op = ShardedFilterGroup(wl["cond"], wl["keys"], wl["aggs"], bench.synth_dictionary(args.kcat), rank, world,
                             local_rank, order=wl.get("order"), limit=wl.get("limit"))
     dev = torch.device("cuda", local_rank)
+    mode = args.exchange
+    if mode == "auto":  # the configuration north_star names: rows hash-partitioned on the group key by one all-to-all
+        mode = "rows"
 
-    def step(last=False):
-        if op.has_distinct or args.exchange == "rows":
-            raw, info = op.run(args.rows, cols.by_path)
-        elif args.exchange == "partials":
-            raw, info = op.run_partials(args.rows, cols.by_path, want_rows_selected=last)
-        else:
-            raw, info = op.run_gathered(args.rows, cols.by_path, want_rows_selected=last)
-        keys, _aggs = op.combine(raw, info, dev)  # every rank holds the job's result; rank 0 reports it
-        return keys, info
+    def step():
+        if op.has_distinct or mode == "rows":
+            return op.run_rows(rows, cols.by_path)
+        if mode == "partials":
+            return op.run_partials(rows, cols.by_path)
+        return op.run_gathered(rows, cols.by_path)
 
     for _ in range(args.warmup):
-        allg, info = step()
+        res, info = step()
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        allg, info = step(last=(i == args.steps - 1))
+        res, info = step()
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     if rank == 0:
-        mode = info.get("mode", "rows")
-        how = ("per-GPU partial groups merged after ONE RCCL all-gather (every rank holds the result)" if mode == "gathered partials"
-               else "partial groups hash-partitioned on the group key by RCCL all-to-all, final groups gathered on rank 0"
-               if mode == "partials" else
-               "filtered rows hash-partitioned on the group key by RCCL all-to-all, final groups gathered on rank 0")
+        how = {"gathered partials": "per-GPU partial groups merged after ONE RCCL all-gather (every rank holds the result)",
+               "partials": "partial groups hash-partitioned on the group key by ONE RCCL all-to-all, final groups all-gathered",
+               }.get(info.get("mode"), "filtered rows hash-partitioned on the group key by ONE RCCL all-to-all (counts + rows "
+                                       "in one packed region per peer), final groups all-gathered")
         out = {
-            "metric": "rows/sec filter+group-by on 100M synthetic JSON docs; achieved HBM GB/s",
+            "metric": bench.METRIC,
             "value": total_rows * args.steps / elapsed,
             "unit": "rows/s",
             "n_gpus": world,
@@ -400,21 +362,24 @@ def bench_main(args, rank: int, world: int, local_rank: int):
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "int64/f64 tagged scalars (u8 tag + 8 B payload), u32 dictionary codes",
+            "dtype": bench.DTYPE,
             "data": "synthetic",
-            "config": {"workload": "%s: %s @ %d rows per GPU x %d GPUs, K_cat=%d, %s" %
-                                   (args.workload, wl["sql"], args.rows, world, args.kcat, how),
-                       "rows_per_gpu": args.rows, "groups": int(allg.shape[0]) if allg is not None else None,
+            "config": {"workload": "%s: %s @ %d rows in all over %d GPUs (%d per GPU), K_cat=%d, columns resident in HBM; %s" %
+                                   (args.workload, wl["sql"], total_rows, world, rows, args.kcat, how),
+                       "rows_per_gpu": rows, "total_rows": total_rows, "groups": int(res["ngroups"]), "exchange": info.get("mode"),
                        "exchange_rank0": info},
         }
         if info.get("scan_ms"):
-            alg = wl["bytes_per_row"] * args.rows
+            alg = wl["bytes_per_row"] * rows
             ach = alg / (info["scan_ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / bench.HBM_PEAK_GBS, "traffic": None, "kernel_ms": info["scan_ms"],
-                               "kernel": "rank 0: scan_spec_kernel(+merge_slabs_kernel)" if info.get("spec_kernel")
-                               else "rank 0: scan kernel", "algorithmic_bytes_per_launch": alg}
+                               "kernel": "rank 0: partition_kernel (Filter + hash partition of the shard)" if info.get("mode", "").startswith("rows")
+                               else "rank 0: scan kernel of the shard", "algorithmic_bytes_per_launch": alg}
+        if not args.no_cpu:
+            out["cpu_baseline"] = bench.cpu_baseline(wl, args.kcat, bool(args.zipf), total_rows, min(args.cpu_sample, total_rows))
         print(json.dumps(out))
+    op.done()
     dist.destroy_process_group()

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "n1k.h")).read()
-    declared = set(re.findall(r"\b(n1k_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(n1k_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"n1k_status", "n1k_handle"}
     assert declared == set(_ffi.SYMBOLS), (declared ^ set(_ffi.SYMBOLS))
     L = C.CDLL(_ffi.LIB_PATH)

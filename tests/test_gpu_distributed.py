@@ -152,7 +152,8 @@ def test_rank_pipeline_partials_world1_rccl(mode):
         raw, info = op.run_partials(n, dev) if mode == "partials" else op.run_gathered(n, dev)
         assert info["mode"] == ("partials" if mode == "partials" else "gathered partials")
         ora = n1o.run(t, COND, KEYS, AGGS)
-        assert info["rows_selected"] == ora.rows_passed and raw["ngroups"] == len(ora.keys)
+        op.sender.sync()
+        assert op.sender.stats()["rows_selected"] == ora.rows_passed and raw["ngroups"] == len(ora.keys)
         cache = {}
         from query_amd.gpu_operator import GroupRows
         got = GroupRows(1, len(AGGS), op.receiver._py_values(raw["keys"], cache), op.receiver._py_values(raw["aggs"], cache), [])
@@ -177,14 +178,12 @@ def test_rank_pipeline_world1_rccl():
         t = n1o.synth_table(n, k_cat=50)
         op = qd.ShardedFilterGroup(COND, KEYS, AGGS, t.dictionary, 0, 1, 0)
         dev, keep = _device_cols(t, op.send_paths)
-        raw, info = op.run(n, dev)
         ora = n1o.run(t, COND, KEYS, AGGS)
-        assert info["sent_rows"] == info["recv_rows"] == ora.rows_passed
-        assert raw["ngroups"] == len(ora.keys)
-        rec = np.concatenate([raw["keys"].view(np.uint8).reshape(raw["ngroups"], -1),
-                              raw["aggs"].view(np.uint8).reshape(raw["ngroups"], -1)], axis=1)
-        allg = qd.gather_groups(rec, device=torch.device("cuda", 0))
-        assert allg.shape == rec.shape
+        for step in range(3):  # the first step sizes the regions for the whole shard, the later ones for what arrived
+            raw, info = op.run_rows(n, dev)
+            assert info["mode"] == "rows" and info["recv_rows"] == ora.rows_passed
+            assert raw["ngroups"] == len(ora.keys)
+        assert info["region_rows"] < n  # (regions shrank to the survivors' share)
         cache = {}
         keys = op.receiver._py_values(raw["keys"], cache)
         aggs = op.receiver._py_values(raw["aggs"], cache)
@@ -249,8 +248,8 @@ def test_rank_pipeline_grouped_tail(mode):
         having = "(5 < count(*))"
         op = qd.ShardedFilterGroup(None, keys, aggs, t.dictionary, 0, 1, 0, order=order, limit=limit, offset=offset, having=having)
         dev, keep = _device_cols(t, op.send_paths)
-        raw, info = {"gathered": op.run_gathered, "partials": op.run_partials, "rows": op.run}[mode](n, dev)
-        k, a = op.combine(raw, info, torch.device("cuda", 0))
+        raw, info = {"gathered": op.run_gathered, "partials": op.run_partials, "rows": op.run_rows}[mode](n, dev)
+        k, a = raw["keys"], raw["aggs"]  # (already the union with the grouped tail applied: n1k_gather_groups)
         ora = n1o.run(t, None, keys, aggs)
         ci = aggs.index("count(*)")
         kept = [(kk, aa) for kk, aa in zip(ora.keys, ora.aggs) if aa[ci][1] > 5]
