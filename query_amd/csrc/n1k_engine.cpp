@@ -94,6 +94,11 @@ struct n1k_handle {
     DevBuf<uint64_t> d_rec_key[3], d_rec_pay[3][kRecOperands];
     DevBuf<uint8_t> d_rec_tag[3][kRecOperands];
     DevBuf<uint64_t> d_emit;  // the bins' partial groups before they are merged into the table
+    // the same path with the plan-specialised front end: 16-byte records (Rec16) written straight into 256 hash regions
+    // by the scan (projection + first partition pass in one kernel), then into bins of fixed capacity
+    DevBuf<uint64_t> d_rregion, d_rbins;
+    DevBuf<unsigned long long> d_rcursor;
+    uint32_t opt_records = 1;  // 0: always the three-array records of the interpreter front end (ablation, tests)
     // ... or instead of it: while the table is empty and their keys are unique, the region IS the set of groups;
     // n1k_finish finalizes it directly, anything else that needs the table merges it first (flush_pending)
     struct { uint64_t count = 0, cap = 0; } pending;
@@ -1410,6 +1415,159 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
     return N1K_OK;
 }
 
+// The partitioned path with the plan-specialised front end (n1k_spec.h, records mode).  Optimistic: hash regions and
+// bins have fixed capacities (mix64 spreads the keys evenly unless few keys own most rows); when either overflows —
+// or the plan's shape has no specialised kernel — *done stays false, nothing of the batch has been kept, and the caller
+// runs the exact path (run_group_partitioned: histogram-driven passes over three-array records).
+n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionPlan& pp, bool may_keep_region, bool* done) {
+    *done = false;
+    Program& P = h->prog;
+    const uint64_t n = b->nrows;
+    if (!h->opt_records || !h->opt_spec || pp.nsrc > 1 || n == 0 || n >= (1ull << 31)) return N1K_OK;
+    FastArgs F;
+    const uint32_t direct_max_slots = (uint32_t)std::min<uint64_t>((156u * 1024u) / (P.lds_words * 8), 1u << 15);
+    if (!build_fast_args(h, direct_max_slots, F)) return N1K_OK;
+    const SpecSig sig = make_plan_sig(h, F);
+    const SpecEntry* spec = find_spec(sig);
+    const JitKernel* jit = nullptr;
+    if (!spec && h->opt_jit) {
+        jit = jit_get(sig);
+        if (jit->failed || !jit->rec_wide) {
+            h->jit_log = jit->log;
+            jit = nullptr;
+        }
+    }
+    if (!spec && !jit) return N1K_OK;
+    n1k_status st = ensure_table(h, 0);
+    if (st != N1K_OK) return st;
+    // capacities: a region takes its share of the rows plus a quarter, plus the three chunks every workgroup reserves
+    // (and pads) per region; a bin its share plus a half
+    const uint64_t tiles = (n / 2 + 1023) / 1024;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 2, (tiles + 3) / 4));
+    uint64_t cap = (n + n / 4) / 256 + ((uint64_t)grid + 1) * 3 * 16 + n / 8192 + 4096;
+    cap = (cap + 15) / 16 * 16;
+    const bool second = n > 256ull * 1024;
+    const uint64_t mean = n / 65536 + 1, bin_cap = mean + mean / 2 + 256;
+    HIP_TRY(h, h->d_rregion.ensure(2 * 256 * cap));
+    HIP_TRY(h, h->d_rcursor.ensure(256 * kCursorStride));
+    if (second) {
+        HIP_TRY(h, h->d_rbins.ensure(2 * 65536 * bin_cap));
+        HIP_TRY(h, h->d_cursor.ensure(65536));
+    }
+    uint32_t* d_flags = (uint32_t*)(h->d_counters.p + 20);  // [0] a hash region overflowed, [1] a bin
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    if (e0) (void)hipEventRecord(e0, h->stream);
+    HIP_TRY(h, hipMemsetAsync(h->d_rcursor.p, 0, 256 * kCursorStride * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(d_flags, 0, 8, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_counters.p + 25, h->d_counters.p + 0, 8, hipMemcpyDeviceToDevice, h->stream));  // rows_selected, to undo
+    // (1) Filter + packed key + operand -> records in the hash regions
+    bool aligned = true;
+    for (uint32_t c = 0; c < P.ncols; c++) {
+        F.cols[c] = P.cols[c];
+        aligned &= ((uintptr_t)F.cols[c].tags % 2 == 0) && ((uintptr_t)F.cols[c].payload % 16 == 0) && ((uintptr_t)F.cols[c].codes % 8 == 0);
+    }
+    const bool wide = aligned && h->opt_wide && n >= 2;
+    F.nrows = (uint32_t)n;
+    F.row_base = h->row_base;
+    F.err_flags = h->d_errp;
+    F.rows_selected = h->d_counters.p + 0;
+    WordLogArgs L;
+    memset(&L, 0, sizeof L);
+    L.region[0] = h->d_rregion.p;
+    L.region_cursor[0] = h->d_rcursor.p;
+    L.region_cap = cap;
+    L.rec_overflow = d_flags;
+    if (spec) HIP_TRY(h, spec->launch_records(P, F, grid, wide, L, h->stream));
+    else HIP_TRY(h, jit_launch_records(jit, P, F, grid, wide, L, h->stream));
+    // (2) the second partition pass, into bins of fixed capacity
+    BinAggArgs B{};
+    B.nsrc = pp.nsrc;
+    if (second) {
+        RadixArgs R{};
+        R.src = h->d_rregion.p;
+        R.dst = h->d_rbins.p;
+        R.seg_count = h->d_rcursor.p;
+        R.seg_stride = cap;
+        R.nseg = 256;
+        R.shift = 48;
+        R.cursor = h->d_cursor.p;
+        R.bin_cap = bin_cap;
+        R.overflow = d_flags + 1;
+        const uint64_t seg_tiles = (cap + 4095) / 4096;
+        const uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / 256 + 8, seg_tiles));
+        HIP_TRY(h, launch_radix_scatter16(R, slices, h->stream));
+        B.rec = h->d_rbins.p;
+        B.bin_count = h->d_cursor.p;
+        B.bin_count_stride = 1;
+        B.bin_stride = bin_cap;
+        B.nbins = 65536;
+    } else {
+        B.rec = h->d_rregion.p;
+        B.bin_count = h->d_rcursor.p;
+        B.bin_count_stride = kCursorStride;
+        B.bin_stride = cap;
+        B.nbins = 256;
+    }
+    // (3) one workgroup per bin: InitialGroup in an LDS table, the bin's groups into the compact region
+    uint32_t slots = (uint32_t)std::min<uint64_t>((64u * 1024u) / (P.lds_words * 8), 1u << 13);
+    if (slots < 64) return N1K_OK;
+    const uint64_t per = n / B.nbins + 1;  // records (hence groups at most) a bin holds on average
+    uint32_t bslots = slots;
+    while (bslots > 256 && (uint64_t)bslots / 4 >= per) bslots /= 2;
+    B.lds_slots = bslots;
+    B.lds_max_fill = std::max(1u, bslots * 5 / 8);
+    for (uint32_t a = 0; a < kMaxAggs; a++) B.agg_src[a] = a < P.naggs ? pp.agg_src[a] : 0xFFFFFFFFu;
+    B.err_flags = h->d_errp;
+    uint32_t nsum = 0;
+    for (uint32_t a = 0; a < P.naggs; a++) nsum += (P.aggs[a].kind == AGG_SUM || P.aggs[a].kind == AGG_AVG) ? 1u : 0u;
+    const uint64_t ecap = n * (1 + nsum) + 1024;
+    const uint64_t region_words = 2 + ecap * (1 + (uint64_t)P.glob_words);
+    HIP_TRY(h, h->d_emit.ensure(region_words));
+    HIP_TRY(h, hipMemsetAsync(h->d_emit.p, 0, 16, h->stream));
+    B.emit = h->d_emit.p;
+    B.emit_cap = ecap;
+    B.emit_singletons = h->d_counters.p + 22;
+    HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 22, 0, sizeof(unsigned long long), h->stream));
+    {
+        const size_t shmem = (size_t)bslots * P.lds_words * 8 + 1024;
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
+        const uint32_t bgrid = (uint32_t)std::min<uint64_t>(B.nbins, (uint64_t)h->num_cus * per_cu);
+        HIP_TRY(h, launch_agg_bins(P, B, h->table, h->d_counters.p + 1, bgrid, h->stream));
+    }
+    unsigned long long emitted = 0, have = 0, singletons = 0;
+    uint32_t flags[2] = {0, 0};
+    HIP_TRY(h, hipMemcpyAsync(&singletons, h->d_counters.p + 22, sizeof singletons, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&emitted, h->d_emit.p, sizeof emitted, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&have, h->d_counters.p + 1, sizeof have, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (flags[0] | flags[1]) {
+        // a region or a bin overflowed: nothing was merged anywhere yet — forget the records and the survivor count
+        HIP_TRY(h, hipMemcpyAsync(h->d_counters.p + 0, h->d_counters.p + 25, 8, hipMemcpyDeviceToDevice, h->stream));
+        if (e0) h->event_pool.push_back(e0);
+        if (e1) h->event_pool.push_back(e1);
+        return N1K_OK;
+    }
+    *done = true;
+    emitted = std::min<unsigned long long>(emitted, ecap);
+    h->stats.agg_mode = N1K_MODE_PARTITIONED;
+    h->stats.spec_kernel = spec ? 1u : 2u;
+    if (may_keep_region && have == 0 && singletons == 0) {
+        h->pending.count = emitted;
+        h->pending.cap = ecap;
+        if (e1) (void)hipEventRecord(e1, h->stream);
+        h->events.emplace_back(e0, e1);
+        return N1K_OK;
+    }
+    st = ensure_table_groups(h, have + emitted);
+    if (st != N1K_OK) return st;
+    HIP_TRY(h, launch_merge_partials(P, h->table, 1, ecap, h->d_emit.p, region_words, h->d_errp, h->d_counters.p + 1, h->stream, emitted,
+                                     singletons == 0));
+    if (e1) (void)hipEventRecord(e1, h->stream);
+    h->events.emplace_back(e0, e1);
+    return N1K_OK;
+}
+
 n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
     n1k_status st = ensure_device(h);
@@ -1490,7 +1648,12 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     }
     if (b->nrows) {
         if (!h->plan.has_group) st = run_filter_batch(h, &v);
-        else st = partition ? run_group_partitioned(h, &v, pp, groups_est, first_rows) : run_group_batch(h, &v);
+        else if (partition) {
+            bool done = false;
+            st = run_group_records(h, &v, pp, first_rows, &done);
+            if (st == N1K_OK && !done) st = run_group_partitioned(h, &v, pp, groups_est, first_rows);
+        } else
+            st = run_group_batch(h, &v);
         if (st != N1K_OK) return st;
     }
     h->row_base += b->nrows;
@@ -1783,6 +1946,9 @@ static void destroy_handle(n1k_handle* h) {
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
         h->d_emit.release();
+        h->d_rregion.release();
+        h->d_rbins.release();
+        h->d_rcursor.release();
         for (int i = 0; i < 3; i++) {
             h->d_rec_key[i].release();
             for (uint32_t e = 0; e < kRecOperands; e++) {
@@ -1912,6 +2078,8 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         uint32_t v = 64;
         while (v < (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 8192)) v <<= 1;
         h->opt_distinct_set_slots = v;
+    } else if (n == "records") {
+        h->opt_records = value ? 1 : 0;
     } else if (n == "spec_debug") {
         h->opt_spec_debug = (uint32_t)value;
     } else if (n == "distinct_region_cap") {

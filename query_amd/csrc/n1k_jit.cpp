@@ -88,7 +88,11 @@ std::string jit_source(const SpecSig& g) {
       << "    n1k::scan_spec_body<n1k::SpecJ, 2, 512, true>(P, F, G, ngroups, L);\n}\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
       << "        const n1k::GlobalTable G, unsigned long long* ngroups, const n1k::WordLogArgs L) {\n"
-      << "    n1k::scan_spec_body<n1k::SpecJ, 4, 512, false>(P, F, G, ngroups, L);\n}\n";
+      << "    n1k::scan_spec_body<n1k::SpecJ, 4, 512, false>(P, F, G, ngroups, L);\n}\n"
+      << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_rec_wide(const n1k::Program P, const n1k::FastArgs F,\n"
+      << "        const n1k::WordLogArgs L) {\n    n1k::scan_spec_records_body<n1k::SpecJ, 2, 512, true>(P, F, L);\n}\n"
+      << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_rec_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
+      << "        const n1k::WordLogArgs L) {\n    n1k::scan_spec_records_body<n1k::SpecJ, 4, 512, false>(P, F, L);\n}\n";
     return o.str();
 }
 
@@ -114,7 +118,9 @@ const JitKernel* jit_get(const SpecSig& sig) {
     }
     if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
         hipModuleGetFunction(&k->wide, k->module, "n1k_jit_wide") != hipSuccess ||
-        hipModuleGetFunction(&k->narrow, k->module, "n1k_jit_narrow") != hipSuccess) {
+        hipModuleGetFunction(&k->narrow, k->module, "n1k_jit_narrow") != hipSuccess ||
+        hipModuleGetFunction(&k->rec_wide, k->module, "n1k_jit_rec_wide") != hipSuccess ||
+        hipModuleGetFunction(&k->rec_narrow, k->module, "n1k_jit_rec_narrow") != hipSuccess) {
         k->failed = true;
         k->log += "\nhipModuleLoadData / hipModuleGetFunction failed";
     }
@@ -126,6 +132,14 @@ hipError_t jit_launch(const JitKernel* k, const Program& P, const FastArgs& F, c
     size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * ndistinct * 8;
     void* args[] = {(void*)&P, (void*)&F, (void*)&G, (void*)&ngroups, (void*)&L};
     return hipModuleLaunchKernel(wide ? k->wide : k->narrow, grid, 1, 1, 512, 1, 1, (unsigned)shmem, st, args, nullptr);
+}
+
+hipError_t jit_launch_records(const JitKernel* k, const Program& P, const FastArgs& F, uint32_t grid, bool wide, const WordLogArgs& L,
+                              hipStream_t st) {
+    const unsigned shmem = 256u * 16u * 16u + 8u * 256u * 4u;  // sizeof(WcLdsT<Rec16>), n1k_spec.h
+    hipFunction_t f = wide ? k->rec_wide : k->rec_narrow;
+    void* args[] = {(void*)&P, (void*)&F, (void*)&L};
+    return hipModuleLaunchKernel(f, grid, 1, 1, 512, 1, 1, shmem, st, args, nullptr);
 }
 
 }  // namespace n1k

@@ -15,6 +15,7 @@ struct JitKernel {
     hipModule_t module = nullptr;
     hipFunction_t wide = nullptr;    // scan_spec_body<Spec, 2, 512, true>
     hipFunction_t narrow = nullptr;  // scan_spec_body<Spec, 4, 512, false>
+    hipFunction_t rec_wide = nullptr, rec_narrow = nullptr;  // scan_spec_records_body (partitioned GROUP BY front end)
     bool failed = false;
     std::string log;
 };
@@ -28,5 +29,8 @@ const JitKernel* jit_get(const SpecSig& sig);
 bool jit_compile_check(const SpecSig& sig, std::string* log);
 hipError_t jit_launch(const JitKernel* k, const Program& P, const FastArgs& F, const GlobalTable& G,
                       unsigned long long* ngroups, uint32_t grid, bool wide, const WordLogArgs& L, uint32_t ndistinct, hipStream_t st);
+
+hipError_t jit_launch_records(const JitKernel* k, const Program& P, const FastArgs& F, uint32_t grid, bool wide, const WordLogArgs& L,
+                              hipStream_t st);
 
 }  // namespace n1k

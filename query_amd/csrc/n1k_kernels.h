@@ -95,7 +95,11 @@ struct SpecEntry {
     SpecSig sig;
     hipError_t (*launch)(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                          uint32_t grid, uint32_t block, bool wide, const WordLogArgs& L, hipStream_t st);
+    // records mode (partitioned GROUP BY): Filter + packed key -> 16-byte records in the hash regions
+    hipError_t (*launch_records)(const Program& P, const FastArgs& F, uint32_t grid, bool wide, const WordLogArgs& L, hipStream_t st);
 };
+size_t spec_records_lds_bytes();
+hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t slices, hipStream_t st);
 const std::vector<SpecEntry>& spec_registry();
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,
                            OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count, uint64_t max_out,

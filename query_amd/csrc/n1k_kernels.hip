@@ -570,6 +570,88 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
     }
 }
 
+// The second partition pass of the 16-byte records (partitioned GROUP BY): segment s = hash region s (fixed capacity,
+// its record count in seg_count), bins of fixed capacity like the member words' second pass — the keys were spread by
+// mix64, so a bin holds its share unless few keys own most rows, in which case *overflow is set and the engine redoes
+// the batch on the exact path.  Records whose key is kEmptyKey are the regions' padding and stay behind.
+constexpr int kRec16Per = 8, kRec16Tile = kRadixBlock * kRec16Per;  // 4096 records = 64 KB staged
+__global__ __launch_bounds__(kRadixBlock) void radix_scatter16_kernel(const RadixArgs A) {
+    extern __shared__ uint64_t dyn16[];
+    Rec16* stage = (Rec16*)dyn16;
+    __shared__ uint32_t cnt[256], pre[256], wsum[4];
+    __shared__ unsigned long long gbase[256];
+    const uint32_t tid = threadIdx.x, s = blockIdx.y, cstride = A.cursor_stride ? A.cursor_stride : 1u;
+    const Rec16* src = (const Rec16*)A.src;
+    Rec16* dst = (Rec16*)A.dst;
+    // slice of the segment this workgroup owns, in whole tiles
+    const uint64_t c0 = A.seg_count[(size_t)s * kCursorStride];
+    const uint64_t s0 = (uint64_t)s * A.seg_stride, s1 = s0 + (c0 < A.seg_stride ? c0 : A.seg_stride);
+    uint64_t chunk = (s1 - s0 + gridDim.x - 1) / gridDim.x;
+    chunk = (chunk + kRec16Tile - 1) / kRec16Tile * kRec16Tile;
+    uint64_t lo = s0 + (uint64_t)blockIdx.x * chunk, hi = lo + chunk < s1 ? lo + chunk : s1;
+    if (lo > s1) lo = hi = s1;
+    for (uint64_t tile = lo; tile < hi; tile += kRec16Tile) {
+        const uint32_t n = (uint32_t)(hi - tile < (uint64_t)kRec16Tile ? hi - tile : (uint64_t)kRec16Tile);
+        if (tid < 256) cnt[tid] = 0;
+        __syncthreads();
+        Rec16 w[kRec16Per];
+        uint32_t rk[kRec16Per];
+#pragma unroll
+        for (int j = 0; j < kRec16Per; j++) {
+            const uint32_t p = (uint32_t)j * kRadixBlock + tid;
+            if (p < n) w[j] = src[tile + p];
+            else { w[j].k = kEmptyKey; w[j].v = 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < kRec16Per; j++) {
+            rk[j] = 0xFFFFFFFFu;
+            if (w[j].k != kEmptyKey) {
+                const uint32_t b = radix_bin(w[j].k & ~kRecIntFlag, A.shift);
+                rk[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t mine = tid < 256 ? cnt[tid] : 0u, incl = mine;
+        if (tid < 256) {
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t t = __shfl_up(incl, off, 64);
+                if ((int)(tid & 63) >= off) incl += t;
+            }
+            if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t before = 0;
+            for (uint32_t q = 0; q < (tid >> 6); q++) before += wsum[q];
+            pre[tid] = before + incl - mine;
+            gbase[tid] = mine ? atomicAdd(&A.cursor[((size_t)s * 256 + tid) * cstride], (unsigned long long)mine) : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kRec16Per; j++)
+            if (rk[j] != 0xFFFFFFFFu) stage[pre[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = w[j];
+        __syncthreads();
+        const uint32_t staged = pre[255] + cnt[255];
+        for (uint32_t p = tid; p < staged; p += kRadixBlock) {
+            const Rec16 x = stage[p];
+            const uint32_t b = radix_bin(x.k & ~kRecIntFlag, A.shift);
+            const unsigned long long pos = gbase[b] + (p - pre[b]);
+            if (pos < A.bin_cap) dst[((size_t)s * 256 + b) * A.bin_cap + pos] = x;
+            else *(volatile uint32_t*)A.overflow = 1u;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t slices, hipStream_t st) {
+    (void)hipMemsetAsync(A.cursor, 0, (size_t)A.nseg * 256 * (A.cursor_stride ? A.cursor_stride : 1u) * sizeof(unsigned long long), st);
+    auto k = radix_scatter16_kernel;
+    const size_t shmem = (size_t)kRec16Tile * sizeof(Rec16);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3(slices, A.nseg), dim3(kRadixBlock), shmem, st, A);
+    return hipGetLastError();
+}
+
 // one workgroup per bin (persistent over bins): LDS open-addressed set of the bin's words; every first insertion is
 // one more member of its group's set (Set.Len(), value/set.go:198-215), counted in LDS per packed group key — by the
 // key itself when the keys are small (direct_keys), else in a second LDS table keyed by the packed key — and handed
@@ -1264,9 +1346,26 @@ static hipError_t launch_spec(const Program& P, const FastArgs& F, const GlobalT
     return hipGetLastError();
 }
 
+// records mode of a shape (n1k_spec.h): Filter + packed key, 16-byte records into the hash regions
+template <class Spec>
+static hipError_t launch_spec_records(const Program& P, const FastArgs& F, uint32_t grid, bool wide, const WordLogArgs& L, hipStream_t st) {
+    const size_t shmem = sizeof(WcLdsT<Rec16>);
+    if (wide) {
+        auto k = scan_spec_records_kernel<Spec, 2, 512, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), shmem, st, P, F, L);
+    } else {
+        auto k = scan_spec_records_kernel<Spec, 4, 512, false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), shmem, st, P, F, L);
+    }
+    return hipGetLastError();
+}
+size_t spec_records_lds_bytes() { return sizeof(WcLdsT<Rec16>); }
+
 const std::vector<SpecEntry>& spec_registry() {
     static const std::vector<SpecEntry> reg = {
-#define N1K_REG(S) SpecEntry{#S, make_sig<S>(), &launch_spec<S>}
+#define N1K_REG(S) SpecEntry{#S, make_sig<S>(), &launch_spec<S>, &launch_spec_records<S>}
         N1K_REG(Spec_gt_sum), N1K_REG(Spec_lt_sum), N1K_REG(Spec_gtf_sum), N1K_REG(Spec_gt_all), N1K_REG(Spec_gt_count),
         N1K_REG(Spec_sum), N1K_REG(Spec_avg), N1K_REG(Spec_count), N1K_REG(Spec_gt_nokey_count), N1K_REG(Spec_2k_sum),
         N1K_REG(Spec_ik_count), N1K_REG(Spec_ik_sum), N1K_REG(Spec_dik_sum), N1K_REG(Spec_cd_avg), N1K_REG(Spec_cd),
@@ -2012,8 +2111,17 @@ __global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const 
     __shared__ unsigned long long emit_base;
     const uint32_t S = A.lds_slots, tid = threadIdx.x;
     uint32_t new_groups = 0;
+    const Rec16* const rec16 = (const Rec16*)A.rec;
     for (uint32_t bin = blockIdx.x; bin < A.nbins; bin += gridDim.x) {
-        const uint64_t lo = A.bin_start[bin], hi = A.bin_start[bin + 1];
+        uint64_t lo, hi;
+        if (rec16) {
+            const uint64_t c = A.bin_count[(size_t)bin * (A.bin_count_stride ? A.bin_count_stride : 1u)];
+            lo = (uint64_t)bin * A.bin_stride;
+            hi = lo + (c < A.bin_stride ? c : A.bin_stride);
+        } else {
+            lo = A.bin_start[bin];
+            hi = A.bin_start[bin + 1];
+        }
         if (lo == hi) continue;
         __syncthreads();
         lds_table_init<BLOCK>(P, lds, S, tid);
@@ -2021,12 +2129,21 @@ __global__ __launch_bounds__(BLOCK) void agg_bins_kernel(const Program P, const 
         __syncthreads();
         // InitialGroup over the bin's records (execution/group_initial.go:56-100)
         for (uint64_t i = lo + tid; i < hi; i += BLOCK) {
-            const uint64_t key = A.in.key[i];
+            uint64_t key;
             uint32_t vt[kRecOperands];
             uint64_t vp[kRecOperands];
-            for (uint32_t e = 0; e < A.nsrc; e++) {
-                vt[e] = A.in.tag[e][i];
-                vp[e] = A.in.pay[e][i];
+            if (rec16) {
+                const Rec16 r = rec16[i];
+                if (r.k == kEmptyKey) continue;  // padding of the hash regions
+                rec16_decode(r, key, vt[0], vp[0]);
+                vt[1] = T_NULL;
+                vp[1] = 0;
+            } else {
+                key = A.in.key[i];
+                for (uint32_t e = 0; e < A.nsrc; e++) {
+                    vt[e] = A.in.tag[e][i];
+                    vp[e] = A.in.pay[e][i];
+                }
             }
             const int slot = lds_find_or_insert(lds, S, key, &lds_fill, A.lds_max_fill);
             long long grow = -1;

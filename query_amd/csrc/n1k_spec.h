@@ -249,6 +249,56 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
     }
 }
 
+// the loads of one tile (R items per thread x the Spec's columns), all issued before anything is computed
+template <class Spec, int R, int BLOCK, bool WIDE>
+N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, uint32_t tid,
+                            uint32_t (&tg)[R][WIDE ? 2 : 1][kFastCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kFastCols], bool (&valid)[R]) {
+    constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const uint32_t i = base + (uint32_t)j * BLOCK + tid;
+        valid[j] = i < nitems;
+#pragma unroll
+        for (int c = 0; c < kFastCols; c++) {
+            if (c < Spec::ncols) {
+                if (Spec::col_kind[c] == COLK_DICT32) {
+                    if (WIDE) {
+                        typedef uint32_t n1k_u32x2 __attribute__((ext_vector_type(2)));
+                        n1k_u32x2 cc = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                        if (valid[j]) cc = __builtin_nontemporal_load((const n1k_u32x2*)F.cols[c].codes + i);
+                        pv[j][0][c] = cc.x;
+                        pv[j][WIDE ? 1 : 0][c] = cc.y;
+                    } else {
+                        pv[j][0][c] = valid[j] ? F.cols[c].codes[i] : 0xFFFFFFFFu;
+                    }
+#pragma unroll
+                    for (int h = 0; h < (int)kRowsPerItem; h++) {
+                        uint32_t code = (uint32_t)pv[j][h][c];
+                        tg[j][h][c] = code == 0xFFFFFFFFu ? (uint32_t)T_MISSING : (code == 0xFFFFFFFEu ? (uint32_t)T_NULL : (uint32_t)T_STRING);
+                    }
+                } else {
+                    if (WIDE) {
+                        typedef unsigned long long n1k_u64x2 __attribute__((ext_vector_type(2)));
+                        n1k_u64x2 pp = {0ull, 0ull};
+                        if (valid[j]) pp = __builtin_nontemporal_load((const n1k_u64x2*)F.cols[c].payload + i);
+                        uint32_t tt = valid[j] ? (uint32_t)__builtin_nontemporal_load((const uint16_t*)F.cols[c].tags + i) : 0u;
+                        pv[j][0][c] = pp.x;
+                        pv[j][WIDE ? 1 : 0][c] = pp.y;
+                        tg[j][0][c] = tt & 255u;
+                        tg[j][WIDE ? 1 : 0][c] = tt >> 8;
+                    } else {
+                        pv[j][0][c] = valid[j] ? F.cols[c].payload[i] : 0ull;
+                        tg[j][0][c] = valid[j] ? (uint32_t)F.cols[c].tags[i] : (uint32_t)T_MISSING;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < (int)kRowsPerItem; h++) { tg[j][h][c] = T_MISSING; pv[j][h][c] = 0; }
+            }
+        }
+    }
+}
+
 // ---- member words -> hash regions: write combining in LDS ------------------------------------------------------
 //
 // Every workgroup keeps, per DISTINCT aggregate and hash region, kWcSlots staging slots in LDS and private CHUNKS of
@@ -262,14 +312,23 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
 // which every reader of the regions skips.  (Region capacities and all reservations are multiples of kWcChunk.)
 constexpr uint32_t kWcSlots = 16, kWcChunk = 16;
 
-// LDS of one DISTINCT aggregate.  The chunk state and the tile counters exist twice: in tile t everybody reads copy
+// The same machinery moves 8-byte member words (COUNT(DISTINCT)) and 16-byte records (the partitioned GROUP BY: packed
+// key + one operand, Rec16 in n1k_tables.h); "no element" is kEmptyKey / a record whose key is kEmptyKey.
+N1K_DEV bool wc_none(uint64_t w) { return w == kEmptyKey; }
+N1K_DEV bool wc_none(const Rec16& r) { return r.k == kEmptyKey; }
+N1K_DEV void wc_set_none(uint64_t& w) { w = kEmptyKey; }
+N1K_DEV void wc_set_none(Rec16& r) { r.k = kEmptyKey; r.v = 0; }
+
+// LDS of one stream of elements.  The chunk state and the tile counters exist twice: in tile t everybody reads copy
 // t & 1 and region b's owner writes copy (t + 1) & 1, so that the owners' updates need no barrier of their own.
-struct WcLds {
-    uint64_t slot[256 * kWcSlots];
-    uint32_t cur[2][256], next[2][256];  // first word of the current / next chunk (position inside the region, < 2^32)
-    uint32_t used[2][256];               // words of the current chunk already written
-    uint32_t fill[2][256];               // words appended to the slots in this tile
+template <class E>
+struct WcLdsT {
+    E slot[256 * kWcSlots];
+    uint32_t cur[2][256], next[2][256];  // first element of the current / next chunk (position inside the region, < 2^32)
+    uint32_t used[2][256];               // elements of the current chunk already written
+    uint32_t fill[2][256];               // elements appended to the slots in this tile
 };
+typedef WcLdsT<uint64_t> WcLds;
 constexpr uint32_t kWcNone = 0xFFFFFFFFu;  // "no chunk": the region is full
 
 // what the owner of a region carries in registers from tile to tile
@@ -279,8 +338,9 @@ struct WcOwner {
     bool pending;
 };
 
+// an element whose region is full: a member word goes to the plain word log (n1k_finish then takes the exact path); a
+// record raises the flag that makes the engine redo the batch on the exact path
 N1K_DEV void wc_over_append(const WordLogArgs& L, int d, uint32_t b, uint64_t word, uint32_t* err_flags) {
-    // the region is full (many copies of few words): the plain word log takes the word, n1k_finish the exact path
     const uint32_t li = L.log_index[d];
     const unsigned long long q = atomicAdd(&L.over_cursor[li], 1ull);
     if (q < L.over_capacity) {
@@ -289,14 +349,15 @@ N1K_DEV void wc_over_append(const WordLogArgs& L, int d, uint32_t b, uint64_t wo
     } else
         atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
 }
+N1K_DEV void wc_over_append(const WordLogArgs& L, int, uint32_t, const Rec16&, uint32_t*) { *(volatile uint32_t*)L.rec_overflow = 1u; }
 
 // a reservation [base, base + kWcChunk) as a chunk: inside the region or not at all (both are multiples of kWcChunk)
 N1K_DEV uint32_t wc_chunk(const WordLogArgs& L, unsigned long long base) {
     return base + kWcChunk <= L.region_cap ? (uint32_t)base : kWcNone;
 }
 
-template <int BLOCK>
-N1K_DEV void wc_init(const WordLogArgs& L, int d, WcLds& W, WcOwner& O) {
+template <int BLOCK, class E>
+N1K_DEV void wc_init(const WordLogArgs& L, int d, WcLdsT<E>& W, WcOwner& O) {
     O.pend = 0;
     O.third = kWcNone;
     O.pending = false;
@@ -312,27 +373,30 @@ N1K_DEV void wc_init(const WordLogArgs& L, int d, WcLds& W, WcOwner& O) {
 }
 
 // All threads of the workgroup call it once per tile (two barriers).  `par` = tile & 1.
-template <int BLOCK, int NW>
-N1K_DEV void wc_tile(const WordLogArgs& L, int d, const uint64_t (&w)[NW], const uint32_t (&wb)[NW], WcLds& W, uint32_t par,
+template <int BLOCK, int NW, class E>
+N1K_DEV void wc_tile(const WordLogArgs& L, int d, const E (&w)[NW], const uint32_t (&wb)[NW], WcLdsT<E>& W, uint32_t par,
                      WcOwner& O, uint32_t* err_flags) {
     static_assert(BLOCK >= 256, "one owner thread per hash region");
     constexpr int kPer = 256 * 16 / BLOCK;  // regions per 16-lane group
     const uint32_t tid = threadIdx.x;
-    if (L.pad & 2u) return;  // (timing experiments only: words dropped)
+    E* const region0 = (E*)L.region[d];
+    if (L.pad & 2u) return;  // (timing experiments only: elements dropped)
 #pragma unroll
     for (int j = 0; j < NW; j++) {
-        if (w[j] == kEmptyKey) continue;
+        if (wc_none(w[j])) continue;
         const uint32_t b = wb[j];
         const uint32_t r = atomicAdd(&W.fill[par][b], 1u);
         if (r < kWcSlots) {
             W.slot[b * kWcSlots + r] = w[j];
         } else {
-            // more words for one region in one tile than its slots take (a few per thousand tiles): a line of its own
+            // more elements for one region in one tile than its slots take (a few per thousand tiles): a chunk of its own
             const unsigned long long q = atomicAdd(&L.region_cursor[d][b * kCursorStride], (unsigned long long)kWcChunk);
             if (q + kWcChunk <= L.region_cap) {
-                uint64_t* line = L.region[d] + (size_t)b * L.region_cap + q;
+                E* line = region0 + (size_t)b * L.region_cap + q;
                 line[0] = w[j];
-                for (uint32_t i = 1; i < kWcChunk; i++) line[i] = kEmptyKey;
+                E none;
+                wc_set_none(none);
+                for (uint32_t i = 1; i < kWcChunk; i++) line[i] = none;
             } else
                 wc_over_append(L, d, b, w[j], err_flags);
         }
@@ -340,7 +404,7 @@ N1K_DEV void wc_tile(const WordLogArgs& L, int d, const uint64_t (&w)[NW], const
     __syncthreads();
     // owners: the state of the next tile.  A region whose chunk fills up in this tile moves on to the next one (which has
     // been known for a tile at least), the third becomes the next, and a new third is reserved; its answer is read at the
-    // start of the next tile's owner step.  (A tile brings at most kWcSlots = kWcChunk words: one move per tile.)
+    // start of the next tile's owner step.  (A tile brings at most kWcSlots = kWcChunk elements: one move per tile.)
     if (tid < 256) {
         const uint32_t b = tid, f = W.fill[par][b], n = f < kWcSlots ? f : kWcSlots, used = W.used[par][b];
         if (O.pending) {
@@ -360,7 +424,7 @@ N1K_DEV void wc_tile(const WordLogArgs& L, int d, const uint64_t (&w)[NW], const
         }
         W.fill[par ^ 1][b] = 0;
     }
-    // copy: a 16-lane group per region, consecutive lanes write consecutive words of a line
+    // copy: a 16-lane group per region, consecutive lanes write consecutive elements of a chunk
     const uint32_t g = tid >> 4, l = tid & 15u;
 #pragma unroll 2
     for (int k = 0; k < kPer; k++) {
@@ -370,28 +434,118 @@ N1K_DEV void wc_tile(const WordLogArgs& L, int d, const uint64_t (&w)[NW], const
         if (l >= n) continue;
         const uint32_t pos = W.used[par][b] + l;
         const uint32_t base = pos < kWcChunk ? W.cur[par][b] : W.next[par][b];
-        const uint64_t word = W.slot[b * kWcSlots + l];
-        if (L.pad & 1u) continue;  // (timing experiments only: words not stored)
-        if (base != kWcNone) L.region[d][(size_t)b * L.region_cap + base + (pos & (kWcChunk - 1))] = word;
-        else wc_over_append(L, d, b, word, err_flags);
+        const E e = W.slot[b * kWcSlots + l];
+        if (L.pad & 1u) continue;  // (timing experiments only: elements not stored)
+        if (base != kWcNone) region0[(size_t)b * L.region_cap + base + (pos & (kWcChunk - 1))] = e;
+        else wc_over_append(L, d, b, e, err_flags);
     }
     __syncthreads();
 }
 
-// end of the kernel: what the workgroup reserved and did not fill reads as "no word".  `par` = parity of the next tile.
-template <int BLOCK>
-N1K_DEV void wc_finish(const WordLogArgs& L, int d, WcLds& W, uint32_t par, WcOwner& O) {
+// end of the kernel: what the workgroup reserved and did not fill reads as "no element".  `par` = parity of the next tile.
+template <int BLOCK, class E>
+N1K_DEV void wc_finish(const WordLogArgs& L, int d, WcLdsT<E>& W, uint32_t par, WcOwner& O) {
     const uint32_t b = threadIdx.x;
     if (b >= 256) return;
     const uint32_t cur = W.cur[par][b], nx = W.next[par][b], used = W.used[par][b];
     const uint32_t third = O.pending ? wc_chunk(L, O.pend) : O.third;
-    uint64_t* region = L.region[d] + (size_t)b * L.region_cap;
+    E* region = (E*)L.region[d] + (size_t)b * L.region_cap;
+    E none;
+    wc_set_none(none);
     if (cur != kWcNone)
-        for (uint32_t pos = used; pos < kWcChunk; pos++) region[cur + pos] = kEmptyKey;
+        for (uint32_t pos = used; pos < kWcChunk; pos++) region[cur + pos] = none;
     if (nx != kWcNone)
-        for (uint32_t pos = 0; pos < kWcChunk; pos++) region[nx + pos] = kEmptyKey;
+        for (uint32_t pos = 0; pos < kWcChunk; pos++) region[nx + pos] = none;
     if (third != kWcNone)
-        for (uint32_t pos = 0; pos < kWcChunk; pos++) region[third + pos] = kEmptyKey;
+        for (uint32_t pos = 0; pos < kWcChunk; pos++) region[third + pos] = none;
+}
+
+// ---- records mode: Filter + group key of the plan shape, each surviving row leaves as a 16-byte record ----------
+//
+// High-cardinality GROUP BY (N1K_MODE_PARTITIONED): no workgroup table would absorb anything, so the specialised scan
+// only evaluates the Filter, packs the group key and scatters (key, operand) records by the first radix digit of
+// mix64(key) into the 256 hash regions — the projection and the first partition pass of the partitioned path in one
+// kernel, reading the columns once and writing 16 bytes per surviving row.
+template <class Spec>
+constexpr int spec_operand_col() {
+    for (int a = 0; a < Spec::naggs; a++)
+        if (Spec::aggs[a].has_operand) return (int)Spec::aggs[a].col;
+    return -1;
+}
+
+template <class Spec>
+N1K_DEV void spec_row_record(const Program& P, const FastArgs& F, const uint32_t (&tg)[kFastCols], const uint64_t (&pv)[kFastCols],
+                             uint32_t& selected, uint32_t& unpackable, Rec16& rec, uint32_t& bin) {
+    bool pass = true;
+#pragma unroll
+    for (int t = 0; t < Spec::nterms; t++) pass = pass && spec_term_true<Spec>(t, F, tg[Spec::terms[t].col], pv[Spec::terms[t].col]);
+    if (!pass) return;
+    uint64_t key = 0;
+#pragma unroll
+    for (int k = 0; k < Spec::nkeys; k++) {
+        uint64_t f = 0, canon;
+        if (!pack_key_field(P, P.keys[k], tg[Spec::key_col[k]], pv[Spec::key_col[k]], f, canon)) {
+            unpackable = 1;
+            return;
+        }
+        key |= f << P.keys[k].shift;
+    }
+    selected++;
+    constexpr int oc = spec_operand_col<Spec>();
+    rec = rec16_encode(key, oc >= 0 ? tg[oc >= 0 ? oc : 0] : (uint32_t)T_NULL, oc >= 0 ? pv[oc >= 0 ? oc : 0] : 0ull);
+    bin = (uint32_t)(mix64(key) >> 56);
+}
+
+template <class Spec, int R, int BLOCK, bool WIDE>
+N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const WordLogArgs& L) {
+    extern __shared__ uint64_t lds[];
+    WcLdsT<Rec16>& W = *(WcLdsT<Rec16>*)lds;
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
+    constexpr int kNW = R * (int)kRowsPerItem;
+    WcOwner own;
+    uint32_t par = 0;
+    wc_init<BLOCK>(L, 0, W, own);
+    __syncthreads();
+    uint32_t unpackable = 0, selected = 0;
+    const uint32_t nrows = F.nrows;
+    const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
+    const uint32_t tile = BLOCK * R;
+    for (uint32_t base = blockIdx.x * tile; base < nitems; base += gridDim.x * tile) {
+        uint32_t tg[R][kRowsPerItem][kFastCols];
+        uint64_t pv[R][kRowsPerItem][kFastCols];
+        bool valid[R];
+        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
+        Rec16 recs[kNW];
+        uint32_t bins[kNW];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+#pragma unroll
+            for (int h = 0; h < (int)kRowsPerItem; h++) {
+                const int at = j * (int)kRowsPerItem + h;
+                wc_set_none(recs[at]);
+                bins[at] = 0;
+                const bool row_ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nrows);
+                if (row_ok) spec_row_record<Spec>(P, F, tg[j][h], pv[j][h], selected, unpackable, recs[at], bins[at]);
+            }
+        }
+        wc_tile<BLOCK, kNW>(L, 0, recs, bins, W, par, own, F.err_flags);
+        par ^= 1u;
+    }
+    wc_finish<BLOCK>(L, 0, W, par, own);
+    if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+    __shared__ unsigned int block_selected;
+    if (tid == 0) block_selected = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) selected += __shfl_down(selected, off, 64);
+    if ((tid & 63) == 0 && selected) atomicAdd(&block_selected, selected);
+    __syncthreads();
+    if (tid == 0 && block_selected) atomicAdd(F.rows_selected, (unsigned long long)block_selected);
+}
+
+template <class Spec, int R, int BLOCK, bool WIDE>
+__global__ __launch_bounds__(BLOCK) void scan_spec_records_kernel(const Program P, const FastArgs F, const WordLogArgs L) {
+    scan_spec_records_body<Spec, R, BLOCK, WIDE>(P, F, L);
 }
 
 template <class Spec, int R, int BLOCK, bool WIDE>
@@ -432,49 +586,7 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
         uint32_t tg[R][kRowsPerItem][kFastCols];
         uint64_t pv[R][kRowsPerItem][kFastCols];
         bool valid[R];
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            const uint32_t i = base + (uint32_t)j * BLOCK + tid;
-            valid[j] = i < nitems;
-#pragma unroll
-            for (int c = 0; c < kFastCols; c++) {
-                if (c < Spec::ncols) {
-                    if (Spec::col_kind[c] == COLK_DICT32) {
-                        if (WIDE) {
-                            typedef uint32_t n1k_u32x2 __attribute__((ext_vector_type(2)));
-                            n1k_u32x2 cc = {0xFFFFFFFFu, 0xFFFFFFFFu};
-                            if (valid[j]) cc = __builtin_nontemporal_load((const n1k_u32x2*)F.cols[c].codes + i);
-                            pv[j][0][c] = cc.x;
-                            pv[j][WIDE ? 1 : 0][c] = cc.y;
-                        } else {
-                            pv[j][0][c] = valid[j] ? F.cols[c].codes[i] : 0xFFFFFFFFu;
-                        }
-#pragma unroll
-                        for (int h = 0; h < (int)kRowsPerItem; h++) {
-                            uint32_t code = (uint32_t)pv[j][h][c];
-                            tg[j][h][c] = code == 0xFFFFFFFFu ? (uint32_t)T_MISSING : (code == 0xFFFFFFFEu ? (uint32_t)T_NULL : (uint32_t)T_STRING);
-                        }
-                    } else {
-                        if (WIDE) {
-                            typedef unsigned long long n1k_u64x2 __attribute__((ext_vector_type(2)));
-                            n1k_u64x2 pp = {0ull, 0ull};
-                            if (valid[j]) pp = __builtin_nontemporal_load((const n1k_u64x2*)F.cols[c].payload + i);
-                            uint32_t tt = valid[j] ? (uint32_t)__builtin_nontemporal_load((const uint16_t*)F.cols[c].tags + i) : 0u;
-                            pv[j][0][c] = pp.x;
-                            pv[j][WIDE ? 1 : 0][c] = pp.y;
-                            tg[j][0][c] = tt & 255u;
-                            tg[j][WIDE ? 1 : 0][c] = tt >> 8;
-                        } else {
-                            pv[j][0][c] = valid[j] ? F.cols[c].payload[i] : 0ull;
-                            tg[j][0][c] = valid[j] ? (uint32_t)F.cols[c].tags[i] : (uint32_t)T_MISSING;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int h = 0; h < (int)kRowsPerItem; h++) { tg[j][h][c] = T_MISSING; pv[j][h][c] = 0; }
-                }
-            }
-        }
+        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
         uint64_t mw[kSpecDistinct][kNW];  // this thread's member words of the tile (kEmptyKey = none) and their hash regions
         uint32_t mb[kSpecDistinct][kNW];
 #pragma unroll

@@ -333,6 +333,43 @@ N1K_DEV bool member_word_bits(uint32_t key_bits, uint32_t val_bits, uint64_t key
 // radix digit of a member word / record key: 8 bits of its hash (equal words always share every digit)
 N1K_DEV uint32_t radix_bin(uint64_t w, uint32_t shift) { return (uint32_t)(mix64(w) >> shift) & 255u; }
 
+// ------------------------------------------------------------------ 16-byte records of the partitioned GROUP BY
+//
+// (packed group key, one aggregate operand).  The key's bit 63 is free (packed keys use 63 bits) and says "the operand
+// is an INT"; everything else travels in the operand word: a FLOAT as its bits (any NaN as the canonical quiet NaN), the
+// other tags boxed into a negative quiet NaN that no float of the path ever has: 0xFFF8 << 48 | tag << 40 | payload (a
+// dictionary code: < 2^40).
+struct Rec16 {
+    uint64_t k, v;
+};
+constexpr uint64_t kRecIntFlag = 1ull << 63, kRecBox = 0xFFF8000000000000ull;
+N1K_DEV Rec16 rec16_encode(uint64_t key, uint32_t tag, uint64_t p) {
+    Rec16 r;
+    r.k = key;
+    if (tag == T_INT) {
+        r.k |= kRecIntFlag;
+        r.v = p;
+    } else if (tag == T_FLOAT) {
+        const double d = as_f64(p);
+        r.v = d != d ? 0x7FF8000000000000ull : p;
+    } else
+        r.v = kRecBox | ((uint64_t)tag << 40) | (p & 0xFFFFFFFFFFull);
+    return r;
+}
+N1K_DEV void rec16_decode(const Rec16& r, uint64_t& key, uint32_t& tag, uint64_t& p) {
+    key = r.k & ~kRecIntFlag;
+    if (r.k & kRecIntFlag) {
+        tag = T_INT;
+        p = r.v;
+    } else if ((r.v >> 48) == 0xFFF8ull) {
+        tag = (uint32_t)(r.v >> 40) & 0xFFu;
+        p = r.v & 0xFFFFFFFFFFull;
+    } else {
+        tag = T_FLOAT;
+        p = r.v;
+    }
+}
+
 // perfect-hash slot -> packed group key (inverse of slot = sum(field_k * stride_k))
 N1K_DEV uint64_t fast_slot_key(const FastArgs& F, uint32_t slot) {
     uint64_t key = 0;

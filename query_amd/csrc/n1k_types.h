@@ -33,6 +33,7 @@ constexpr int kMaxLdsWords = 40;   // 1 key word + accumulators
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 // device counters of a handle: [0] rows selected [1] groups [2] out count [3] filter total [4] rehash scratch
 // [5] DISTINCT region words [8..11] pair-log cursors [12] error flags [13] wide key values [16..19] word-log cursors
+// [25] survivor count saved by the optimistic partitioned path
 // [20] COUNT(DISTINCT) optimistic path: set / bin overflow flags [21] records of the partitioned path [22] its singleton
 // partial groups [24] COUNT(DISTINCT) exact path: LDS-set overflow flag
 constexpr uint32_t kCounters = 32;
@@ -233,6 +234,9 @@ struct WordLogArgs {
     uint32_t log_index[kSpecDistinct];
     uint32_t nw_key_bits, nw_val_bits;
     uint32_t dcache_slots, pad;                   // per aggregate: "already logged" cache in LDS (power of two), 0 = none
+    // records mode (the partitioned GROUP BY's 16-byte records, region[0] / region_cursor[0]): set when a region is full —
+    // the engine then redoes the batch on the exact path
+    uint32_t* rec_overflow;
 };
 
 // radix partition of a word log by bits of mix64(word) (finish step of COUNT(DISTINCT), see n1k_kernels.hip)
@@ -281,6 +285,12 @@ struct ProjectArgs {
 };
 struct BinAggArgs {
     RecArrays in;
+    // ... or 16-byte records (Rec16, n1k_tables.h) in bins of fixed capacity: bin i is rec[i * bin_stride .. + min(
+    // bin_count[i], bin_stride)); entries whose key is kEmptyKey are padding
+    const void* rec;
+    const unsigned long long* bin_count;  // (entry i at bin_count[i * bin_count_stride])
+    uint64_t bin_stride;
+    uint32_t bin_count_stride, pad1;
     const uint64_t* bin_start;  // nbins + 1
     uint32_t nbins;
     uint32_t nsrc;
