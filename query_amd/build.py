@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libn1k.so")
-SOURCES = ["n1k_kernels.hip", "n1k_plan.cpp", "n1k_engine.cpp", "n1k_jit.cpp", "n1k_json.cpp"]
-HEADERS = ["n1k_types.h", "n1k_device.h", "n1k_tables.h", "n1k_spec.h", "n1k_jit.h", "n1k_kernels.h", "n1k_plan.h", os.path.join("..", "..", "include", "n1k.h")]
+SOURCES = ["n1k_kernels.hip", "n1k_bins.hip", "n1k_plan.cpp", "n1k_engine.cpp", "n1k_jit.cpp", "n1k_json.cpp"]
+HEADERS = ["n1k_types.h", "n1k_device.h", "n1k_tables.h", "n1k_scatter.h", "n1k_spec.h", "n1k_jit.h", "n1k_kernels.h", "n1k_plan.h", os.path.join("..", "..", "include", "n1k.h")]
 ARCH = "gfx950"
 
 
@@ -24,24 +24,45 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+OBJDIR = os.path.join(CSRC, "build")  # objects: git-ignored, rebuilt per source when it or any header is newer
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    mt = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, f)) > mt:
-            return True
-    return False
+    mt = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > mt for d in deps)
+
+
+def needs_build() -> bool:
+    return _stale(LIB, [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (compiled in parallel, only the stale ones), then one link."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-           "-Wall", "-Wno-unused-function", "-o", LIB]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-lhiprtc", "-lrccl", "-ldl", "-pthread"]  # hiprtc: run-time instantiation of the plan-specialised kernel
-    # (n1k_jit.cpp); rccl: the multi-GPU exchange behind the ABI (n1k_comm_*, n1k_exchange_*)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.abspath(__file__)]
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if force or _stale(obj, [path] + headers):
+            cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    # hiprtc: run-time instantiation of the plan-specialised kernel (n1k_jit.cpp); rccl: the multi-GPU exchange behind
+    # the ABI (n1k_comm_*, n1k_exchange_*)
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lhiprtc", "-lrccl", "-ldl", "-pthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

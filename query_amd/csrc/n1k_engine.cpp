@@ -99,6 +99,7 @@ struct n1k_handle {
     DevBuf<uint64_t> d_rregion, d_rbins;
     DevBuf<unsigned long long> d_rcursor;
     uint32_t opt_records = 1;  // 0: always the three-array records of the interpreter front end (ablation, tests)
+    uint32_t opt_rec_slots = 0, opt_rec_bins = 0, opt_rec_slices = 0, opt_rec_unroll = 0;  // tuning (0 = chosen from the data)
     // ... or instead of it: while the table is empty and their keys are unique, the region IS the set of groups;
     // n1k_finish finalizes it directly, anything else that needs the table merges it first (flush_pending)
     struct { uint64_t count = 0, cap = 0; } pending;
@@ -130,6 +131,7 @@ struct n1k_handle {
     uint32_t opt_json_threads = 0;  // 0 = hardware concurrency (at most 16)
     bool out_count_dirty = true;  // the finalize position counter holds a previous finish's count
     char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
+    unsigned long long* pin_counters = nullptr;  // pinned host copy of the device counters (one D2H per decision point)
     size_t pin_cap = 0;
     std::string jit_log;
     int device = -1;
@@ -1419,7 +1421,8 @@ n1k_status run_group_partitioned(n1k_handle* h, const n1k_batch* b, const Partit
 // bins have fixed capacities (mix64 spreads the keys evenly unless few keys own most rows); when either overflows —
 // or the plan's shape has no specialised kernel — *done stays false, nothing of the batch has been kept, and the caller
 // runs the exact path (run_group_partitioned: histogram-driven passes over three-array records).
-n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionPlan& pp, bool may_keep_region, bool* done) {
+n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionPlan& pp, uint64_t groups_est, bool may_keep_region,
+                             bool* done) {
     *done = false;
     Program& P = h->prog;
     const uint64_t n = b->nrows;
@@ -1440,24 +1443,36 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
     if (!spec && !jit) return N1K_OK;
     n1k_status st = ensure_table(h, 0);
     if (st != N1K_OK) return st;
-    // capacities: a region takes its share of the rows plus a quarter, plus the three chunks every workgroup reserves
-    // (and pads) per region; a bin its share plus a half
-    const uint64_t tiles = (n / 2 + 1023) / 1024;
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 2, (tiles + 3) / 4));
-    uint64_t cap = (n + n / 4) / 256 + ((uint64_t)grid + 1) * 3 * 16 + n / 8192 + 4096;
-    cap = (cap + 15) / 16 * 16;
-    const bool second = n > 256ull * 1024;
-    const uint64_t mean = n / 65536 + 1, bin_cap = mean + mean / 2 + 256;
-    HIP_TRY(h, h->d_rregion.ensure(2 * 256 * cap));
-    HIP_TRY(h, h->d_rcursor.ensure(256 * kCursorStride));
-    if (second) {
-        HIP_TRY(h, h->d_rbins.ensure(2 * 65536 * bin_cap));
-        HIP_TRY(h, h->d_cursor.ensure(65536));
-    }
+    // the scan: tiles of 4096 rows, a grid that is a multiple of 8 (sub-region = workgroup label, n1k_spec.h)
+    const uint64_t tiles = (n + 4095) / 4096;
+    const uint32_t grid = (uint32_t)((std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 2, tiles)) + 7) / 8 * 8);
+    // The per-bin LDS tables: `slots` slots each (option rec_slots), filled to 5/8 at most; the second pass splits every
+    // hash region into as many bins (a power of two <= 256, option rec_bins) as it takes for a bin's expected groups —
+    // the probe's estimate carries a factor of two already — to stay under half of that.
+    uint32_t slots = h->opt_rec_slots ? h->opt_rec_slots : 1024u;
+    while (slots > 64 && (size_t)slots * P.lds_words * 8 > 64u * 1024u) slots /= 2;
+    if ((size_t)slots * P.lds_words * 8 > 64u * 1024u) return N1K_OK;
+    const uint64_t groups = std::min<uint64_t>(groups_est, n);
+    const uint64_t want_bins = groups / (slots / 2) + 1;
+    uint32_t bps = 1;  // bins per region
+    while (bps < 256 && 256ull * bps < want_bins) bps *= 2;
+    if (h->opt_rec_bins) bps = h->opt_rec_bins;
+    const uint64_t nbins = 256ull * bps;
+    // Capacities.  A bin's (a sub-region's) record count is a sum over its groups: variance = mean x (rows per group + 1);
+    // six deviations and an eighth (a quarter) on top.  Whatever overflows raises a flag and the batch takes the exact path.
+    const double rows_per_group = std::min<double>((double)n, 2.0 * (double)n / (double)std::max<uint64_t>(groups, 1) + 1.0);
+    const uint64_t mean = n / nbins + 1;
+    const uint64_t bin_cap = mean + mean / 8 + (uint64_t)(6.0 * std::sqrt((double)mean * (rows_per_group + 1.0))) + 64;
+    const uint64_t nsub = 256ull * kRecSubs, sub_mean = n / nsub + 1;
+    const uint64_t cap = sub_mean + sub_mean / 4 + (uint64_t)(6.0 * std::sqrt((double)sub_mean * (rows_per_group + 1.0))) + 256;
+    HIP_TRY(h, h->d_rregion.ensure(2 * nsub * cap));
+    HIP_TRY(h, h->d_rcursor.ensure(nsub * kCursorStride));
+    HIP_TRY(h, h->d_rbins.ensure(2 * nbins * bin_cap));
+    HIP_TRY(h, h->d_cursor.ensure(65536));
     uint32_t* d_flags = (uint32_t*)(h->d_counters.p + 20);  // [0] a hash region overflowed, [1] a bin
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
     if (e0) (void)hipEventRecord(e0, h->stream);
-    HIP_TRY(h, hipMemsetAsync(h->d_rcursor.p, 0, 256 * kCursorStride * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_rcursor.p, 0, nsub * kCursorStride * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipMemsetAsync(d_flags, 0, 8, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_counters.p + 25, h->d_counters.p + 0, 8, hipMemcpyDeviceToDevice, h->stream));  // rows_selected, to undo
     // (1) Filter + packed key + operand -> records in the hash regions
@@ -1477,45 +1492,35 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
     L.region_cursor[0] = h->d_rcursor.p;
     L.region_cap = cap;
     L.rec_overflow = d_flags;
+    L.pad = h->opt_spec_debug & 3u;  // (timing experiments only)
     if (spec) HIP_TRY(h, spec->launch_records(P, F, grid, wide, L, h->stream));
     else HIP_TRY(h, jit_launch_records(jit, P, F, grid, wide, L, h->stream));
-    // (2) the second partition pass, into bins of fixed capacity
+    // (2) the second partition pass: the regions' 8 sub-regions into `bps` bins of fixed capacity per region
     BinAggArgs B{};
     B.nsrc = pp.nsrc;
-    if (second) {
+    {
         RadixArgs R{};
         R.src = h->d_rregion.p;
         R.dst = h->d_rbins.p;
         R.seg_count = h->d_rcursor.p;
         R.seg_stride = cap;
-        R.nseg = 256;
+        R.nseg = (uint32_t)nsub;
         R.shift = 48;
         R.cursor = h->d_cursor.p;
         R.bin_cap = bin_cap;
         R.overflow = d_flags + 1;
-        const uint64_t seg_tiles = (cap + 4095) / 4096;
-        const uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / 256 + 8, seg_tiles));
-        HIP_TRY(h, launch_radix_scatter16(R, slices, h->stream));
+        const uint64_t region_tiles = (n / 256 + 4095) / 4096 + kRecSubs;
+        const uint32_t wpr = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(h->opt_rec_slices ? h->opt_rec_slices : 8u, region_tiles));
+        HIP_TRY(h, launch_radix_scatter16(R, wpr, bps, h->stream));
         B.rec = h->d_rbins.p;
         B.bin_count = h->d_cursor.p;
         B.bin_count_stride = 1;
         B.bin_stride = bin_cap;
-        B.nbins = 65536;
-    } else {
-        B.rec = h->d_rregion.p;
-        B.bin_count = h->d_rcursor.p;
-        B.bin_count_stride = kCursorStride;
-        B.bin_stride = cap;
-        B.nbins = 256;
+        B.nbins = (uint32_t)nbins;
     }
     // (3) one workgroup per bin: InitialGroup in an LDS table, the bin's groups into the compact region
-    uint32_t slots = (uint32_t)std::min<uint64_t>((64u * 1024u) / (P.lds_words * 8), 1u << 13);
-    if (slots < 64) return N1K_OK;
-    const uint64_t per = n / B.nbins + 1;  // records (hence groups at most) a bin holds on average
-    uint32_t bslots = slots;
-    while (bslots > 256 && (uint64_t)bslots / 4 >= per) bslots /= 2;
-    B.lds_slots = bslots;
-    B.lds_max_fill = std::max(1u, bslots * 5 / 8);
+    B.lds_slots = slots;
+    B.lds_max_fill = std::max(1u, slots * 5 / 8);
     for (uint32_t a = 0; a < kMaxAggs; a++) B.agg_src[a] = a < P.naggs ? pp.agg_src[a] : 0xFFFFFFFFu;
     B.err_flags = h->d_errp;
     uint32_t nsum = 0;
@@ -1529,18 +1534,21 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
     B.emit_singletons = h->d_counters.p + 22;
     HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 22, 0, sizeof(unsigned long long), h->stream));
     {
-        const size_t shmem = (size_t)bslots * P.lds_words * 8 + 1024;
+        const size_t shmem = (size_t)slots * P.lds_words * 8 + 1024;
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
         const uint32_t bgrid = (uint32_t)std::min<uint64_t>(B.nbins, (uint64_t)h->num_cus * per_cu);
-        HIP_TRY(h, launch_agg_bins(P, B, h->table, h->d_counters.p + 1, bgrid, h->stream));
+        const uint64_t per_thread = mean / 512 + 1;
+        HIP_TRY(h, launch_agg_bins16(P, B, bgrid, h->opt_rec_unroll ? h->opt_rec_unroll : (uint32_t)std::min<uint64_t>(per_thread, 4), h->stream));
     }
-    unsigned long long emitted = 0, have = 0, singletons = 0;
-    uint32_t flags[2] = {0, 0};
-    HIP_TRY(h, hipMemcpyAsync(&singletons, h->d_counters.p + 22, sizeof singletons, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&emitted, h->d_emit.p, sizeof emitted, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&have, h->d_counters.p + 1, sizeof have, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, h->stream));
+    // one copy of the counters into pinned memory (the region's group count joins them first): one host round trip
+    if (!h->pin_counters) HIP_TRY(h, hipHostMalloc((void**)&h->pin_counters, kCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(h, hipMemcpyAsync(h->d_counters.p + 26, h->d_emit.p, 8, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->pin_counters, h->d_counters.p, kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    unsigned long long emitted = h->pin_counters[26];
+    const unsigned long long have = h->pin_counters[1], singletons = h->pin_counters[22];
+    uint32_t flags[2];
+    memcpy(flags, &h->pin_counters[20], 8);
     if (flags[0] | flags[1]) {
         // a region or a bin overflowed: nothing was merged anywhere yet — forget the records and the survivor count
         HIP_TRY(h, hipMemcpyAsync(h->d_counters.p + 0, h->d_counters.p + 25, 8, hipMemcpyDeviceToDevice, h->stream));
@@ -1650,7 +1658,7 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
         if (!h->plan.has_group) st = run_filter_batch(h, &v);
         else if (partition) {
             bool done = false;
-            st = run_group_records(h, &v, pp, first_rows, &done);
+            st = run_group_records(h, &v, pp, groups_est, first_rows, &done);
             if (st == N1K_OK && !done) st = run_group_partitioned(h, &v, pp, groups_est, first_rows);
         } else
             st = run_group_batch(h, &v);
@@ -1945,6 +1953,7 @@ static void destroy_handle(n1k_handle* h) {
         h->d_wide_int.release();
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
+        if (h->pin_counters) (void)hipHostFree(h->pin_counters);
         h->d_emit.release();
         h->d_rregion.release();
         h->d_rbins.release();
@@ -2080,6 +2089,16 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         h->opt_distinct_set_slots = v;
     } else if (n == "records") {
         h->opt_records = value ? 1 : 0;
+    } else if (n == "rec_slots") {
+        h->opt_rec_slots = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8192);
+    } else if (n == "rec_bins") {
+        uint32_t v = 0;
+        if (value > 0) for (v = 1; v < (uint32_t)std::min<int64_t>(value, 256); v <<= 1) {}
+        h->opt_rec_bins = v;
+    } else if (n == "rec_slices") {
+        h->opt_rec_slices = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64);
+    } else if (n == "rec_unroll") {
+        h->opt_rec_unroll = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8);
     } else if (n == "spec_debug") {
         h->opt_spec_debug = (uint32_t)value;
     } else if (n == "distinct_region_cap") {

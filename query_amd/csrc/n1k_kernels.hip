@@ -570,88 +570,6 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
     }
 }
 
-// The second partition pass of the 16-byte records (partitioned GROUP BY): segment s = hash region s (fixed capacity,
-// its record count in seg_count), bins of fixed capacity like the member words' second pass — the keys were spread by
-// mix64, so a bin holds its share unless few keys own most rows, in which case *overflow is set and the engine redoes
-// the batch on the exact path.  Records whose key is kEmptyKey are the regions' padding and stay behind.
-constexpr int kRec16Per = 8, kRec16Tile = kRadixBlock * kRec16Per;  // 4096 records = 64 KB staged
-__global__ __launch_bounds__(kRadixBlock) void radix_scatter16_kernel(const RadixArgs A) {
-    extern __shared__ uint64_t dyn16[];
-    Rec16* stage = (Rec16*)dyn16;
-    __shared__ uint32_t cnt[256], pre[256], wsum[4];
-    __shared__ unsigned long long gbase[256];
-    const uint32_t tid = threadIdx.x, s = blockIdx.y, cstride = A.cursor_stride ? A.cursor_stride : 1u;
-    const Rec16* src = (const Rec16*)A.src;
-    Rec16* dst = (Rec16*)A.dst;
-    // slice of the segment this workgroup owns, in whole tiles
-    const uint64_t c0 = A.seg_count[(size_t)s * kCursorStride];
-    const uint64_t s0 = (uint64_t)s * A.seg_stride, s1 = s0 + (c0 < A.seg_stride ? c0 : A.seg_stride);
-    uint64_t chunk = (s1 - s0 + gridDim.x - 1) / gridDim.x;
-    chunk = (chunk + kRec16Tile - 1) / kRec16Tile * kRec16Tile;
-    uint64_t lo = s0 + (uint64_t)blockIdx.x * chunk, hi = lo + chunk < s1 ? lo + chunk : s1;
-    if (lo > s1) lo = hi = s1;
-    for (uint64_t tile = lo; tile < hi; tile += kRec16Tile) {
-        const uint32_t n = (uint32_t)(hi - tile < (uint64_t)kRec16Tile ? hi - tile : (uint64_t)kRec16Tile);
-        if (tid < 256) cnt[tid] = 0;
-        __syncthreads();
-        Rec16 w[kRec16Per];
-        uint32_t rk[kRec16Per];
-#pragma unroll
-        for (int j = 0; j < kRec16Per; j++) {
-            const uint32_t p = (uint32_t)j * kRadixBlock + tid;
-            if (p < n) w[j] = src[tile + p];
-            else { w[j].k = kEmptyKey; w[j].v = 0; }
-        }
-#pragma unroll
-        for (int j = 0; j < kRec16Per; j++) {
-            rk[j] = 0xFFFFFFFFu;
-            if (w[j].k != kEmptyKey) {
-                const uint32_t b = radix_bin(w[j].k & ~kRecIntFlag, A.shift);
-                rk[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
-            }
-        }
-        __syncthreads();
-        uint32_t mine = tid < 256 ? cnt[tid] : 0u, incl = mine;
-        if (tid < 256) {
-            for (int off = 1; off < 64; off <<= 1) {
-                uint32_t t = __shfl_up(incl, off, 64);
-                if ((int)(tid & 63) >= off) incl += t;
-            }
-            if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-        }
-        __syncthreads();
-        if (tid < 256) {
-            uint32_t before = 0;
-            for (uint32_t q = 0; q < (tid >> 6); q++) before += wsum[q];
-            pre[tid] = before + incl - mine;
-            gbase[tid] = mine ? atomicAdd(&A.cursor[((size_t)s * 256 + tid) * cstride], (unsigned long long)mine) : 0ull;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kRec16Per; j++)
-            if (rk[j] != 0xFFFFFFFFu) stage[pre[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = w[j];
-        __syncthreads();
-        const uint32_t staged = pre[255] + cnt[255];
-        for (uint32_t p = tid; p < staged; p += kRadixBlock) {
-            const Rec16 x = stage[p];
-            const uint32_t b = radix_bin(x.k & ~kRecIntFlag, A.shift);
-            const unsigned long long pos = gbase[b] + (p - pre[b]);
-            if (pos < A.bin_cap) dst[((size_t)s * 256 + b) * A.bin_cap + pos] = x;
-            else *(volatile uint32_t*)A.overflow = 1u;
-        }
-        __syncthreads();
-    }
-}
-
-hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t slices, hipStream_t st) {
-    (void)hipMemsetAsync(A.cursor, 0, (size_t)A.nseg * 256 * (A.cursor_stride ? A.cursor_stride : 1u) * sizeof(unsigned long long), st);
-    auto k = radix_scatter16_kernel;
-    const size_t shmem = (size_t)kRec16Tile * sizeof(Rec16);
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k, dim3(slices, A.nseg), dim3(kRadixBlock), shmem, st, A);
-    return hipGetLastError();
-}
-
 // one workgroup per bin (persistent over bins): LDS open-addressed set of the bin's words; every first insertion is
 // one more member of its group's set (Set.Len(), value/set.go:198-215), counted in LDS per packed group key — by the
 // key itself when the keys are small (direct_keys), else in a second LDS table keyed by the packed key — and handed
@@ -1346,22 +1264,22 @@ static hipError_t launch_spec(const Program& P, const FastArgs& F, const GlobalT
     return hipGetLastError();
 }
 
-// records mode of a shape (n1k_spec.h): Filter + packed key, 16-byte records into the hash regions
+// records mode of a shape (n1k_spec.h): Filter + packed key, 16-byte records into the hash regions; tiles of 4096 rows
 template <class Spec>
 static hipError_t launch_spec_records(const Program& P, const FastArgs& F, uint32_t grid, bool wide, const WordLogArgs& L, hipStream_t st) {
-    const size_t shmem = sizeof(WcLdsT<Rec16>);
+    const size_t shmem = sizeof(ScatterLds<512, 8>);
     if (wide) {
-        auto k = scan_spec_records_kernel<Spec, 2, 512, true>;
+        auto k = scan_spec_records_kernel<Spec, 4, 512, true>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), shmem, st, P, F, L);
     } else {
-        auto k = scan_spec_records_kernel<Spec, 4, 512, false>;
+        auto k = scan_spec_records_kernel<Spec, 8, 512, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), shmem, st, P, F, L);
     }
     return hipGetLastError();
 }
-size_t spec_records_lds_bytes() { return sizeof(WcLdsT<Rec16>); }
+size_t spec_records_lds_bytes() { return sizeof(ScatterLds<512, 8>); }
 
 const std::vector<SpecEntry>& spec_registry() {
     static const std::vector<SpecEntry> reg = {
@@ -2069,7 +1987,7 @@ template <int R, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void probe_keys_kernel(const Program P, uint64_t nrows, const GlobalTable G, uint32_t* err_flags,
                                                           unsigned long long* ngroups) {
     const uint32_t tid = threadIdx.x;
-    uint32_t unsupported = 0;
+    uint32_t unsupported = 0, fresh = 0;
     const uint64_t tile_rows = (uint64_t)BLOCK * R;
     const uint64_t ntiles = (nrows + tile_rows - 1) / tile_rows;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -2097,9 +2015,21 @@ __global__ __launch_bounds__(BLOCK) void probe_keys_kernel(const Program P, uint
             }
         }
 #pragma unroll
-        for (int j = 0; j < R; j++)
-            if (pass[j]) (void)global_find_or_insert(G, key[j], err_flags, ngroups);
+        for (int j = 0; j < R; j++) {
+            bool f = false;
+            if (pass[j]) (void)global_find_or_insert_quiet(G, key[j], err_flags, f);
+            fresh += f ? 1u : 0u;
+        }
     }
+    // new groups: one atomic per workgroup (same-address atomics cost ~10 ns each; a probe of all-new keys spent 0.4 ms
+    // on one per wave and row)
+    __shared__ unsigned int block_fresh;
+    if (tid == 0) block_fresh = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) fresh += __shfl_down(fresh, off, 64);
+    if ((tid & 63) == 0 && fresh) atomicAdd(&block_fresh, fresh);
+    __syncthreads();
+    if (tid == 0 && block_fresh) atomicAdd(ngroups, (unsigned long long)block_fresh);
 }
 
 template <int BLOCK>

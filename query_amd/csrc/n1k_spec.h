@@ -9,6 +9,7 @@
 //
 // WIDE: two adjacent rows per lane and load: payload 16 B, tags 2 B, codes 8 B per lane (needs aligned bases).
 #pragma once
+#include "n1k_scatter.h"
 #include "n1k_tables.h"
 
 namespace n1k {
@@ -312,12 +313,9 @@ N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, u
 // which every reader of the regions skips.  (Region capacities and all reservations are multiples of kWcChunk.)
 constexpr uint32_t kWcSlots = 16, kWcChunk = 16;
 
-// The same machinery moves 8-byte member words (COUNT(DISTINCT)) and 16-byte records (the partitioned GROUP BY: packed
-// key + one operand, Rec16 in n1k_tables.h); "no element" is kEmptyKey / a record whose key is kEmptyKey.
+// (templated on the element: 8-byte member words today; "no element" is kEmptyKey)
 N1K_DEV bool wc_none(uint64_t w) { return w == kEmptyKey; }
-N1K_DEV bool wc_none(const Rec16& r) { return r.k == kEmptyKey; }
 N1K_DEV void wc_set_none(uint64_t& w) { w = kEmptyKey; }
-N1K_DEV void wc_set_none(Rec16& r) { r.k = kEmptyKey; r.v = 0; }
 
 // LDS of one stream of elements.  The chunk state and the tile counters exist twice: in tile t everybody reads copy
 // t & 1 and region b's owner writes copy (t + 1) & 1, so that the owners' updates need no barrier of their own.
@@ -349,7 +347,6 @@ N1K_DEV void wc_over_append(const WordLogArgs& L, int d, uint32_t b, uint64_t wo
     } else
         atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
 }
-N1K_DEV void wc_over_append(const WordLogArgs& L, int, uint32_t, const Rec16&, uint32_t*) { *(volatile uint32_t*)L.rec_overflow = 1u; }
 
 // a reservation [base, base + kWcChunk) as a chunk: inside the region or not at all (both are multiples of kWcChunk)
 N1K_DEV uint32_t wc_chunk(const WordLogArgs& L, unsigned long long base) {
@@ -464,14 +461,24 @@ N1K_DEV void wc_finish(const WordLogArgs& L, int d, WcLdsT<E>& W, uint32_t par, 
 //
 // High-cardinality GROUP BY (N1K_MODE_PARTITIONED): no workgroup table would absorb anything, so the specialised scan
 // only evaluates the Filter, packs the group key and scatters (key, operand) records by the first radix digit of
-// mix64(key) into the 256 hash regions — the projection and the first partition pass of the partitioned path in one
-// kernel, reading the columns once and writing 16 bytes per surviving row.
+// mix64(key) into 256 hash regions — the projection and the first partition pass of the partitioned path in one
+// kernel, reading the columns once and writing 16 bytes per surviving row (scatter_tile, n1k_scatter.h: a tile of
+// BLOCK x kNW rows is ranked, staged in LDS in region order and written in runs).
+//
+// Every region is split into 8 sub-regions, one per workgroup label blockIdx.x % 8: workgroups are dealt round-robin
+// over the 8 XCDs, whose L2s are private, so the partial cache lines at the ends of the runs — the next run of the same
+// sub-region completes them — are merged in ONE L2 before they leave for HBM (with all workgroups appending to one
+// tail the kernel wrote 1.5x its bytes).  Speed only: any placement gives the same records.  Sub-region (r, x) holds
+// region_cap records at (r * 8 + x) * region_cap, its count at region_cursor[0][(r * 8 + x) * kCursorStride].
+
 template <class Spec>
 constexpr int spec_operand_col() {
     for (int a = 0; a < Spec::naggs; a++)
         if (Spec::aggs[a].has_operand) return (int)Spec::aggs[a].col;
     return -1;
 }
+
+N1K_DEV uint32_t rec16_region(const Rec16& r) { return (uint32_t)(mix64(r.k & ~kRecIntFlag) >> 56); }
 
 template <class Spec>
 N1K_DEV void spec_row_record(const Program& P, const FastArgs& F, const uint32_t (&tg)[kFastCols], const uint64_t (&pv)[kFastCols],
@@ -493,21 +500,22 @@ N1K_DEV void spec_row_record(const Program& P, const FastArgs& F, const uint32_t
     selected++;
     constexpr int oc = spec_operand_col<Spec>();
     rec = rec16_encode(key, oc >= 0 ? tg[oc >= 0 ? oc : 0] : (uint32_t)T_NULL, oc >= 0 ? pv[oc >= 0 ? oc : 0] : 0ull);
-    bin = (uint32_t)(mix64(key) >> 56);
+    bin = rec16_region(rec);
 }
 
 template <class Spec, int R, int BLOCK, bool WIDE>
 N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const WordLogArgs& L) {
-    extern __shared__ uint64_t lds[];
-    WcLdsT<Rec16>& W = *(WcLdsT<Rec16>*)lds;
-    const uint32_t tid = threadIdx.x;
     constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
     constexpr int kNW = R * (int)kRowsPerItem;
-    WcOwner own;
-    uint32_t par = 0;
-    wc_init<BLOCK>(L, 0, W, own);
+    extern __shared__ uint64_t lds[];
+    ScatterLds<BLOCK, kNW>& S = *(ScatterLds<BLOCK, kNW>*)lds;
+    const uint32_t tid = threadIdx.x;
+    scatter_init<BLOCK>(S.cnt);
     __syncthreads();
-    uint32_t unpackable = 0, selected = 0;
+    const uint32_t sub = blockIdx.x % kRecSubs;
+    unsigned long long* const cursor = L.region_cursor[0] + (size_t)sub * kCursorStride;
+    Rec16* const dst = (Rec16*)L.region[0] + (size_t)sub * L.region_cap;
+    uint32_t par = 0, unpackable = 0, selected = 0;
     const uint32_t nrows = F.nrows;
     const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
     const uint32_t tile = BLOCK * R;
@@ -523,16 +531,17 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
 #pragma unroll
             for (int h = 0; h < (int)kRowsPerItem; h++) {
                 const int at = j * (int)kRowsPerItem + h;
-                wc_set_none(recs[at]);
-                bins[at] = 0;
+                recs[at].k = kEmptyKey;
+                recs[at].v = 0;
+                bins[at] = kScatterNone;
                 const bool row_ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nrows);
                 if (row_ok) spec_row_record<Spec>(P, F, tg[j][h], pv[j][h], selected, unpackable, recs[at], bins[at]);
             }
         }
-        wc_tile<BLOCK, kNW>(L, 0, recs, bins, W, par, own, F.err_flags);
+        scatter_tile<BLOCK, kNW>(S, par, recs, bins, cursor, kRecSubs * kCursorStride, dst, (uint64_t)kRecSubs * L.region_cap,
+                                 L.region_cap, L.rec_overflow, [](const Rec16& r) { return rec16_region(r); });
         par ^= 1u;
     }
-    wc_finish<BLOCK>(L, 0, W, par, own);
     if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
     __shared__ unsigned int block_selected;
     if (tid == 0) block_selected = 0;

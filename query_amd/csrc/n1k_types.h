@@ -33,7 +33,7 @@ constexpr int kMaxLdsWords = 40;   // 1 key word + accumulators
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 // device counters of a handle: [0] rows selected [1] groups [2] out count [3] filter total [4] rehash scratch
 // [5] DISTINCT region words [8..11] pair-log cursors [12] error flags [13] wide key values [16..19] word-log cursors
-// [25] survivor count saved by the optimistic partitioned path
+// [25] survivor count saved by the optimistic partitioned path [26] its region's group count (copied for the host)
 // [20] COUNT(DISTINCT) optimistic path: set / bin overflow flags [21] records of the partitioned path [22] its singleton
 // partial groups [24] COUNT(DISTINCT) exact path: LDS-set overflow flag
 constexpr uint32_t kCounters = 32;
@@ -268,6 +268,7 @@ struct RadixArgs {
 // High-cardinality GROUP BY: rows are projected to records (packed key + the aggregates' operands), radix
 // partitioned by mix64(key) with the same passes as the COUNT(DISTINCT) words, and aggregated bin by bin in LDS.
 constexpr uint32_t kRecOperands = 2;  // distinct operand sources a record carries
+constexpr uint32_t kRecSubs = 8;      // sub-regions per hash region of the 16-byte records: one per workgroup label (n1k_spec.h)
 struct RecArrays {
     uint64_t* key;
     uint64_t* pay[kRecOperands];
