@@ -173,76 +173,110 @@ __global__ __launch_bounds__(BLOCK) void agg_bins16_kernel(const Program P, cons
         emit_n = 0;
     }
     __syncthreads();
-    for (uint32_t bin = blockIdx.x; bin < A.nbins; bin += gridDim.x) {
-        const uint64_t c = A.bin_count[(size_t)bin * cstride];
-        const uint64_t lo = (uint64_t)bin * A.bin_stride, hi = lo + (c < A.bin_stride ? c : A.bin_stride);
-        if (lo == hi) continue;
-        for (uint64_t base = lo; base < hi; base += (uint64_t)BLOCK * U) {
-            Rec16 r[U];
+    // The workgroup's chunks (BLOCK x U records of one bin) in order, the next one always requested before the current one
+    // is processed — across the end of a bin too, so that loads stay in flight through the barriers and the emit step.
+    struct Chunk {
+        uint32_t bin;
+        uint64_t base, hi;
+    };
+    auto enter = [&](Chunk& c) {  // first chunk of bin c.bin or of the next non-empty bin of this workgroup
+        while (c.bin < A.nbins) {
+            const uint64_t n = A.bin_count[(size_t)c.bin * cstride];
+            c.base = (uint64_t)c.bin * A.bin_stride;
+            c.hi = c.base + (n < A.bin_stride ? n : A.bin_stride);
+            if (c.base < c.hi) return;
+            c.bin += gridDim.x;
+        }
+    };
+    auto load = [&](const Chunk& c, Rec16 (&r)[U]) {
 #pragma unroll
-            for (int j = 0; j < U; j++) {
-                const uint64_t i = base + (uint64_t)j * BLOCK + tid;
-                r[j].k = kEmptyKey;
-                r[j].v = 0;
-                if (i < hi) {
-                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-                    const u64x2 v = __builtin_nontemporal_load((const u64x2*)(rec + i));
-                    r[j].k = v.x;
-                    r[j].v = v.y;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < U; j++) {
-                if (r[j].k == kEmptyKey) continue;  // beyond the bin, or padding of the hash regions
-                uint64_t key, p;
-                uint32_t t;
-                rec16_decode(r[j], key, t, p);
-                const int slot = lds_find_or_insert(lds, S, key, &lds_fill, A.lds_max_fill);
-                if (slot < 0) {  // more groups in the bin than the LDS table takes
-                    emit_single(P, A, key, nullptr, t, p);
-                    continue;
-                }
-                for (uint32_t a = 0; a < P.naggs; a++) {
-                    const bool has = A.agg_src[a] < kRecOperands;
-                    if (!acc_lds(P, P.aggs[a], lds, S, (uint32_t)slot, has ? t : (uint32_t)T_NULL, has ? p : 0ull))
-                        emit_single(P, A, key, &P.aggs[a], t, p);  // |int| >= 2^40: leaves with just this contribution
-                }
+        for (int j = 0; j < U; j++) {
+            const uint64_t i = c.base + (uint64_t)j * BLOCK + tid;
+            r[j].k = kEmptyKey;
+            r[j].v = 0;
+            if (c.bin < A.nbins && i < c.hi) {
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 v = __builtin_nontemporal_load((const u64x2*)(rec + i));
+                r[j].k = v.x;
+                r[j].v = v.y;
             }
         }
-        __syncthreads();
-        if (tid == 0) {
-            const uint32_t n = lds_fill;
-            emit_base = n ? atomicAdd((unsigned long long*)&A.emit[0], (unsigned long long)n) : 0ull;
-            lds_fill = 0;
-            emit_n = 0;
+    };
+    Chunk cur;
+    cur.bin = blockIdx.x;
+    cur.base = cur.hi = 0;
+    enter(cur);
+    Rec16 r[U], rn[U];
+    load(cur, r);
+    while (cur.bin < A.nbins) {
+        Chunk nxt = cur;
+        nxt.base += (uint64_t)BLOCK * U;
+        if (nxt.base >= nxt.hi) {
+            nxt.bin += gridDim.x;
+            enter(nxt);
         }
-        __syncthreads();
-        const unsigned long long q0 = emit_base;
-        for (uint32_t s = tid; s < S; s += BLOCK) {
-            const uint64_t key = lds[s];
-            if (key == kEmptyKey) continue;
-            const unsigned long long q = q0 + atomicAdd(&emit_n, 1u);
-            if (q < A.emit_cap) {
-                A.emit[2 + q] = key;
-                store_slot(P, lds, S, s, A.emit + 2 + A.emit_cap + q * P.glob_words);
-            } else
-                atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
-            lds_slot_reset(P, lds, S, s);
+        load(nxt, rn);
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            if (r[j].k == kEmptyKey) continue;  // beyond the bin
+            uint64_t key, p;
+            uint32_t t;
+            rec16_decode(r[j], key, t, p);
+            const int slot = lds_find_or_insert(lds, S, key, &lds_fill, A.lds_max_fill);
+            if (slot < 0) {  // more groups in the bin than the LDS table takes
+                emit_single(P, A, key, nullptr, t, p);
+                continue;
+            }
+            for (uint32_t a = 0; a < P.naggs; a++) {
+                const bool has = A.agg_src[a] < kRecOperands;
+                if (!acc_lds(P, P.aggs[a], lds, S, (uint32_t)slot, has ? t : (uint32_t)T_NULL, has ? p : 0ull))
+                    emit_single(P, A, key, &P.aggs[a], t, p);  // |int| >= 2^40: leaves with just this contribution
+            }
         }
-        __syncthreads();
+        if (nxt.bin != cur.bin) {
+            // end of the bin: its groups join the compact region, every slot they used is reset
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t n = lds_fill;
+                emit_base = n ? atomicAdd((unsigned long long*)&A.emit[0], (unsigned long long)n) : 0ull;
+                lds_fill = 0;
+                emit_n = 0;
+            }
+            __syncthreads();
+            const unsigned long long q0 = emit_base;
+            for (uint32_t s = tid; s < S; s += BLOCK) {
+                const uint64_t key = lds[s];
+                if (key == kEmptyKey) continue;
+                const unsigned long long q = q0 + atomicAdd(&emit_n, 1u);
+                if (q < A.emit_cap) {
+                    A.emit[2 + q] = key;
+                    store_slot(P, lds, S, s, A.emit + 2 + A.emit_cap + q * P.glob_words);
+                } else
+                    atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
+                lds_slot_reset(P, lds, S, s);
+            }
+            __syncthreads();
+        }
+        cur = nxt;
+#pragma unroll
+        for (int j = 0; j < U; j++) r[j] = rn[j];
     }
 }
 
-hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t per_thread, hipStream_t st) {
+hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t block, uint32_t per_thread, hipStream_t st) {
     const size_t shmem = (size_t)A.lds_slots * P.lds_words * 8;
-#define N1K_AGG16(UU)                                                                                             \
+#define N1K_AGG16(BB, UU)                                                                                         \
     {                                                                                                             \
-        auto k = agg_bins16_kernel<kBlock, UU>;                                                                   \
+        auto k = agg_bins16_kernel<BB, UU>;                                                                       \
         if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), shmem, st, P, A);                                          \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(BB), shmem, st, P, A);                                              \
     }
-    if (per_thread <= 2) N1K_AGG16(2)
-    else N1K_AGG16(4)  // (8 in flight spilled to scratch)
+    // (8 records in flight per thread spilled to scratch)
+    if (block <= 256) {
+        if (per_thread <= 2) N1K_AGG16(256, 2) else N1K_AGG16(256, 4)
+    } else {
+        if (per_thread <= 2) N1K_AGG16(512, 2) else N1K_AGG16(512, 4)
+    }
 #undef N1K_AGG16
     return hipGetLastError();
 }

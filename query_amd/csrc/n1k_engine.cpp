@@ -99,7 +99,7 @@ struct n1k_handle {
     DevBuf<uint64_t> d_rregion, d_rbins;
     DevBuf<unsigned long long> d_rcursor;
     uint32_t opt_records = 1;  // 0: always the three-array records of the interpreter front end (ablation, tests)
-    uint32_t opt_rec_slots = 0, opt_rec_bins = 0, opt_rec_slices = 0, opt_rec_unroll = 0;  // tuning (0 = chosen from the data)
+    uint32_t opt_rec_slots = 0, opt_rec_bins = 0, opt_rec_slices = 0, opt_rec_unroll = 0, opt_rec_block = 0;  // tuning (0 = chosen from the data)
     // ... or instead of it: while the table is empty and their keys are unique, the region IS the set of groups;
     // n1k_finish finalizes it directly, anything else that needs the table merges it first (flush_pending)
     struct { uint64_t count = 0, cap = 0; } pending;
@@ -1534,11 +1534,12 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
     B.emit_singletons = h->d_counters.p + 22;
     HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 22, 0, sizeof(unsigned long long), h->stream));
     {
+        const uint32_t block = h->opt_rec_block ? h->opt_rec_block : 256u;
         const size_t shmem = (size_t)slots * P.lds_words * 8 + 1024;
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / shmem));
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / block / 2, (160 * 1024) / shmem));
         const uint32_t bgrid = (uint32_t)std::min<uint64_t>(B.nbins, (uint64_t)h->num_cus * per_cu);
-        const uint64_t per_thread = mean / 512 + 1;
-        HIP_TRY(h, launch_agg_bins16(P, B, bgrid, h->opt_rec_unroll ? h->opt_rec_unroll : (uint32_t)std::min<uint64_t>(per_thread, 4), h->stream));
+        const uint64_t per_thread = mean / block + 1;
+        HIP_TRY(h, launch_agg_bins16(P, B, bgrid, block, h->opt_rec_unroll ? h->opt_rec_unroll : (uint32_t)std::min<uint64_t>(per_thread, 4), h->stream));
     }
     // one copy of the counters into pinned memory (the region's group count joins them first): one host round trip
     if (!h->pin_counters) HIP_TRY(h, hipHostMalloc((void**)&h->pin_counters, kCounters * sizeof(unsigned long long), hipHostMallocDefault));
@@ -2097,6 +2098,8 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         h->opt_rec_bins = v;
     } else if (n == "rec_slices") {
         h->opt_rec_slices = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64);
+    } else if (n == "rec_block") {
+        h->opt_rec_block = value <= 0 ? 0u : (value <= 256 ? 256u : 512u);
     } else if (n == "rec_unroll") {
         h->opt_rec_unroll = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8);
     } else if (n == "spec_debug") {

@@ -100,9 +100,9 @@ struct SpecEntry {
 };
 size_t spec_records_lds_bytes();
 // n1k_bins.hip: the partitioned GROUP BY over 16-byte records — second partition pass (`bins_per_seg` bins of fixed capacity
-// per hash region, a power of two <= 256) and the per-bin LDS tables (`per_thread` = records a thread loads at once)
+// per hash region, a power of two <= 256) and the per-bin LDS tables (`block` threads per bin, `per_thread` = records a thread loads at once)
 hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t slices, uint32_t bins_per_seg, hipStream_t st);
-hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t per_thread, hipStream_t st);
+hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t block, uint32_t per_thread, hipStream_t st);
 const std::vector<SpecEntry>& spec_registry();
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,
                            OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count, uint64_t max_out,
