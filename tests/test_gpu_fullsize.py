@@ -33,11 +33,11 @@ def columns():
     return bench.DeviceColumns(ROWS, K_CAT, False, 0, ROWS, 0)
 
 
-def run(columns, cond, keys, aggs, ranges, filter_only=False, **opts):
+def run(columns, cond, keys, aggs, ranges, filter_only=False, kcat=K_CAT, order=None, limit=None, **opts):
     """Push the given row ranges of the resident columns as separate device batches."""
     import bench
-    op = query_amd.GpuFilterGroup(plan.filter_group_plan(cond, keys, aggs, filter_only=filter_only), **opts)
-    op.intern(bench.synth_dictionary(K_CAT))
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(cond, keys, aggs, filter_only=filter_only, order=order, limit=limit), **opts)
+    op.intern(bench.synth_dictionary(kcat))
     for lo, hi in ranges:
         cols = []
         for p in op.column_paths:
@@ -186,3 +186,73 @@ def test_full_size_high_cardinality_paths_agree(columns):
     assert np.array_equal(pa["v"], sa["v"])  # COUNT, integer SUM and MAX are bit-exact whatever the order of the rows
     ci = aggs.index("count(*)")
     assert int(pa[:, ci]["v"].astype(np.int64).sum()) == ROWS
+
+
+def test_full_size_config5_own_query():
+    """BASELINE config 5's own query — GROUP BY cat, region_id (K_cat = 100 000: 6.4 M groups) ORDER BY SUM(price) DESC
+    LIMIT 100 — at 100 M rows: the partitioned path with the plan-specialised records front end (chosen from the data)
+    against the scan-kernel path (LDS hash + global table) and the three-array partitioned path, rank by rank and, without
+    the tail, group by group; then the same query on a prefix of the same data set against the oracle."""
+    import bench
+    k5 = 100_000
+    cols = bench.DeviceColumns(ROWS, k5, False, 0, ROWS, 0)
+    keys = [D("cat"), D("region_id")]
+    aggs = ["sum(%s)" % D("price")]
+    order = [(aggs[0], True)]
+
+    def f64(v):
+        return v.astype(np.uint64).view(np.float64)
+
+    def near(a, b):
+        return np.abs(a - b) <= 1e-9 * np.maximum(np.abs(a), np.abs(b))
+
+    # --- the tail: 100 rows leave the device
+    rec, rst = run(cols, None, keys, aggs, [(0, ROWS)], kcat=k5, order=order, limit=100)
+    assert rst["agg_mode"] == 4 and rst["spec_kernel"] != 0  # partitioned, records written by the specialised scan
+    assert rec["ngroups"] == 100 and rst["rows_selected"] == ROWS
+    scan, sst = run(cols, None, keys, aggs, [(0, ROWS)], kcat=k5, order=order, limit=100, agg_mode=_ffi.MODE_LDS_HASH)
+    assert sst["agg_mode"] != 4
+    old, ost = run(cols, None, keys, aggs, [(0, ROWS)], kcat=k5, order=order, limit=100, records=0)
+    assert ost["agg_mode"] == 4 and ost["spec_kernel"] == 0
+    for other in (scan, old):
+        assert other["ngroups"] == 100
+        a, b = rec["aggs"][:, 0], other["aggs"][:, 0]
+        assert np.array_equal(a["tag"], b["tag"]) and np.all(a["tag"] == _ffi.T_FLOAT)
+        sa, sb = f64(a["v"]), f64(b["v"])
+        assert np.all(near(sa, sb)), "rank sums differ"
+        assert np.all(sa[:-1] >= sa[1:] * (1 - 1e-9))  # descending
+        # rows may trade places only where neighbouring sums agree within the float tolerance
+        same = np.all(rec["keys"]["v"] == other["keys"]["v"], axis=1)
+        for i in np.nonzero(~same)[0]:
+            lo, hi = max(i - 1, 0), min(i + 1, 99)
+            assert near(sa[i], sa[lo]) or near(sa[i], sa[hi]), ("row %d differs beyond ties" % i)
+    # --- without the tail: all groups, records front end vs three-array records
+    rec, rst = run(cols, None, keys, aggs, [(0, ROWS)], kcat=k5)
+    old, ost = run(cols, None, keys, aggs, [(0, ROWS)], kcat=k5, records=0)
+    assert rst["agg_mode"] == 4 and rst["spec_kernel"] != 0 and ost["spec_kernel"] == 0
+    # 100 M uniform draws over 6.4 M keys leave 6.4 M * e^-15.6 ~ 1 key unseen
+    assert rec["ngroups"] == old["ngroups"] and 64 * k5 - 100 < rec["ngroups"] <= 64 * k5
+
+    def table(raw):
+        k = raw["keys"]["v"].astype(np.uint64)
+        order = np.argsort(k[:, 0] * np.uint64(64) + k[:, 1], kind="stable")
+        return raw["keys"][order], raw["aggs"][order]
+
+    rk, ra = table(rec)
+    ok, oa = table(old)
+    assert np.array_equal(rk["v"], ok["v"]) and np.array_equal(rk["tag"], ok["tag"])
+    assert np.array_equal(ra["tag"], oa["tag"])
+    isf = ra["tag"][:, 0] == _ffi.T_FLOAT
+    assert np.array_equal(ra["v"][~isf], oa["v"][~isf])  # integer sums are bit-exact
+    assert np.all(near(f64(ra["v"][isf]), f64(oa["v"][isf])))
+    del cols
+    # --- the oracle on a prefix of the same data set, the partitioned path forced (a prefix is below the probe's threshold)
+    n = 400_000
+    t = n1o.synth_table(n, k_cat=k5, total_rows=ROWS)
+    ora = n1o.run(t, None, keys, aggs, threads=4)
+    gpu, st = pu.run_gpu(t, None, keys, aggs, device_resident=True, agg_mode=4)
+    assert st["agg_mode"] == 4 and st["spec_kernel"] != 0
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    gpu, st = pu.run_gpu(t, None, keys, aggs, device_resident=True, agg_mode=4, order=order, limit=100, topk_min_groups=1024)
+    assert st["agg_mode"] == 4
+    pu.assert_ordered_groups(gpu, ora, keys, aggs, order, limit=100)
