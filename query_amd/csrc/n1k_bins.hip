@@ -16,69 +16,87 @@ namespace {
 constexpr int kBlock = 512;
 }  // namespace
 
-// The second partition pass.  Input: 256 hash regions x 8 sub-regions of fixed capacity (n1k_spec.h records mode;
-// sub-region i holds seg_count[i * kCursorStride] records at src[i * seg_stride ..]).  Output: `nb` bins per region,
+// The second partition pass, of 16-byte records (the partitioned GROUP BY) or 8-byte member words (COUNT(DISTINCT)).
+// Input: 256 hash regions x 8 sub-regions of fixed capacity, written by the plan-specialised scan (n1k_spec.h;
+// sub-region i holds seg_count[i * kCursorStride] elements at src[i * seg_stride ..]).  Output: `nb` bins per region,
 // bin (r, b) = dst[(r * nb + b) * bin_cap ..], its count in cursor[r * nb + b] — the keys were spread by mix64, so a bin
-// holds its share unless few keys own most rows, in which case *overflow is set and the engine redoes the batch on the
-// exact path.  `wpr` workgroups share a region: they take its tiles (4096 records of one sub-region) in turn.  They
-// append to the same nb bin tails, so they get ids that are equal mod 8 — workgroups are dealt round-robin over the 8
-// XCDs, whose L2s are private: one L2 sees all the partial lines of a tail and merges them before they leave for HBM.
-// Speed only; any placement is correct.
-constexpr int kRec16Per = 8, kRec16Tile = kBlock * kRec16Per;  // 4096 records = 64 KB staged
-__global__ __launch_bounds__(kBlock) void radix_scatter16_kernel(const RadixArgs A, uint32_t wpr, uint32_t bin_mask) {
+// holds its share unless few keys own most rows, in which case *overflow is set and the engine takes the exact path.
+// `wpr` workgroups share a region: they take its tiles (of one sub-region each) in turn.  They append to the same nb
+// bin tails, so they get ids that are equal mod 8 — workgroups are dealt round-robin over the 8 XCDs, whose L2s are
+// private: one L2 sees all the partial lines of a tail and merges them before they leave for HBM.  Speed only; any
+// placement is correct.
+namespace {
+__device__ __forceinline__ uint64_t elem_key(uint64_t w) { return w; }
+__device__ __forceinline__ uint64_t elem_key(const Rec16& r) { return r.k & ~kRecIntFlag; }
+__device__ __forceinline__ bool elem_none(uint64_t w) { return w == kEmptyKey; }
+__device__ __forceinline__ bool elem_none(const Rec16& r) { return r.k == kEmptyKey; }
+__device__ __forceinline__ void elem_load(const uint64_t* p, uint64_t& e) { e = __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void elem_load(const Rec16* p, Rec16& e) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 v = __builtin_nontemporal_load((const u64x2*)p);
+    e.k = v.x;
+    e.v = v.y;
+}
+__device__ __forceinline__ void elem_clear(uint64_t& e) { e = kEmptyKey; }
+__device__ __forceinline__ void elem_clear(Rec16& e) { e.k = kEmptyKey; e.v = 0; }
+}  // namespace
+
+template <class E, int PER>
+__global__ __launch_bounds__(kBlock) void radix_scatter_sub_kernel(const RadixArgs A, uint32_t wpr, uint32_t bin_mask) {
     extern __shared__ uint64_t dyn16[];
-    ScatterLds<kBlock, kRec16Per>& S = *(ScatterLds<kBlock, kRec16Per>*)dyn16;
+    ScatterLds<E, kBlock, PER>& S = *(ScatterLds<E, kBlock, PER>*)dyn16;
+    constexpr uint32_t kTile = kBlock * PER;
     const uint32_t tid = threadIdx.x, nb = bin_mask + 1u, shift = A.shift;
     // region and turn of this workgroup: ids equal mod 8 share a region (nseg / kRecSubs regions, a multiple of 8)
     const uint32_t id = blockIdx.x, lane = id & 7u, rest = id >> 3;
     const uint32_t w = rest % wpr, r = (rest / wpr) * 8u + lane;
     scatter_init<kBlock>(S.cnt);
     __syncthreads();
-    const Rec16* src = (const Rec16*)A.src;
-    Rec16* dst = (Rec16*)A.dst + (size_t)r * nb * A.bin_cap;
+    const E* src = (const E*)A.src;
+    E* dst = (E*)A.dst + (size_t)r * nb * A.bin_cap;
     unsigned long long* cursor = A.cursor + (size_t)r * nb;
+    uint32_t* const flag = A.overflow;
     uint32_t par = 0, turn = 0;
     for (uint32_t x = 0; x < kRecSubs; x++) {
         const uint32_t seg = r * kRecSubs + x;
         const uint64_t c0 = A.seg_count[(size_t)seg * kCursorStride];
         const uint64_t s0 = (uint64_t)seg * A.seg_stride, s1 = s0 + (c0 < A.seg_stride ? c0 : A.seg_stride);
-        for (uint64_t tile = s0; tile < s1; tile += kRec16Tile, turn++) {
+        for (uint64_t tile = s0; tile < s1; tile += kTile, turn++) {
             if (turn % wpr != w) continue;
-            const uint32_t n = (uint32_t)(s1 - tile < (uint64_t)kRec16Tile ? s1 - tile : (uint64_t)kRec16Tile);
-            Rec16 rec[kRec16Per];
-            uint32_t bins[kRec16Per];
+            const uint32_t n = (uint32_t)(s1 - tile < (uint64_t)kTile ? s1 - tile : (uint64_t)kTile);
+            E e[PER];
+            uint32_t bins[PER];
 #pragma unroll
-            for (int j = 0; j < kRec16Per; j++) {
+            for (int j = 0; j < PER; j++) {
                 const uint32_t p = (uint32_t)j * kBlock + tid;
-                bins[j] = kScatterNone;
-                rec[j].k = kEmptyKey;
-                rec[j].v = 0;
-                if (p < n) {
-                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-                    const u64x2 v = __builtin_nontemporal_load((const u64x2*)(src + tile + p));
-                    rec[j].k = v.x;
-                    rec[j].v = v.y;
-                }
+                elem_clear(e[j]);
+                if (p < n) elem_load(src + tile + p, e[j]);
             }
 #pragma unroll
-            for (int j = 0; j < kRec16Per; j++)
-                if (rec[j].k != kEmptyKey) bins[j] = radix_bin(rec[j].k & ~kRecIntFlag, shift) & bin_mask;
-            scatter_tile<kBlock, kRec16Per>(S, par, rec, bins, cursor, 1u, dst, A.bin_cap, A.bin_cap, A.overflow,
-                                            [=](const Rec16& e) { return radix_bin(e.k & ~kRecIntFlag, shift) & bin_mask; });
+            for (int j = 0; j < PER; j++) bins[j] = elem_none(e[j]) ? kScatterNone : (radix_bin(elem_key(e[j]), shift) & bin_mask);
+            scatter_tile<kBlock, PER>(S, par, e, bins, cursor, 1u, dst, A.bin_cap, A.bin_cap,
+                                      [=](uint32_t, const E&) { *(volatile uint32_t*)flag = 1u; });
             par ^= 1u;
         }
     }
 }
 
-// `A.nseg` = sub-regions (256 regions x kRecSubs); `wpr` workgroups per region; `bins_per_seg` bins per REGION
-hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t wpr, uint32_t bins_per_seg, hipStream_t st) {
+// `A.nseg` = sub-regions (256 regions x kRecSubs); `wpr` workgroups per region; `bins_per_region` (a power of two <= 256)
+template <class E, int PER>
+static hipError_t launch_scatter_sub(const RadixArgs& A, uint32_t wpr, uint32_t bins_per_region, hipStream_t st) {
     const uint32_t nreg = A.nseg / kRecSubs;
-    (void)hipMemsetAsync(A.cursor, 0, (size_t)nreg * bins_per_seg * sizeof(unsigned long long), st);
-    auto k = radix_scatter16_kernel;
-    const size_t shmem = sizeof(ScatterLds<kBlock, kRec16Per>);
+    (void)hipMemsetAsync(A.cursor, 0, (size_t)nreg * bins_per_region * sizeof(unsigned long long), st);
+    auto k = radix_scatter_sub_kernel<E, PER>;
+    const size_t shmem = sizeof(ScatterLds<E, kBlock, PER>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k, dim3(wpr * nreg), dim3(kBlock), shmem, st, A, wpr, bins_per_seg - 1u);
+    hipLaunchKernelGGL(k, dim3(wpr * nreg), dim3(kBlock), shmem, st, A, wpr, bins_per_region - 1u);
     return hipGetLastError();
+}
+hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t wpr, uint32_t bins_per_region, hipStream_t st) {
+    return launch_scatter_sub<Rec16, 8>(A, wpr, bins_per_region, st);  // tiles of 4096 records = 64 KB staged
+}
+hipError_t launch_radix_scatter_words(const RadixArgs& A, uint32_t wpr, uint32_t bins_per_region, hipStream_t st) {
+    return launch_scatter_sub<uint64_t, 16>(A, wpr, bins_per_region, st);  // tiles of 8192 words = 64 KB staged
 }
 
 namespace {
@@ -235,14 +253,14 @@ __global__ __launch_bounds__(BLOCK) void agg_bins16_kernel(const Program P, cons
         }
         if (nxt.bin != cur.bin) {
             // end of the bin: its groups join the compact region, every slot they used is reset
-            __syncthreads();
+            lds_barrier();  // (LDS only: the next chunk's loads stay in flight)
             if (tid == 0) {
                 const uint32_t n = lds_fill;
                 emit_base = n ? atomicAdd((unsigned long long*)&A.emit[0], (unsigned long long)n) : 0ull;
                 lds_fill = 0;
                 emit_n = 0;
             }
-            __syncthreads();
+            lds_barrier();  // (LDS only: the next chunk's loads stay in flight)
             const unsigned long long q0 = emit_base;
             for (uint32_t s = tid; s < S; s += BLOCK) {
                 const uint64_t key = lds[s];
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(BLOCK) void agg_bins16_kernel(const Program P, cons
                     atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
                 lds_slot_reset(P, lds, S, s);
             }
-            __syncthreads();
+            lds_barrier();  // (LDS only: the next chunk's loads stay in flight)
         }
         cur = nxt;
 #pragma unroll

@@ -234,6 +234,19 @@ N1K_DEV uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// 32-bit hash of a packed key / member word for the radix partitions (its bytes, from the top, are the digits of the
+// passes): a fold of the two halves and murmur3's 32-bit finalizer — three 32-bit multiplies where mix64 needs the
+// equivalent of eight (integer multiplies issue at a quarter of the VALU rate, and every row is hashed in every pass)
+N1K_DEV uint32_t part_hash(uint64_t x) {
+    uint32_t h = (uint32_t)x ^ ((uint32_t)(x >> 32) * 0x9E3779B1u);
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
 N1K_DEV uint64_t zigzag(int64_t x) { return ((uint64_t)x << 1) ^ (uint64_t)(x >> 63); }
 N1K_DEV int64_t unzigzag(uint64_t z) { return (int64_t)(z >> 1) ^ -(int64_t)(z & 1); }
 

@@ -99,7 +99,7 @@ struct n1k_handle {
     DevBuf<uint64_t> d_rregion, d_rbins;
     DevBuf<unsigned long long> d_rcursor;
     uint32_t opt_records = 1;  // 0: always the three-array records of the interpreter front end (ablation, tests)
-    uint32_t opt_rec_slots = 0, opt_rec_bins = 0, opt_rec_slices = 0, opt_rec_unroll = 0, opt_rec_block = 0;  // tuning (0 = chosen from the data)
+    uint32_t opt_rec_slots = 0, opt_rec_bins = 0, opt_rec_slices = 0, opt_rec_unroll = 0, opt_rec_block = 0, opt_rec_scan_per_cu = 0;  // tuning (0 = chosen from the data)
     // ... or instead of it: while the table is empty and their keys are unique, the region IS the set of groups;
     // n1k_finish finalizes it directly, anything else that needs the table merges it first (flush_pending)
     struct { uint64_t count = 0, cap = 0; } pending;
@@ -165,11 +165,11 @@ struct n1k_handle {
     // COUNT(DISTINCT) member words (ScanArgs::log_word) and the scratch of their partition / de-duplication at finish
     DevBuf<uint64_t> d_log_word[kMaxDistinct], d_part[2], d_seg[3], d_wtable;
     DevBuf<unsigned long long> d_hist, d_cursor, d_dcounts, d_word_hist;
-    // hash regions of the specialised scan's COUNT(DISTINCT) (WordLogArgs): 256 regions x wregion_cap words per aggregate
+    // hash regions of the specialised scan's COUNT(DISTINCT) (WordLogArgs): per aggregate 256 regions x kRecSubs sub-regions
+    // (kWordSubs in all) of wregion_cap words each
     DevBuf<uint64_t> d_wregion[kMaxDistinct], d_woff, d_wgather;
-    DevBuf<unsigned long long> d_wcursor;  // kMaxDistinct x 256 counters, kCursorStride apart
-    std::vector<unsigned long long> wcursor_host;
-    uint64_t wregion_cap = 0, wregion_reserved = 0;
+    DevBuf<unsigned long long> d_wcursor;  // kMaxDistinct x kWordSubs counters, kCursorStride apart
+    uint64_t wregion_cap = 0;
     bool wregion_used = false;             // some batch of this query went through the regions
     uint32_t opt_dedupe_block = 1025;      // workgroup size of the de-duplication kernel, +1: probe word by word (tuning)
     uint32_t opt_spec_debug = 0;           // timing experiments: 1 words not stored, 2 word scatter skipped, 4 no workgroup cache, 8 finish skips the sets
@@ -607,6 +607,8 @@ n1k_status fix_layout(n1k_handle* h, const n1k_batch* b) {
 
 namespace {
 
+constexpr uint64_t kWordSubs = 256ull * kRecSubs;  // sub-regions of a DISTINCT aggregate's member words
+
 n1k_status alloc_table(n1k_handle* h, uint64_t capacity, GlobalTable& t, DevBuf<uint64_t>& keys, DevBuf<uint64_t>& acc,
                        DevBuf<uint64_t>& rep) {
     HIP_TRY(h, keys.ensure(capacity));
@@ -918,9 +920,9 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         }
         const Program& P = ndist ? Pc : h->prog;  // (shadows the handle's program for the launches below)
         const uint32_t table_bytes = F.lds_slots * P.lds_words * 8;
-        // the word scatter's LDS (write-combining slots and chunk state per DISTINCT aggregate, n1k_spec.h: WcLds) and, in
-        // what is left of the workgroup's share of the CU, its "already logged" caches
-        const uint32_t scatter_bytes = ndist * (256u * 16u * 8u + 8u * 256u * 4u) + (ndist ? 64u : 0u);
+        // the word scatter's LDS (per DISTINCT aggregate one ScatterLds<uint64_t, 512, 4>, n1k_scatter.h: 2048 staged words,
+        // counters, run starts) and, in what is left of the workgroup's share of the CU, its "already logged" caches
+        const uint32_t scatter_bytes = ndist * (2048u * 8u + 2u * 256u * 4u + 256u * 4u + 256u * 8u + 2048u) + (ndist ? 64u : 0u);
         uint32_t dcache_slots = 0;
         if (ndist) {
             const uint32_t without = table_bytes + scatter_bytes;
@@ -967,21 +969,15 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         WordLogArgs L;
         memset(&L, 0, sizeof L);
         if (ndist) {
-            // hash regions: 256 per DISTINCT aggregate, each with room for its share of all rows pushed so far plus a
-            // quarter (mix64 spreads distinct words evenly; many copies of few words overflow into the plain word log)
+            // hash regions: 256 x kRecSubs sub-regions per DISTINCT aggregate, each with room for its share of all rows
+            // pushed so far plus a quarter (mix64 spreads distinct words evenly; many copies of few words overflow into the
+            // plain word log)
             const uint64_t rows_total = h->row_base + b->nrows;
-            // (every workgroup of a launch reserves two chunks per region ahead of its words and pads what it leaves)
-            {
-                const uint64_t per_launch = std::min<uint64_t>(b->nrows, 1ull << 31);
-                const uint64_t tiles4 = (per_launch / 1024 + 1 + 3) / 4;  // >= the tiles of a launch (1024+ rows each) / 4
-                // three lines of 16 words per workgroup and region, plus a line per word that found its region's slots full
-                h->wregion_reserved += ((std::min<uint64_t>(fgrid, tiles4) + 1) * 3 * 16 + per_launch / 8192 + 64) * ((b->nrows >> 31) + 1);
-            }
-            uint64_t need = h->opt_region_cap ? h->opt_region_cap : (rows_total + rows_total / 4) / 256 + h->wregion_reserved + 4096;
+            uint64_t need = h->opt_region_cap ? h->opt_region_cap : (rows_total + rows_total / 4) / kWordSubs + 4096;
             need = (need + 15) / 16 * 16;  // whole 128-byte lines
             if (!h->d_wcursor.p) {
-                HIP_TRY(h, h->d_wcursor.ensure(kMaxDistinct * 256 * kCursorStride));
-                HIP_TRY(h, hipMemsetAsync(h->d_wcursor.p, 0, kMaxDistinct * 256 * kCursorStride * sizeof(unsigned long long), h->stream));
+                HIP_TRY(h, h->d_wcursor.ensure(kMaxDistinct * kWordSubs * kCursorStride));
+                HIP_TRY(h, hipMemsetAsync(h->d_wcursor.p, 0, kMaxDistinct * kWordSubs * kCursorStride * sizeof(unsigned long long), h->stream));
             }
             if (need > h->wregion_cap) {
                 const uint64_t ncap = (std::max<uint64_t>(need, h->wregion_cap * 2) + 15) / 16 * 16;
@@ -991,9 +987,10 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                     if (!P.aggs[a].distinct) continue;
                     const uint32_t li = P.aggs[a].log_index;
                     DevBuf<uint64_t> nb;
-                    HIP_TRY(h, nb.ensure(256 * ncap));
+                    HIP_TRY(h, nb.ensure(kWordSubs * ncap));
                     if (h->wregion_cap && h->wregion_used)
-                        HIP_TRY(h, launch_regrow_regions(h->d_wregion[li].p, h->wregion_cap, nb.p, ncap, h->d_wcursor.p + (size_t)li * 256 * kCursorStride, h->stream));  // (clamps the cursors of regions that had overflowed)
+                        HIP_TRY(h, launch_regrow_regions(h->d_wregion[li].p, kWordSubs, h->wregion_cap, nb.p, ncap,
+                                                         h->d_wcursor.p + (size_t)li * kWordSubs * kCursorStride, h->stream));  // (clamps the cursors of regions that had overflowed)
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                     h->d_wregion[li].release();
                     h->d_wregion[li] = nb;
@@ -1005,7 +1002,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 if (!P.aggs[a].distinct) continue;
                 const uint32_t li = P.aggs[a].log_index;
                 L.region[d] = h->d_wregion[li].p;
-                L.region_cursor[d] = h->d_wcursor.p + (size_t)li * 256 * kCursorStride;
+                L.region_cursor[d] = h->d_wcursor.p + (size_t)li * kWordSubs * kCursorStride;
                 L.over_word[d] = A.log_word[li];
                 L.log_key[d] = A.log_key[li];
                 L.log_val[d] = A.log_val[li];
@@ -1443,9 +1440,10 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
     if (!spec && !jit) return N1K_OK;
     n1k_status st = ensure_table(h, 0);
     if (st != N1K_OK) return st;
-    // the scan: tiles of 4096 rows, a grid that is a multiple of 8 (sub-region = workgroup label, n1k_spec.h)
-    const uint64_t tiles = (n + 4095) / 4096;
-    const uint32_t grid = (uint32_t)((std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 2, tiles)) + 7) / 8 * 8);
+    // the scan: tiles of 2048 rows, a grid that is a multiple of 8 (sub-region = workgroup label, n1k_spec.h)
+    const uint64_t tiles = (n + 2047) / 2048;
+    const uint32_t per_cu = h->opt_rec_scan_per_cu ? h->opt_rec_scan_per_cu : 2u;
+    const uint32_t grid = (uint32_t)((std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * per_cu, tiles)) + 7) / 8 * 8);
     // The per-bin LDS tables: `slots` slots each (option rec_slots), filled to 5/8 at most; the second pass splits every
     // hash region into as many bins (a power of two <= 256, option rec_bins) as it takes for a bin's expected groups —
     // the probe's estimate carries a factor of two already — to stay under half of that.
@@ -2009,9 +2007,8 @@ n1k_status n1k_reset(n1k_handle* h) {
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
         if (h->d_word_hist.p) HIP_TRY(h, hipMemsetAsync(h->d_word_hist.p, 0, kMaxDistinct * 256 * sizeof(unsigned long long), h->stream));
-        if (h->d_wcursor.p) HIP_TRY(h, hipMemsetAsync(h->d_wcursor.p, 0, kMaxDistinct * 256 * kCursorStride * sizeof(unsigned long long), h->stream));
+        if (h->d_wcursor.p) HIP_TRY(h, hipMemsetAsync(h->d_wcursor.p, 0, kMaxDistinct * kWordSubs * kCursorStride * sizeof(unsigned long long), h->stream));
         h->wregion_used = false;
-        h->wregion_reserved = 0;
         if (h->prog.wide_int) {
             const size_t n = (size_t)1 << h->prog.wide_bits;
             HIP_TRY(h, hipMemsetAsync(h->d_wide_int.p, 0xFF, n * 8, h->stream));
@@ -2098,6 +2095,8 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         h->opt_rec_bins = v;
     } else if (n == "rec_slices") {
         h->opt_rec_slices = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64);
+    } else if (n == "rec_scan_per_cu") {
+        h->opt_rec_scan_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8);
     } else if (n == "rec_block") {
         h->opt_rec_block = value <= 0 ? 0u : (value <= 256 ? 256u : 512u);
     } else if (n == "rec_unroll") {
@@ -2384,64 +2383,52 @@ static n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64
     return N1K_OK;
 }
 
-// The same when the specialised scan scattered the words into its 256 hash regions already (the first partition pass
-// is done): one more pass into bins of fixed capacity — no histogram, mix64 spreads distinct words evenly — and the LDS
-// sets.  Whenever that optimism fails (a region or a bin overflowed: many copies of few words; an LDS set too small;
-// words of the interpreter kernel in the plain log as well) everything is gathered into one log and the exact path
-// above runs instead.  `rc` = the regions' word counts, `nover` = words in the plain log.
-static n1k_status distinct_regions_finish(n1k_handle* h, const AggSpec& ag, const unsigned long long* rc, uint64_t nover,
-                                          bool force_exact, bool* deferred) {
+// The same when the specialised scan scattered the words into its hash regions already (the first partition pass is
+// done): one more pass into bins of fixed capacity — no histogram, mix64 spreads distinct words evenly — and the LDS
+// sets, without a host synchronisation (nothing here depends on a count the host would have to read).  Whenever that
+// optimism fails (a sub-region or a bin overflowed: many copies of few words; an LDS set too small; words of the
+// interpreter kernel in the plain log as well) everything is gathered into one log and the exact path above runs
+// instead.  `nover` = words in the plain log.
+static n1k_status distinct_regions_finish(n1k_handle* h, const AggSpec& ag, uint64_t nover, bool force_exact, bool* deferred) {
     const uint32_t li = ag.log_index;
     const uint64_t cap = h->wregion_cap;
-    uint64_t total = 0, biggest = 0;
-    bool spilled = false;
-    for (uint32_t b = 0; b < 256; b++) {
-        spilled |= rc[b] > cap;
-        const uint64_t c = std::min<uint64_t>(rc[b], cap);
-        total += c;
-        biggest = std::max(biggest, c);
-    }
-    if (total == 0) return nover ? distinct_words_finish(h, ag, nover) : N1K_OK;
+    unsigned long long* const cursors = h->d_wcursor.p + (size_t)li * kWordSubs * kCursorStride;
     const uint32_t set_slots = h->opt_distinct_set_slots;
     const uint64_t per_bin = std::max<uint64_t>(set_slots / 4, 16);
-    bool exact = force_exact || spilled || nover > 0 || h->opt_distinct_levels == 0;
+    const bool exact = force_exact || nover > 0 || h->opt_distinct_levels == 0;
     uint32_t* d_overflow = (uint32_t*)(h->d_counters.p + 20);  // [0] an LDS set overflowed, [1] a bin of the second pass
     if (!exact) {
-        // Optimistic and without a host synchronisation: the member counts are only added to the groups when neither flag
-        // came up (the kernel checks), and n1k_finish reads the flags together with the results (*deferred)
-        const bool second = h->opt_distinct_levels >= 0 ? h->opt_distinct_levels == 2 : total > 256 * per_bin;
+        // Optimistic: the member counts are only added to the groups when neither flag came up (the kernel checks), and
+        // n1k_finish reads the flags together with the results (*deferred).  The rows pushed bound the words.
+        const uint64_t bound = std::max<uint64_t>(h->row_base, 1);
+        uint32_t bps = 1;  // bins per region: a bin's words should fit an LDS set at a quarter of its slots
+        while (bps < 256 && 256ull * bps * per_bin < bound) bps *= 2;
+        if (h->opt_distinct_levels == 2) bps = 256;
+        else if (h->opt_distinct_levels == 1) bps = 1;
+        const uint64_t nbins = 256ull * bps, mean = bound / nbins + 1, bin_cap = mean + mean / 2 + 256;
         HIP_TRY(h, h->d_dcounts.ensure(h->table.capacity + 2));
         HIP_TRY(h, hipMemsetAsync(h->d_dcounts.p, 0, (h->table.capacity + 2) * sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, h->d_part[0].ensure(nbins * bin_cap));
+        HIP_TRY(h, h->d_cursor.ensure(65536));
+        RadixArgs R{};
+        R.src = h->d_wregion[li].p;
+        R.dst = h->d_part[0].p;
+        R.seg_count = cursors;
+        R.seg_stride = cap;
+        R.nseg = (uint32_t)kWordSubs;
+        R.shift = 48;
+        R.cursor = h->d_cursor.p;
+        R.bin_cap = bin_cap;
+        R.overflow = d_overflow + 1;
+        const uint64_t region_tiles = (bound / 256 + 8191) / 8192 + kRecSubs;
+        const uint32_t wpr = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, region_tiles));
+        HIP_TRY(h, launch_radix_scatter_words(R, wpr, bps, h->stream));
         DedupeArgs D{};
-        D.words = h->d_wregion[li].p;
-        D.bin_count = h->d_wcursor.p + (size_t)li * 256 * kCursorStride;
-        D.count_stride = kCursorStride;
-        D.bin_stride = cap;
-        D.nbins = 256;
-        if (second) {
-            const uint64_t mean = biggest / 256 + 1;
-            const uint64_t bin_cap = mean + mean / 2 + 256;
-            HIP_TRY(h, h->d_part[0].ensure(65536 * bin_cap));
-            HIP_TRY(h, h->d_cursor.ensure(65536));
-            RadixArgs R{};
-            R.src = h->d_wregion[li].p;
-            R.dst = h->d_part[0].p;
-            R.seg_count = h->d_wcursor.p + (size_t)li * 256 * kCursorStride;
-            R.seg_stride = cap;
-            R.nseg = 256;
-            R.shift = 48;
-            R.cursor = h->d_cursor.p;
-            R.bin_cap = bin_cap;
-            R.overflow = d_overflow + 1;
-            const uint64_t tiles = (biggest + 8191) / 8192;
-            const uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 8 / 256 + 8, tiles));
-            HIP_TRY(h, launch_radix_pass(R, slices, h->stream, false));
-            D.words = R.dst;
-            D.bin_count = h->d_cursor.p;
-            D.count_stride = 1;
-            D.bin_stride = bin_cap;
-            D.nbins = 65536;
-        }
+        D.words = R.dst;
+        D.bin_count = h->d_cursor.p;
+        D.count_stride = 1;
+        D.bin_stride = bin_cap;
+        D.nbins = (uint32_t)nbins;
         D.set_slots = set_slots;
         D.key_shift = h->nw_val_bits + 3;
         D.glob_off = ag.glob_off;
@@ -2454,20 +2441,22 @@ static n1k_status distinct_regions_finish(n1k_handle* h, const AggSpec& ag, cons
         *deferred = true;
         return N1K_OK;
     }
-    // exact path: the regions' words join the plain log (behind its own words), then partition by histogram
-    std::vector<uint64_t> off(256);
+    // exact path: the sub-regions' words join the plain log (behind its own words), then partition by histogram
+    std::vector<unsigned long long> rc((size_t)kWordSubs * kCursorStride);
+    HIP_TRY(h, hipMemcpyAsync(rc.data(), cursors, rc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<uint64_t> off(kWordSubs);
     uint64_t at = nover;
-    for (uint32_t b = 0; b < 256; b++) {
+    for (uint32_t b = 0; b < kWordSubs; b++) {
         off[b] = at;
-        at += std::min<uint64_t>(rc[b], cap);
+        at += std::min<uint64_t>(rc[(size_t)b * kCursorStride], cap);
     }
-    // (the regions' padding comes along — "no word" entries every step below skips — so the gathered log has its own buffer)
+    if (at == 0) return N1K_OK;
     HIP_TRY(h, h->d_wgather.ensure(at));
-    HIP_TRY(h, h->d_woff.ensure(256));
+    HIP_TRY(h, h->d_woff.ensure(kWordSubs));
     if (nover) HIP_TRY(h, hipMemcpyAsync(h->d_wgather.p, h->d_log_word[li].p, nover * 8, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_woff.p, off.data(), 256 * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, launch_compact_regions(h->d_wregion[li].p, cap, h->d_wcursor.p + (size_t)li * 256 * kCursorStride, h->d_woff.p,
-                                      h->d_wgather.p, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_woff.p, off.data(), kWordSubs * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, launch_compact_regions(h->d_wregion[li].p, (uint32_t)kWordSubs, cap, cursors, h->d_woff.p, h->d_wgather.p, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // (`off` lives on this stack frame)
     return distinct_words_finish(h, ag, at, false, h->d_wgather.p);
 }
@@ -2834,11 +2823,6 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             memcpy(counters, h->pin_out + total, sizeof counters);
         } else {
             HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
-            if (h->wregion_used) {  // the hash regions' word counts travel with the counters: one synchronisation
-                h->wcursor_host.resize((size_t)kMaxDistinct * 256 * kCursorStride);
-                HIP_TRY(h, hipMemcpyAsync(h->wcursor_host.data(), h->d_wcursor.p, h->wcursor_host.size() * sizeof(unsigned long long),
-                                          hipMemcpyDeviceToHost, h->stream));
-            }
             HIP_TRY(h, hipStreamSynchronize(h->stream));
         }
         err_flags = (uint32_t)counters[12];
@@ -2901,9 +2885,7 @@ redo_sets:
             }
             if (h->opt_spec_debug & 8u) continue;
             if (h->wregion_used && h->distinct_words[ag.log_index]) {
-                unsigned long long rc[256];
-                for (uint32_t b = 0; b < 256; b++) rc[b] = h->wcursor_host[((size_t)ag.log_index * 256 + b) * kCursorStride];
-                n1k_status st = distinct_regions_finish(h, ag, rc, nwords, sets_exact, &sets_deferred);
+                n1k_status st = distinct_regions_finish(h, ag, nwords, sets_exact, &sets_deferred);
                 if (st != N1K_OK) return st;
             } else if (nwords) {
                 n1k_status st = distinct_words_finish(h, ag, nwords);

@@ -91,9 +91,9 @@ std::string jit_source(const SpecSig& g) {
       << "        const n1k::GlobalTable G, unsigned long long* ngroups, const n1k::WordLogArgs L) {\n"
       << "    n1k::scan_spec_body<n1k::SpecJ, 4, 512, false>(P, F, G, ngroups, L);\n}\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_rec_wide(const n1k::Program P, const n1k::FastArgs F,\n"
-      << "        const n1k::WordLogArgs L) {\n    n1k::scan_spec_records_body<n1k::SpecJ, 4, 512, true>(P, F, L);\n}\n"
+      << "        const n1k::WordLogArgs L) {\n    n1k::scan_spec_records_body<n1k::SpecJ, 2, 512, true>(P, F, L);\n}\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_rec_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
-      << "        const n1k::WordLogArgs L) {\n    n1k::scan_spec_records_body<n1k::SpecJ, 8, 512, false>(P, F, L);\n}\n";
+      << "        const n1k::WordLogArgs L) {\n    n1k::scan_spec_records_body<n1k::SpecJ, 4, 512, false>(P, F, L);\n}\n";
     return o.str();
 }
 
@@ -137,7 +137,7 @@ hipError_t jit_launch(const JitKernel* k, const Program& P, const FastArgs& F, c
 
 hipError_t jit_launch_records(const JitKernel* k, const Program& P, const FastArgs& F, uint32_t grid, bool wide, const WordLogArgs& L,
                               hipStream_t st) {
-    const unsigned shmem = (unsigned)spec_records_lds_bytes();  // sizeof(ScatterLds<512, 8>), n1k_scatter.h
+    const unsigned shmem = (unsigned)spec_records_lds_bytes();  // sizeof(ScatterLds<Rec16, 512, 4>), n1k_scatter.h
     hipFunction_t f = wide ? k->rec_wide : k->rec_narrow;
     void* args[] = {(void*)&P, (void*)&F, (void*)&L};
     return hipModuleLaunchKernel(f, grid, 1, 1, 512, 1, 1, shmem, st, args, nullptr);

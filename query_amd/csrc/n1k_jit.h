@@ -15,7 +15,7 @@ struct JitKernel {
     hipModule_t module = nullptr;
     hipFunction_t wide = nullptr;    // scan_spec_body<Spec, 2, 512, true>
     hipFunction_t narrow = nullptr;  // scan_spec_body<Spec, 4, 512, false>
-    hipFunction_t rec_wide = nullptr, rec_narrow = nullptr;  // scan_spec_records_body<Spec, 4 / 8, 512, true / false> (partitioned GROUP BY front end)
+    hipFunction_t rec_wide = nullptr, rec_narrow = nullptr;  // scan_spec_records_body<Spec, 2 / 4, 512, true / false> (partitioned GROUP BY front end)
     bool failed = false;
     std::string log;
 };

@@ -71,10 +71,11 @@ hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st
 // ... the per-bin LDS sets, the global-memory fallback, and the hand-over of the member counts to the set sizes
 hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, uint32_t block, hipStream_t st);
 size_t distinct_dedupe_lds(const DedupeArgs& D);
-hipError_t launch_compact_regions(const uint64_t* region, uint64_t cap, const unsigned long long* count, const uint64_t* off,
+// (`nreg` regions of fixed capacity: the 256 x kRecSubs sub-regions of a DISTINCT aggregate's member words)
+hipError_t launch_compact_regions(const uint64_t* region, uint32_t nreg, uint64_t cap, const unsigned long long* count, const uint64_t* off,
                                   uint64_t* dst, hipStream_t st);
-hipError_t launch_regrow_regions(const uint64_t* src, uint64_t src_cap, uint64_t* dst, uint64_t dst_cap, unsigned long long* count,
-                                 hipStream_t st);
+hipError_t launch_regrow_regions(const uint64_t* src, uint32_t nreg, uint64_t src_cap, uint64_t* dst, uint64_t dst_cap,
+                                 unsigned long long* count, hipStream_t st);
 hipError_t launch_distinct_words_global(const GlobalTable& G, const uint64_t* words, uint64_t n, uint64_t* table, uint64_t mask,
                                         uint32_t key_shift, unsigned long long* counts, uint32_t* err_flags, uint32_t grid,
                                         hipStream_t st);
@@ -101,7 +102,8 @@ struct SpecEntry {
 size_t spec_records_lds_bytes();
 // n1k_bins.hip: the partitioned GROUP BY over 16-byte records — second partition pass (`bins_per_seg` bins of fixed capacity
 // per hash region, a power of two <= 256) and the per-bin LDS tables (`block` threads per bin, `per_thread` = records a thread loads at once)
-hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t slices, uint32_t bins_per_seg, hipStream_t st);
+hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t wpr, uint32_t bins_per_region, hipStream_t st);
+hipError_t launch_radix_scatter_words(const RadixArgs& A, uint32_t wpr, uint32_t bins_per_region, hipStream_t st);  // the same for 8-byte member words
 hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t block, uint32_t per_thread, hipStream_t st);
 const std::vector<SpecEntry>& spec_registry();
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,

@@ -1264,22 +1264,23 @@ static hipError_t launch_spec(const Program& P, const FastArgs& F, const GlobalT
     return hipGetLastError();
 }
 
-// records mode of a shape (n1k_spec.h): Filter + packed key, 16-byte records into the hash regions; tiles of 4096 rows
+// records mode of a shape (n1k_spec.h): Filter + packed key, 16-byte records into the hash regions; tiles of 2048 rows,
+// two in flight
 template <class Spec>
 static hipError_t launch_spec_records(const Program& P, const FastArgs& F, uint32_t grid, bool wide, const WordLogArgs& L, hipStream_t st) {
-    const size_t shmem = sizeof(ScatterLds<512, 8>);
+    const size_t shmem = sizeof(ScatterLds<Rec16, 512, 4>);
     if (wide) {
-        auto k = scan_spec_records_kernel<Spec, 4, 512, true>;
+        auto k = scan_spec_records_kernel<Spec, 2, 512, true>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), shmem, st, P, F, L);
     } else {
-        auto k = scan_spec_records_kernel<Spec, 8, 512, false>;
+        auto k = scan_spec_records_kernel<Spec, 4, 512, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), shmem, st, P, F, L);
     }
     return hipGetLastError();
 }
-size_t spec_records_lds_bytes() { return sizeof(ScatterLds<512, 8>); }
+size_t spec_records_lds_bytes() { return sizeof(ScatterLds<Rec16, 512, 4>); }
 
 const std::vector<SpecEntry>& spec_registry() {
     static const std::vector<SpecEntry> reg = {
@@ -2575,7 +2576,7 @@ hipError_t launch_radix_pass(const RadixArgs& A, uint32_t slices, hipStream_t st
 }
 
 // hash regions -> one contiguous word log (n1k_finish's exact path when a region overflowed, or for the forced
-// partition depths of the tests): region b's words go to dst[off[b] ..]
+// partition depths of the tests): (sub-)region b's words go to dst[off[b] ..]
 __global__ __launch_bounds__(256) void compact_regions_kernel(const uint64_t* region, uint64_t cap, const unsigned long long* count,
                                                               const uint64_t* off, uint64_t* dst) {
     const uint32_t b = blockIdx.y;
@@ -2584,9 +2585,9 @@ __global__ __launch_bounds__(256) void compact_regions_kernel(const uint64_t* re
         dst[off[b] + i] = region[(size_t)b * cap + i];
 }
 
-hipError_t launch_compact_regions(const uint64_t* region, uint64_t cap, const unsigned long long* count, const uint64_t* off,
+hipError_t launch_compact_regions(const uint64_t* region, uint32_t nreg, uint64_t cap, const unsigned long long* count, const uint64_t* off,
                                   uint64_t* dst, hipStream_t st) {
-    hipLaunchKernelGGL(compact_regions_kernel, dim3(32, 256), dim3(256), 0, st, region, cap, count, off, dst);
+    hipLaunchKernelGGL(compact_regions_kernel, dim3(8, nreg), dim3(256), 0, st, region, cap, count, off, dst);
     return hipGetLastError();
 }
 
@@ -2602,14 +2603,14 @@ __global__ __launch_bounds__(256) void regrow_regions_kernel(const uint64_t* src
 // a region that overflowed counted words it never took (they went to the plain log): its cursor goes back to the
 // capacity it had, so that the wider region continues right behind the words that are really there
 __global__ void clamp_cursors_kernel(unsigned long long* count, uint64_t cap) {
-    const uint32_t b = threadIdx.x;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (count[b * kCursorStride] > cap) count[b * kCursorStride] = cap;
 }
 
-hipError_t launch_regrow_regions(const uint64_t* src, uint64_t src_cap, uint64_t* dst, uint64_t dst_cap, unsigned long long* count,
+hipError_t launch_regrow_regions(const uint64_t* src, uint32_t nreg, uint64_t src_cap, uint64_t* dst, uint64_t dst_cap, unsigned long long* count,
                                  hipStream_t st) {
-    hipLaunchKernelGGL(regrow_regions_kernel, dim3(32, 256), dim3(256), 0, st, src, src_cap, dst, dst_cap, count);
-    hipLaunchKernelGGL(clamp_cursors_kernel, dim3(1), dim3(256), 0, st, count, src_cap);
+    hipLaunchKernelGGL(regrow_regions_kernel, dim3(8, nreg), dim3(256), 0, st, src, src_cap, dst, dst_cap, count);
+    hipLaunchKernelGGL(clamp_cursors_kernel, dim3(nreg / 256), dim3(256), 0, st, count, src_cap);  // (nreg: a multiple of 256)
     return hipGetLastError();
 }
 

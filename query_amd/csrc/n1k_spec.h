@@ -231,14 +231,14 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
                 spec_pair_log(P, G, L, d, P.aggs[a], key, cls, val, F.err_flags, ngroups);
                 continue;
             }
-            const uint64_t hw = mix64(word);  // top byte: the hash region; low bits: the slot of the workgroup's cache
+            const uint32_t hw = part_hash(word);  // top byte: the hash region; low bits: the slot of the workgroup's cache
             if (L.dcache_slots) {  // skip a word this workgroup logged already (direct-mapped; a race costs a redundant word)
-                lds_u64* c = lds_word(dcache, (uint32_t)d * L.dcache_slots + ((uint32_t)hw & (L.dcache_slots - 1u)));
+                lds_u64* c = lds_word(dcache, (uint32_t)d * L.dcache_slots + (hw & (L.dcache_slots - 1u)));
                 if (lds_peek(c) == word) continue;
                 *(volatile lds_u64*)c = word;
             }
             words[d] = word;
-            bins[d] = (uint32_t)(hw >> 56);
+            bins[d] = hw >> 24;
             continue;
         }
         if (kHashed && grow >= 0) {  // the LDS table is full: this group lives in the global table only
@@ -300,168 +300,27 @@ N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, u
     }
 }
 
-// ---- member words -> hash regions: write combining in LDS ------------------------------------------------------
+// ---- member words -> hash regions -------------------------------------------------------------------------------
 //
-// Every workgroup keeps, per DISTINCT aggregate and hash region, kWcSlots staging slots in LDS and private CHUNKS of
-// kWcChunk consecutive words inside the region: the one it is filling, the next one, and a third one reserved ahead.
-// A chunk is one aligned 128-byte line.  Per tile: each thread appends its words to their region's slots (one LDS
-// atomic each); after a barrier a 16-lane group per region copies the slots to the chunk — consecutive lanes,
-// consecutive words of a line — and the region's owner (thread b for region b) moves on to the next chunk when the
-// current one is full, reserving the one after the next at that moment.  The answer of that reservation is only read
-// a tile later, so no global round trip sits between the barriers of a tile (a reservation per tile and region cost
-// 0.5 ms per 100 M rows in exposed latency).  What a workgroup reserved but did not fill it pads with kEmptyKey,
-// which every reader of the regions skips.  (Region capacities and all reservations are multiples of kWcChunk.)
-constexpr uint32_t kWcSlots = 16, kWcChunk = 16;
-
-// (templated on the element: 8-byte member words today; "no element" is kEmptyKey)
-N1K_DEV bool wc_none(uint64_t w) { return w == kEmptyKey; }
-N1K_DEV void wc_set_none(uint64_t& w) { w = kEmptyKey; }
-
-// LDS of one stream of elements.  The chunk state and the tile counters exist twice: in tile t everybody reads copy
-// t & 1 and region b's owner writes copy (t + 1) & 1, so that the owners' updates need no barrier of their own.
-template <class E>
-struct WcLdsT {
-    E slot[256 * kWcSlots];
-    uint32_t cur[2][256], next[2][256];  // first element of the current / next chunk (position inside the region, < 2^32)
-    uint32_t used[2][256];               // elements of the current chunk already written
-    uint32_t fill[2][256];               // elements appended to the slots in this tile
-};
-typedef WcLdsT<uint64_t> WcLds;
-constexpr uint32_t kWcNone = 0xFFFFFFFFu;  // "no chunk": the region is full
-
-// what the owner of a region carries in registers from tile to tile
-struct WcOwner {
-    unsigned long long pend;  // answer of the reservation issued a tile ago (when `pending`)
-    uint32_t third;           // the chunk after `next` (valid unless `pending`)
-    bool pending;
-};
-
-// an element whose region is full: a member word goes to the plain word log (n1k_finish then takes the exact path); a
-// record raises the flag that makes the engine redo the batch on the exact path
-N1K_DEV void wc_over_append(const WordLogArgs& L, int d, uint32_t b, uint64_t word, uint32_t* err_flags) {
+// The member words of a DISTINCT aggregate leave the scan already partitioned by the first radix digit of part_hash(word):
+// 256 hash regions, each split into kRecSubs sub-regions, one per workgroup label blockIdx.x % 8 (below: why).  A tile's
+// words are ranked, staged in LDS in region order and written in runs (scatter_tile, n1k_scatter.h).  A word whose
+// sub-region is full (many copies of few words) goes to the plain word log instead; n1k_finish then takes the exact path.
+N1K_DEV void word_over_append(const WordLogArgs& L, int d, uint32_t b, uint64_t word, uint32_t* err_flags) {
     const uint32_t li = L.log_index[d];
     const unsigned long long q = atomicAdd(&L.over_cursor[li], 1ull);
     if (q < L.over_capacity) {
         L.over_word[d][q] = word;
-        atomicAdd(&L.over_hist[li * 256u + b], 1ull);
+        atomicAdd(&L.over_hist[(size_t)li * 256 + b], 1ull);
     } else
         atomicOr(err_flags, (uint32_t)ERR_TABLE_FULL);
-}
-
-// a reservation [base, base + kWcChunk) as a chunk: inside the region or not at all (both are multiples of kWcChunk)
-N1K_DEV uint32_t wc_chunk(const WordLogArgs& L, unsigned long long base) {
-    return base + kWcChunk <= L.region_cap ? (uint32_t)base : kWcNone;
-}
-
-template <int BLOCK, class E>
-N1K_DEV void wc_init(const WordLogArgs& L, int d, WcLdsT<E>& W, WcOwner& O) {
-    O.pend = 0;
-    O.third = kWcNone;
-    O.pending = false;
-    for (uint32_t b = threadIdx.x; b < 256; b += BLOCK) {
-        const unsigned long long r = atomicAdd(&L.region_cursor[d][b * kCursorStride], (unsigned long long)(3 * kWcChunk));
-        W.cur[0][b] = wc_chunk(L, r);
-        W.next[0][b] = wc_chunk(L, r + kWcChunk);
-        O.third = wc_chunk(L, r + 2 * kWcChunk);
-        W.used[0][b] = 0;
-        W.fill[0][b] = 0;
-        W.fill[1][b] = 0;
-    }
-}
-
-// All threads of the workgroup call it once per tile (two barriers).  `par` = tile & 1.
-template <int BLOCK, int NW, class E>
-N1K_DEV void wc_tile(const WordLogArgs& L, int d, const E (&w)[NW], const uint32_t (&wb)[NW], WcLdsT<E>& W, uint32_t par,
-                     WcOwner& O, uint32_t* err_flags) {
-    static_assert(BLOCK >= 256, "one owner thread per hash region");
-    constexpr int kPer = 256 * 16 / BLOCK;  // regions per 16-lane group
-    const uint32_t tid = threadIdx.x;
-    E* const region0 = (E*)L.region[d];
-    if (L.pad & 2u) return;  // (timing experiments only: elements dropped)
-#pragma unroll
-    for (int j = 0; j < NW; j++) {
-        if (wc_none(w[j])) continue;
-        const uint32_t b = wb[j];
-        const uint32_t r = atomicAdd(&W.fill[par][b], 1u);
-        if (r < kWcSlots) {
-            W.slot[b * kWcSlots + r] = w[j];
-        } else {
-            // more elements for one region in one tile than its slots take (a few per thousand tiles): a chunk of its own
-            const unsigned long long q = atomicAdd(&L.region_cursor[d][b * kCursorStride], (unsigned long long)kWcChunk);
-            if (q + kWcChunk <= L.region_cap) {
-                E* line = region0 + (size_t)b * L.region_cap + q;
-                line[0] = w[j];
-                E none;
-                wc_set_none(none);
-                for (uint32_t i = 1; i < kWcChunk; i++) line[i] = none;
-            } else
-                wc_over_append(L, d, b, w[j], err_flags);
-        }
-    }
-    __syncthreads();
-    // owners: the state of the next tile.  A region whose chunk fills up in this tile moves on to the next one (which has
-    // been known for a tile at least), the third becomes the next, and a new third is reserved; its answer is read at the
-    // start of the next tile's owner step.  (A tile brings at most kWcSlots = kWcChunk elements: one move per tile.)
-    if (tid < 256) {
-        const uint32_t b = tid, f = W.fill[par][b], n = f < kWcSlots ? f : kWcSlots, used = W.used[par][b];
-        if (O.pending) {
-            O.third = wc_chunk(L, O.pend);
-            O.pending = false;
-        }
-        if (used + n >= kWcChunk) {
-            W.cur[par ^ 1][b] = W.next[par][b];
-            W.next[par ^ 1][b] = O.third;
-            W.used[par ^ 1][b] = used + n - kWcChunk;
-            O.pend = atomicAdd(&L.region_cursor[d][b * kCursorStride], (unsigned long long)kWcChunk);
-            O.pending = true;
-        } else {
-            W.cur[par ^ 1][b] = W.cur[par][b];
-            W.next[par ^ 1][b] = W.next[par][b];
-            W.used[par ^ 1][b] = used + n;
-        }
-        W.fill[par ^ 1][b] = 0;
-    }
-    // copy: a 16-lane group per region, consecutive lanes write consecutive elements of a chunk
-    const uint32_t g = tid >> 4, l = tid & 15u;
-#pragma unroll 2
-    for (int k = 0; k < kPer; k++) {
-        const uint32_t b = (uint32_t)k * (BLOCK / 16) + g;
-        const uint32_t f = W.fill[par][b];
-        const uint32_t n = f < kWcSlots ? f : kWcSlots;
-        if (l >= n) continue;
-        const uint32_t pos = W.used[par][b] + l;
-        const uint32_t base = pos < kWcChunk ? W.cur[par][b] : W.next[par][b];
-        const E e = W.slot[b * kWcSlots + l];
-        if (L.pad & 1u) continue;  // (timing experiments only: elements not stored)
-        if (base != kWcNone) region0[(size_t)b * L.region_cap + base + (pos & (kWcChunk - 1))] = e;
-        else wc_over_append(L, d, b, e, err_flags);
-    }
-    __syncthreads();
-}
-
-// end of the kernel: what the workgroup reserved and did not fill reads as "no element".  `par` = parity of the next tile.
-template <int BLOCK, class E>
-N1K_DEV void wc_finish(const WordLogArgs& L, int d, WcLdsT<E>& W, uint32_t par, WcOwner& O) {
-    const uint32_t b = threadIdx.x;
-    if (b >= 256) return;
-    const uint32_t cur = W.cur[par][b], nx = W.next[par][b], used = W.used[par][b];
-    const uint32_t third = O.pending ? wc_chunk(L, O.pend) : O.third;
-    E* region = (E*)L.region[d] + (size_t)b * L.region_cap;
-    E none;
-    wc_set_none(none);
-    if (cur != kWcNone)
-        for (uint32_t pos = used; pos < kWcChunk; pos++) region[cur + pos] = none;
-    if (nx != kWcNone)
-        for (uint32_t pos = 0; pos < kWcChunk; pos++) region[nx + pos] = none;
-    if (third != kWcNone)
-        for (uint32_t pos = 0; pos < kWcChunk; pos++) region[third + pos] = none;
 }
 
 // ---- records mode: Filter + group key of the plan shape, each surviving row leaves as a 16-byte record ----------
 //
 // High-cardinality GROUP BY (N1K_MODE_PARTITIONED): no workgroup table would absorb anything, so the specialised scan
 // only evaluates the Filter, packs the group key and scatters (key, operand) records by the first radix digit of
-// mix64(key) into 256 hash regions — the projection and the first partition pass of the partitioned path in one
+// part_hash(key) into 256 hash regions — the projection and the first partition pass of the partitioned path in one
 // kernel, reading the columns once and writing 16 bytes per surviving row (scatter_tile, n1k_scatter.h: a tile of
 // BLOCK x kNW rows is ranked, staged in LDS in region order and written in runs).
 //
@@ -478,7 +337,7 @@ constexpr int spec_operand_col() {
     return -1;
 }
 
-N1K_DEV uint32_t rec16_region(const Rec16& r) { return (uint32_t)(mix64(r.k & ~kRecIntFlag) >> 56); }
+N1K_DEV uint32_t rec16_region(const Rec16& r) { return part_hash(r.k & ~kRecIntFlag) >> 24; }
 
 template <class Spec>
 N1K_DEV void spec_row_record(const Program& P, const FastArgs& F, const uint32_t (&tg)[kFastCols], const uint64_t (&pv)[kFastCols],
@@ -508,7 +367,7 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
     constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
     constexpr int kNW = R * (int)kRowsPerItem;
     extern __shared__ uint64_t lds[];
-    ScatterLds<BLOCK, kNW>& S = *(ScatterLds<BLOCK, kNW>*)lds;
+    ScatterLds<Rec16, BLOCK, kNW>& S = *(ScatterLds<Rec16, BLOCK, kNW>*)lds;
     const uint32_t tid = threadIdx.x;
     scatter_init<BLOCK>(S.cnt);
     __syncthreads();
@@ -519,11 +378,9 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
     const uint32_t nrows = F.nrows;
     const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
     const uint32_t tile = BLOCK * R;
-    for (uint32_t base = blockIdx.x * tile; base < nitems; base += gridDim.x * tile) {
-        uint32_t tg[R][kRowsPerItem][kFastCols];
-        uint64_t pv[R][kRowsPerItem][kFastCols];
-        bool valid[R];
-        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
+    uint32_t* const flag = L.rec_overflow;
+    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kFastCols], const uint64_t (&pv)[R][kRowsPerItem][kFastCols],
+                       const bool (&valid)[R], uint32_t base) {
         Rec16 recs[kNW];
         uint32_t bins[kNW];
 #pragma unroll
@@ -539,8 +396,25 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
             }
         }
         scatter_tile<BLOCK, kNW>(S, par, recs, bins, cursor, kRecSubs * kCursorStride, dst, (uint64_t)kRecSubs * L.region_cap,
-                                 L.region_cap, L.rec_overflow, [](const Rec16& r) { return rec16_region(r); });
+                                 L.region_cap, [=](uint32_t, const Rec16&) { *(volatile uint32_t*)flag = 1u; });
         par ^= 1u;
+    };
+    // Two tiles in flight: the columns of tile t + 1 are requested before tile t's records go through LDS (three barriers
+    // and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
+    uint32_t tgA[R][kRowsPerItem][kFastCols], tgB[R][kRowsPerItem][kFastCols];
+    uint64_t pvA[R][kRowsPerItem][kFastCols], pvB[R][kRowsPerItem][kFastCols];
+    bool vA[R], vB[R];
+    const uint32_t stride = gridDim.x * tile;
+    uint32_t base = blockIdx.x * tile;
+    if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
+    while (base < nitems) {
+        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgB, pvB, vB);  // (beyond the end: no loads)
+        process(tgA, pvA, vA, base);
+        base += stride;
+        if (base >= nitems) break;
+        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgA, pvA, vA);
+        process(tgB, pvB, vB, base);
+        base += stride;
     }
     if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
     __shared__ unsigned int block_selected;
@@ -568,16 +442,14 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     // COUNT(DISTINCT): scratch of the word scatter (nothing when the shape has no DISTINCT aggregate)
     constexpr int kND = spec_ndistinct<Spec>();
     constexpr int kNW = R * (int)kRowsPerItem;  // member words a thread can produce per tile and aggregate
-    __shared__ WcLds w_lds[kND ? kND : 1];
-    WcOwner w_own[kND ? kND : 1];
+    __shared__ ScatterLds<uint64_t, BLOCK, kNW> w_lds[kND ? kND : 1];
     uint32_t w_par = 0;
+    const uint32_t w_sub = blockIdx.x % kRecSubs;  // sub-region of every hash region this workgroup appends to
     uint64_t* dcache = lds + (size_t)S * P.lds_words;  // "already logged" caches of the DISTINCT aggregates
     if constexpr (kND > 0) {
         for (uint32_t i = tid; i < L.dcache_slots * (uint32_t)kND; i += BLOCK) *(volatile lds_u64*)lds_word(dcache, i) = kEmptyKey;
 #pragma unroll
-        for (int d = 0; d < kND; d++) {
-            wc_init<BLOCK>(L, d, w_lds[d], w_own[d]);
-        }
+        for (int d = 0; d < kND; d++) scatter_init<BLOCK>(w_lds[d].cnt);
     }
     lds_table_init<BLOCK>(P, lds, S, tid);
     if (tid == 0) lds_fill = 0;
@@ -590,12 +462,8 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
     const uint32_t tile = BLOCK * R;
 
-    for (uint32_t base = blockIdx.x * tile; base < nitems; base += gridDim.x * tile) {
-        // issue every load of the tile first (R items x ncols columns), then compute
-        uint32_t tg[R][kRowsPerItem][kFastCols];
-        uint64_t pv[R][kRowsPerItem][kFastCols];
-        bool valid[R];
-        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
+    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kFastCols], const uint64_t (&pv)[R][kRowsPerItem][kFastCols],
+                       const bool (&valid)[R], uint32_t base) {
         uint64_t mw[kSpecDistinct][kNW];  // this thread's member words of the tile (kEmptyKey = none) and their hash regions
         uint32_t mb[kSpecDistinct][kNW];
 #pragma unroll
@@ -605,7 +473,7 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
                 uint64_t words[kSpecDistinct];
                 uint32_t bins[kSpecDistinct];
 #pragma unroll
-                for (int d = 0; d < (int)kSpecDistinct; d++) { words[d] = kEmptyKey; bins[d] = 0; }
+                for (int d = 0; d < (int)kSpecDistinct; d++) { words[d] = kEmptyKey; bins[d] = kScatterNone; }
                 const bool row_ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nrows);
                 if (row_ok) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins);
 #pragma unroll
@@ -614,15 +482,46 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
         }
         if constexpr (kND > 0) {
 #pragma unroll
-            for (int d = 0; d < kND; d++) wc_tile<BLOCK, kNW>(L, d, mw[d], mb[d], w_lds[d], w_par, w_own[d], F.err_flags);
+            for (int d = 0; d < kND; d++) {
+                if (L.pad & 2u) continue;  // (timing experiments only: words dropped)
+                uint32_t* const ef = F.err_flags;
+                scatter_tile<BLOCK, kNW>(w_lds[d], w_par, mw[d], mb[d], L.region_cursor[d] + (size_t)w_sub * kCursorStride,
+                                         kRecSubs * kCursorStride, L.region[d] + (size_t)w_sub * L.region_cap,
+                                         (uint64_t)kRecSubs * L.region_cap, L.region_cap,
+                                         [&, d, ef](uint32_t b, uint64_t w) { word_over_append(L, d, b, w, ef); });
+            }
             w_par ^= 1u;
+        }
+    };
+    const uint32_t stride = gridDim.x * tile;
+    if constexpr (kND > 0) {
+        // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
+        // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
+        uint32_t tgA[R][kRowsPerItem][kFastCols], tgB[R][kRowsPerItem][kFastCols];
+        uint64_t pvA[R][kRowsPerItem][kFastCols], pvB[R][kRowsPerItem][kFastCols];
+        bool vA[R], vB[R];
+        uint32_t base = blockIdx.x * tile;
+        if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
+        while (base < nitems) {
+            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgB, pvB, vB);  // (beyond the end: no loads)
+            process(tgA, pvA, vA, base);
+            base += stride;
+            if (base >= nitems) break;
+            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgA, pvA, vA);
+            process(tgB, pvB, vB, base);
+            base += stride;
+        }
+    } else {
+        for (uint32_t base = blockIdx.x * tile; base < nitems; base += stride) {
+            // issue every load of the tile first (R items x ncols columns), then compute
+            uint32_t tg[R][kRowsPerItem][kFastCols];
+            uint64_t pv[R][kRowsPerItem][kFastCols];
+            bool valid[R];
+            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
+            process(tg, pv, valid, base);
         }
     }
 
-    if constexpr (kND > 0) {
-#pragma unroll
-        for (int d = 0; d < kND; d++) wc_finish<BLOCK>(L, d, w_lds[d], w_par, w_own[d]);
-    }
     if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
     // rows that passed the Filter (≙ Filter #itemsOut): wave shuffle, then ONE LDS counter per workgroup — thousands of
     // same-address global atomics at the end of the kernel cost ~10 % of its time

@@ -330,8 +330,9 @@ N1K_DEV bool member_word_bits(uint32_t key_bits, uint32_t val_bits, uint64_t key
     return true;
 }
 
-// radix digit of a member word / record key: 8 bits of its hash (equal words always share every digit)
-N1K_DEV uint32_t radix_bin(uint64_t w, uint32_t shift) { return (uint32_t)(mix64(w) >> shift) & 255u; }
+// radix digit of a member word / record key: 8 bits of its hash (equal words always share every digit); `shift` counts
+// as if the hash had 64 bits (first digit: 56)
+N1K_DEV uint32_t radix_bin(uint64_t w, uint32_t shift) { return (part_hash(w) >> (shift - 32u)) & 255u; }  // shift: 56, 48, 40, 32
 
 // ------------------------------------------------------------------ 16-byte records of the partitioned GROUP BY
 //
