@@ -175,7 +175,7 @@ struct n1k_handle {
     uint32_t opt_spec_debug = 0;           // timing experiments: 1 words not stored, 2 word scatter skipped, 4 no workgroup cache, 8 finish skips the sets
     uint64_t opt_region_cap = 0;           // forced capacity of a hash region (tests: overflow into the plain log), 0 = from the rows
     uint32_t opt_distinct_words = 1;      // 0: every pair takes the (key, value, class) log and the global sets
-    uint32_t opt_distinct_set_slots = 4096;  // LDS set size of the de-duplication kernel (power of two)
+    uint32_t opt_distinct_set_slots = 8192;  // LDS set size of the de-duplication kernel (power of two; 64 KB: two workgroups per CU)
     int32_t opt_distinct_levels = -1;        // partition passes before the LDS sets: -1 = by log size, 0..2 forced (tests)
     uint32_t nw_key_bits = 0, nw_val_bits = 0;
     bool distinct_words[kMaxDistinct] = {false, false, false, false};

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include "n1k_device.h"
 #include "n1k_tables.h"
+#include "n1k_scatter.h"
 #include "n1k_kernels.h"
 #include <algorithm>
 #include <vector>
@@ -622,9 +623,10 @@ __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P,
             nxt[u] = i < nhi ? D.words[i] : kEmptyKey;
         }
         if (lo != hi) {
-            __syncthreads();
+            // (LDS-only barriers: __syncthreads() would also drain the loads of the next bin's words just issued)
+            lds_barrier();
             for (uint32_t i = tid; i < D.set_slots; i += BLOCK) *(volatile lds_u64*)lds_word(set, i) = kEmptyKey;
-            __syncthreads();
+            lds_barrier();
             for (uint64_t base = lo; base < hi; base += (uint64_t)BLOCK * U) {
                 if (base != lo) {
 #pragma unroll

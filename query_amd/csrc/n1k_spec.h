@@ -250,17 +250,22 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
     }
 }
 
-// the loads of one tile (R items per thread x the Spec's columns), all issued before anything is computed
+// The loads of one tile (R items per thread x the Spec's columns), ALL issued before anything is computed from them: the
+// tags are derived in a second phase behind a scheduling barrier.  (Without it the compiler interleaved the first item's
+// tag arithmetic with the loads and waited for the first item's data — s_waitcnt vmcnt(0) — before it had issued the
+// second item's loads: two memory latencies per tile instead of one, config 2's scan 237 -> 283 us.)
 template <class Spec, int R, int BLOCK, bool WIDE>
 N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, uint32_t tid,
                             uint32_t (&tg)[R][WIDE ? 2 : 1][kFastCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kFastCols], bool (&valid)[R]) {
     constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
+    uint32_t tt[R][kFastCols];  // TAGGED64 columns: the item's tag bytes as loaded (WIDE: two rows' tags in one 16-bit load)
 #pragma unroll
     for (int j = 0; j < R; j++) {
         const uint32_t i = base + (uint32_t)j * BLOCK + tid;
         valid[j] = i < nitems;
 #pragma unroll
         for (int c = 0; c < kFastCols; c++) {
+            tt[j][c] = 0;
             if (c < Spec::ncols) {
                 if (Spec::col_kind[c] == COLK_DICT32) {
                     if (WIDE) {
@@ -272,29 +277,40 @@ N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, u
                     } else {
                         pv[j][0][c] = valid[j] ? F.cols[c].codes[i] : 0xFFFFFFFFu;
                     }
-#pragma unroll
-                    for (int h = 0; h < (int)kRowsPerItem; h++) {
-                        uint32_t code = (uint32_t)pv[j][h][c];
-                        tg[j][h][c] = code == 0xFFFFFFFFu ? (uint32_t)T_MISSING : (code == 0xFFFFFFFEu ? (uint32_t)T_NULL : (uint32_t)T_STRING);
-                    }
                 } else {
                     if (WIDE) {
                         typedef unsigned long long n1k_u64x2 __attribute__((ext_vector_type(2)));
                         n1k_u64x2 pp = {0ull, 0ull};
                         if (valid[j]) pp = __builtin_nontemporal_load((const n1k_u64x2*)F.cols[c].payload + i);
-                        uint32_t tt = valid[j] ? (uint32_t)__builtin_nontemporal_load((const uint16_t*)F.cols[c].tags + i) : 0u;
+                        if (valid[j]) tt[j][c] = (uint32_t)__builtin_nontemporal_load((const uint16_t*)F.cols[c].tags + i);
                         pv[j][0][c] = pp.x;
                         pv[j][WIDE ? 1 : 0][c] = pp.y;
-                        tg[j][0][c] = tt & 255u;
-                        tg[j][WIDE ? 1 : 0][c] = tt >> 8;
                     } else {
                         pv[j][0][c] = valid[j] ? F.cols[c].payload[i] : 0ull;
-                        tg[j][0][c] = valid[j] ? (uint32_t)F.cols[c].tags[i] : (uint32_t)T_MISSING;
+                        tt[j][c] = valid[j] ? (uint32_t)F.cols[c].tags[i] : (uint32_t)T_MISSING;
                     }
                 }
             } else {
 #pragma unroll
-                for (int h = 0; h < (int)kRowsPerItem; h++) { tg[j][h][c] = T_MISSING; pv[j][h][c] = 0; }
+                for (int h = 0; h < (int)kRowsPerItem; h++) pv[j][h][c] = 0;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // nothing below moves up between the loads
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+#pragma unroll
+        for (int c = 0; c < kFastCols; c++) {
+#pragma unroll
+            for (int h = 0; h < (int)kRowsPerItem; h++) {
+                if (c >= Spec::ncols) {
+                    tg[j][h][c] = T_MISSING;
+                } else if (Spec::col_kind[c] == COLK_DICT32) {
+                    const uint32_t code = (uint32_t)pv[j][h][c];
+                    tg[j][h][c] = code == 0xFFFFFFFFu ? (uint32_t)T_MISSING : (code == 0xFFFFFFFEu ? (uint32_t)T_NULL : (uint32_t)T_STRING);
+                } else {
+                    tg[j][h][c] = WIDE ? (h == 0 ? (tt[j][c] & 255u) : (tt[j][c] >> 8)) : tt[j][c];
+                }
             }
         }
     }
