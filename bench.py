@@ -28,7 +28,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 SEED = 0x5EED0001
-METRIC = "rows/sec filter+group-by on 100M synthetic JSON docs; achieved HBM GB/s"  # BASELINE.json's metric, verbatim
+METRIC = "rows/sec filter+group-by on 100M synthetic JSON docs; achieved HBM GB/s"  # BASELINE.json's metric, verbatim (the
+# timed region runs over the documents' pre-extracted columns resident in HBM: config.workload says so; the rates from host
+# buffers and from raw JSON text are the h2d_inclusive / json_end_to_end sub-records)
 DTYPE = "int64/f64 tagged scalars (u8 tag + 8 B payload), u32 dictionary codes"
 
 
@@ -235,15 +237,16 @@ def main():
     }
     # HBM traffic of the dominant kernel from the committed PMC passes of this same command (rocprofv3 --pmc cannot run
     # inside the timed process): FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950 counts a wide coalesced
-    # read at half its bytes), WRITE_SIZE is exact; both are KB per dispatch.
-    pmc = os.path.join(ROOT, "profiles", "r01_bench_config2_100M_pmc_fetch_write.json")
-    if args.workload == "config2" and args.rows == 100_000_000 and args.kcat == 1000 and os.path.exists(pmc):
+    # read at half its bytes), WRITE_SIZE is exact; both are KB per dispatch.  The figure belongs to the build the
+    # profile was taken from (tools/profile_round.sh; `traffic_source` names the file): re-profile after kernel changes.
+    pmc = os.path.join(ROOT, "profiles", "r02_bench_%s_100M_pmc_fetch_write.json" % args.workload)
+    if args.rows == 100_000_000 and args.kcat == (100_000 if args.workload.startswith("config5") else 1000) and os.path.exists(pmc):
         try:
             with open(pmc) as fh:
                 c = json.load(fh)
-            k = [n for n in c["FETCH_SIZE"] if "scan_spec_kernel" in n][0]
+            k = [n for n in c["FETCH_SIZE"] if "scan_spec_" in n][0]
             out["roofline"]["traffic"] = 1024.0 * (2.0 * c["FETCH_SIZE"][k]["avg_KB"] + c["WRITE_SIZE"][k]["avg_KB"])
-            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc) + " (scan_spec_kernel, 2*FETCH_SIZE + WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc) + " (%s, 2*FETCH_SIZE + WRITE_SIZE)" % k.split("<")[0].split("::")[-1]
         except Exception:
             pass
     if not args.no_cpu:

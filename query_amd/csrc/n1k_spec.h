@@ -30,6 +30,10 @@ namespace n1k {
     }
 
 // flag bits: fire-and-forget ds_or (no LDS read, so the row loop never waits on lgkmcnt)
+// (experiment switch: two tiles in flight for every shape, not only those whose tiles end in barriers)
+#ifndef N1K_SPEC_PIPE_ALL
+#define N1K_SPEC_PIPE_ALL 0
+#endif
 #ifndef SPEC_FLAG
 #define SPEC_FLAG(ptr, bit) lds_or_u64((ptr), (bit))
 #endif
@@ -510,7 +514,7 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
         }
     };
     const uint32_t stride = gridDim.x * tile;
-    if constexpr (kND > 0) {
+    if constexpr (kND > 0 || N1K_SPEC_PIPE_ALL) {
         // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
         // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
         uint32_t tgA[R][kRowsPerItem][kFastCols], tgB[R][kRowsPerItem][kFastCols];

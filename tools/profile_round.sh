@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/profile_round.sh <round tag, e.g. r02>: the round's committed evidence for every bench workload, run on the GPU box
+# from the repo root — per workload the bench line, the rocprofv3 kernel stats and the two PMC passes (FETCH_SIZE,
+# WRITE_SIZE, each alone).  Output: gpurun_out/profiles_<tag>/ — copy into profiles/ and commit.
+set -e
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+DST=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p $DST
+for WL in config2 config3 config5; do
+  python3 $ROOT/bench.py --workload $WL --steps 20 --warmup 3 2>/dev/null | tail -1 > $DST/${TAG}_bench_${WL}_100M.json.log
+  bash $ROOT/tools/prof.sh ${TAG}_$WL all -- --workload $WL > /dev/null
+  cp $ROOT/gpurun_out/prof_${TAG}_$WL/stats/bench_kernel_stats.csv $DST/${TAG}_bench_${WL}_100M_kernel_stats.csv
+  cp $ROOT/gpurun_out/prof_${TAG}_$WL/pmc_fetch_write.json $DST/${TAG}_bench_${WL}_100M_pmc_fetch_write.json
+  python3 $ROOT/tools/timeline.py $ROOT/gpurun_out/prof_${TAG}_$WL/stats init_table_kernel $([ $WL = config5 ] && echo 2 || echo 1) > $DST/${TAG}_bench_${WL}_100M_timeline.txt
+  echo "$WL done"
+done
+ls -la $DST
