@@ -65,6 +65,20 @@ def workloads():
             "order": [("sum(%s)" % D("price"), True)], "limit": 100,
             "bytes_per_row": 22,
         },
+        # arithmetic in the Filter and in the aggregate's operand (tests' ARITH_CASES[0]) next to the same shape without it:
+        # the run-time-built scan evaluates the nodes in registers, both read the same 22 B per row
+        "arith": {
+            "sql": "SELECT cat, COUNT(*), SUM(price * region_id) FROM default WHERE price + region_id > 100 GROUP BY cat",
+            "cond": "(100 < (%s + %s))" % (D("price"), D("region_id")), "keys": [D("cat")],
+            "aggs": ["count(*)", "sum((%s * %s))" % (D("price"), D("region_id"))],
+            "bytes_per_row": 22,
+        },
+        "arith_plain": {
+            "sql": "SELECT cat, COUNT(*), SUM(region_id) FROM default WHERE price > 50 GROUP BY cat",
+            "cond": "(50 < %s)" % D("price"), "keys": [D("cat")],
+            "aggs": ["count(*)", "sum(%s)" % D("region_id")],
+            "bytes_per_row": 22,
+        },
         "config5_keys": {
             "sql": "SELECT cat, region_id, SUM(price) FROM default GROUP BY cat, region_id",
             "cond": None, "keys": [D("cat"), D("region_id")], "aggs": ["sum(%s)" % D("price")],

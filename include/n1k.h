@@ -152,7 +152,7 @@ typedef struct n1k_stats {
     double device_ms;       /* hipEvent time of all device work (≙ execTime) */
     uint64_t bytes_scanned; /* algorithmic column bytes read by the scan kernel */
     uint32_t agg_mode;      /* n1k_agg_mode actually used by the last batch */
-    uint32_t spec_kernel;   /* plan-specialised kernel that ran the last batch: 0 none, 1 prebuilt, 2 built at run time */
+    uint32_t spec_kernel;   /* plan-specialised kernel that ran the last batch: 0 none, 1 prebuilt, 2 built at run time, 3 built at run time with the plan's arithmetic nodes evaluated in registers */
     uint64_t wide_key_values; /* distinct key numbers held in the wide-value tables (floats, |int| beyond the field); set by finish/export */
     uint32_t distinct_path;  /* how the last finish built the DISTINCT sets: bit 0 per-group sets in global memory (two-word
                                 pairs), bit 1 radix partition + LDS sets (one-word members), bit 2 global one-word set (fallback) */

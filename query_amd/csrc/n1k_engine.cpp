@@ -88,6 +88,8 @@ struct n1k_handle {
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
     uint64_t opt_jit_min_rows = 4u << 20;
+    uint32_t opt_fuse_arith = 1;   // arithmetic nodes evaluated in registers by the run-time-built scan (no derived columns)
+    bool derived_ready = true;     // the derived columns of the batch being pushed are materialised (or there are none)
     uint64_t opt_wide_values = 1u << 20;  // capacity of the wide key value tables (distinct big ints / floats)
     DevBuf<uint64_t> d_wide_int, d_wide_flt;
     // high-cardinality GROUP BY: record arrays (ping-pong per partition pass) and its tuning
@@ -236,6 +238,8 @@ n1k_status fail(n1k_handle* h, n1k_status st, const char* fmt, ...) {
             return fail(h, _e == hipErrorOutOfMemory ? N1K_OOM : N1K_DEVICE_ERROR, "%s failed: %s", #expr, \
                         hipGetErrorString(_e));                                                           \
     } while (0)
+
+n1k_status materialize_derived(n1k_handle* h, const n1k_batch* b);
 
 uint32_t intern(n1k_handle* h, const std::string& s) {
     auto it = h->dict_index.find(s);
@@ -725,10 +729,23 @@ uint64_t batch_bytes_per_row(const n1k_handle* h) {
 }
 
 // Can this plan run on the fast kernel (bounded shape, every descriptor static)?  Fills F when it can.
-bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F) {
+// fuse: the plan's arithmetic nodes stay out of HBM — the kernel (a run-time-built plan-specialised one) evaluates them in
+// registers from the input columns; otherwise they are materialised derived columns and count as inputs.
+bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F, bool fuse = false) {
     const Program& P = h->prog;
     memset(&F, 0, sizeof F);
-    if (h->opt_fast == 0 || P.want_rep_row || P.ncols == 0 || P.ncols > (uint32_t)kFastCols) return false;
+    const uint32_t ni = (uint32_t)h->plan.paths.size(), nd = (uint32_t)h->derived.size();
+    if (fuse) {
+        if (nd == 0 || nd > (uint32_t)kFastDerived || ni == 0 || ni > (uint32_t)kFastCols) return false;
+        for (uint32_t d = 0; d < nd; d++)
+            for (uint32_t k = 0; k < h->derived[d].nops; k++) {
+                const Operand& o = h->derived[d].ops[k];
+                if (!o.is_const && o.col >= ni + d) return false;
+                if (o.is_const) F.dconst[d][k] = o.cpayload;
+            }
+        F.nderived = nd;
+    }
+    if (h->opt_fast == 0 || P.want_rep_row || P.ncols == 0 || (!fuse && P.ncols > (uint32_t)kFastCols)) return false;
     if (P.nkeys > (uint32_t)kFastKeys || P.naggs > (uint32_t)kFastAggs || P.naggs == 0) return false;
     // predicate: none, one term, or AND of two terms
     uint32_t term_ix[2] = {0, 0};
@@ -798,8 +815,8 @@ bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F) {
             F.agg_col[a] = ag.src.col;
         }
     }
-    F.ncols = P.ncols;
-    for (uint32_t c = 0; c < P.ncols; c++) F.cols[c] = P.cols[c];
+    F.ncols = fuse ? ni : P.ncols;
+    for (uint32_t c = 0; c < F.ncols; c++) F.cols[c] = P.cols[c];
     return true;
 }
 
@@ -822,6 +839,16 @@ SpecSig make_plan_sig(const n1k_handle* h, const FastArgs& F) {
         g.aggs[a].has_operand = P.aggs[a].has_operand;
         g.aggs[a].col = P.aggs[a].has_operand ? F.agg_col[a] : 0u;
         g.aggs[a].distinct = P.aggs[a].distinct ? 1u : 0u;
+    }
+    g.nderived = (int)F.nderived;
+    for (uint32_t d = 0; d < F.nderived; d++) {
+        g.derived[d].op = h->derived[d].op;
+        g.derived[d].nops = h->derived[d].nops;
+        for (uint32_t k = 0; k < h->derived[d].nops; k++) {
+            const Operand& o = h->derived[d].ops[k];
+            g.derived[d].ops[k].is_const = o.is_const ? 1u : 0u;
+            g.derived[d].ops[k].v = o.is_const ? o.ctag : o.col;
+        }
     }
     return g;
 }
@@ -901,7 +928,26 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
     FastArgs F;
     // DIRECT tables may take (almost) the whole 160 KiB LDS of a CU: occupancy is chosen from the table size
     const uint32_t direct_max_slots = (uint32_t)std::min<uint64_t>((156u * 1024u) / (P.lds_words * 8), 1u << 15);
-    if (h->opt_agg_mode != N1K_MODE_LDS_HASH && build_fast_args(h, direct_max_slots, F)) {
+    // Arithmetic nodes not materialised yet: is there a run-time-built kernel of this shape that evaluates them in
+    // registers (same conditions as the kernel choice below)?  If not they become derived columns now.
+    bool fuse = false;
+    if (!h->derived_ready) {
+        if (h->opt_fuse_arith && h->opt_agg_mode != N1K_MODE_LDS_HASH && h->opt_spec && h->opt_jit &&
+            (h->opt_jit == 2 || b->nrows >= h->opt_jit_min_rows) && build_fast_args(h, direct_max_slots, F, true)) {
+            bool kh = false;
+            for (uint32_t k = 0; k < F.nkeys; k++) kh |= F.keys[k].col >= F.ncols || F.cols[F.keys[k].col].kind != COLK_DICT32;
+            if ((size_t)F.lds_slots * P.lds_words * 8 <= 64 * 1024 && kh == (F.hashed != 0)) {
+                const JitKernel* k = jit_get(make_plan_sig(h, F));
+                if (k->failed) h->jit_log = k->log;
+                else fuse = true;
+            }
+        }
+        if (!fuse) {
+            st = materialize_derived(h, b);
+            if (st != N1K_OK) return st;
+        }
+    }
+    if (h->opt_agg_mode != N1K_MODE_LDS_HASH && build_fast_args(h, direct_max_slots, F, fuse)) {
         // Shapes with COUNT(DISTINCT): the specialised kernels keep nothing of a DISTINCT aggregate in the workgroup
         // table (its member words go to the hash regions), so they run on a copy of the program with a compact LDS layout
         Program Pc;
@@ -949,7 +995,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         // no prebuilt kernel of this shape: instantiate the same template at run time (large batches, or forced)
         const JitKernel* jit = nullptr;
         bool key_kinds_hashed = false;
-        for (uint32_t k = 0; k < F.nkeys; k++) key_kinds_hashed |= F.cols[F.keys[k].col].kind != COLK_DICT32;
+        for (uint32_t k = 0; k < F.nkeys; k++) key_kinds_hashed |= F.keys[k].col >= F.ncols || F.cols[F.keys[k].col].kind != COLK_DICT32;  // (a fused node is a TAGGED64 value)
         if (!spec && h->opt_spec && h->opt_jit && (h->opt_jit == 2 || b->nrows >= h->opt_jit_min_rows) &&
             table_bytes <= 64 * 1024 && key_kinds_hashed == (F.hashed != 0)) {
             jit = jit_get(sig);
@@ -963,7 +1009,8 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             per_cu = table_bytes <= 48 * 1024 ? 3u : 2u;
             fgrid = h->opt_grid_blocks ? h->opt_grid_blocks : (uint32_t)(h->num_cus * per_cu);
         }
-        h->stats.spec_kernel = spec ? 1u : (jit ? 2u : 0u);
+        h->stats.spec_kernel = spec ? 1u : (jit ? (F.nderived ? 3u : 2u) : 0u);
+        if (F.nderived && !jit) return fail(h, N1K_DEVICE_ERROR, "fused arithmetic without its kernel");  // (decided above)
         if ((F.hashed || ndist || h->push_nrows_dev) && !spec && !jit) goto interpreter;  // the bounded-shape kernel is DIRECT only, no DISTINCT
         F.nrows_dev = h->push_nrows_dev;
         WordLogArgs L;
@@ -1029,7 +1076,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             uint64_t n = std::min<uint64_t>(chunk, b->nrows - off);
             F.row_base = h->row_base + off;
             bool aligned = true;
-            for (uint32_t c = 0; c < P.ncols; c++) {
+            for (uint32_t c = 0; c < F.ncols; c++) {
                 F.cols[c] = P.cols[c];
                 if (F.cols[c].tags) F.cols[c].tags += off;
                 if (F.cols[c].payload) F.cols[c].payload += off;
@@ -1060,7 +1107,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
                 F.slabs = nullptr;
                 if (n_main < n) {
-                    for (uint32_t c = 0; c < P.ncols; c++) {
+                    for (uint32_t c = 0; c < F.ncols; c++) {
                         if (F.cols[c].tags) F.cols[c].tags += n_main;
                         if (F.cols[c].payload) F.cols[c].payload += n_main;
                         if (F.cols[c].codes) F.cols[c].codes += n_main;
@@ -1157,8 +1204,9 @@ n1k_status run_filter_batch(n1k_handle* h, const n1k_batch* b) {
     return N1K_OK;
 }
 
-// Point the program at this batch's input columns and evaluate the arithmetic nodes into derived columns.
-n1k_status bind_columns(n1k_handle* h, const n1k_batch* b) {
+// Point the program at this batch's input columns and evaluate the arithmetic nodes into derived columns (defer: not
+// yet — run_group_batch first looks for a kernel that evaluates them in registers, and materialises them otherwise).
+n1k_status bind_columns(n1k_handle* h, const n1k_batch* b, bool defer = false) {
     Program& P = h->prog;
     // first push: give the plan's string constants their dictionary codes
     auto resolve = [&](Operand& o) {
@@ -1183,7 +1231,23 @@ n1k_status bind_columns(n1k_handle* h, const n1k_batch* b) {
     P.empty_str_code = lookup_code(h, "");
     P.empty_arr_code = lookup_code(h, "[]");
     P.empty_obj_code = lookup_code(h, "{}");
-    if (h->derived.empty()) return N1K_OK;
+    h->derived_ready = h->derived.empty();
+    if (h->derived_ready) return N1K_OK;
+    for (size_t i = 0; i < h->derived.size(); i++) {
+        DevCol& d = P.cols[ni + i];
+        d.kind = COLK_TAGGED64;
+        d.tags = nullptr;
+        d.payload = nullptr;
+        d.codes = nullptr;
+    }
+    return defer ? N1K_OK : materialize_derived(h, b);
+}
+
+// one element-wise arith_kernel launch per arithmetic node: the node's values as a TAGGED64 column in HBM
+n1k_status materialize_derived(n1k_handle* h, const n1k_batch* b) {
+    Program& P = h->prog;
+    if (h->derived_ready) return N1K_OK;
+    const uint32_t ni = (uint32_t)h->plan.paths.size();
     h->dv_tags.resize(h->derived.size());
     h->dv_payload.resize(h->derived.size());
     for (size_t i = 0; i < h->derived.size(); i++) {
@@ -1206,6 +1270,7 @@ n1k_status bind_columns(n1k_handle* h, const n1k_batch* b) {
         d.payload = A.out_payload;
         d.codes = nullptr;
     }
+    h->derived_ready = true;
     return N1K_OK;
 }
 
@@ -1614,7 +1679,9 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     std::vector<n1k_col> cols;
     n1k_batch v{};
     view(0, b->nrows, cols, v);
-    st = bind_columns(h, &v);
+    // (the probe, the partitioned path and the Filter-only kernels read derived columns; run_group_batch decides itself)
+    const bool defer = h->plan.has_group && !decide && !(can_partition && head == 0);
+    st = bind_columns(h, &v, defer);
     if (st != N1K_OK) return st;
     st = ensure_rank(h);
     if (st != N1K_OK) return st;
@@ -2076,6 +2143,7 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fast") h->opt_fast = value ? 1 : 0;
     else if (n == "spec") h->opt_spec = value ? 1 : 0;
     else if (n == "wide") h->opt_wide = value ? 1 : 0;
+    else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
     else if (n == "jit") h->opt_jit = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
     else if (n == "jit_min_rows") h->opt_jit_min_rows = (uint64_t)std::max<int64_t>(value, 0);
     else if (n == "distinct_words") {
@@ -3082,7 +3150,9 @@ n1k_status n1k_jit_check(n1k_handle* h, const uint32_t* col_kinds, uint32_t ncol
     for (uint32_t c = ncols; c < h->prog.ncols; c++) h->prog.cols[c].kind = COLK_TAGGED64;
     FastArgs F;
     const uint32_t max_slots = (uint32_t)std::min<uint64_t>((156u * 1024u) / (h->prog.lds_words * 8), 1u << 15);
-    if (!build_fast_args(h, max_slots, F)) return fail(h, N1K_UNSUPPORTED, "the plan shape is outside the bounded family");
+    // (plans with arithmetic: the shape that evaluates the nodes in registers, as run_group_batch would choose it)
+    const bool fuse = !h->derived.empty() && h->opt_fuse_arith;
+    if (!build_fast_args(h, max_slots, F, fuse)) return fail(h, N1K_UNSUPPORTED, "the plan shape is outside the bounded family");
     SpecSig sig = make_plan_sig(h, F);
     std::string l;
     bool ok = jit_compile_check(sig, &l);

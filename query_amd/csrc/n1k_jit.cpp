@@ -75,9 +75,20 @@ std::string jit_source(const SpecSig& g) {
         else x << "SpecAgg{0u, 0u, 0u, 0u}";
         return x.str();
     };
+    auto derived = [&](int d) {
+        std::ostringstream x;
+        if (d < g.nderived) {
+            x << "SpecDerived{" << g.derived[d].op << "u, " << g.derived[d].nops << "u, {";
+            for (int k = 0; k < 4; k++) x << (k ? ", " : "") << "SpecOperand{" << g.derived[d].ops[k].is_const << "u, " << g.derived[d].ops[k].v << "u}";
+            x << "}}";
+        } else
+            x << "SpecDerived{0u, 0u, {SpecOperand{0u, 0u}, SpecOperand{0u, 0u}, SpecOperand{0u, 0u}, SpecOperand{0u, 0u}}}";
+        return x.str();
+    };
     o << "struct SpecJ {\n"
       << "    static constexpr int ncols = " << g.ncols << ", nterms = " << g.nterms << ", nkeys = " << g.nkeys
-      << ", naggs = " << g.naggs << ";\n"
+      << ", naggs = " << g.naggs << ", nderived = " << g.nderived << ";\n"
+      << "    static constexpr SpecDerived derived[kFastDerived] = {" << derived(0) << ", " << derived(1) << ", " << derived(2) << "};\n"
       << "    static constexpr uint32_t col_kind[kFastCols] = {" << g.col_kind[0] << "u, " << g.col_kind[1] << "u, "
       << g.col_kind[2] << "u};\n"
       << "    static constexpr SpecTerm terms[kFastTerms] = {" << term(0) << ", " << term(1) << "};\n"

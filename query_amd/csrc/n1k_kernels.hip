@@ -212,77 +212,9 @@ __global__ void arith_kernel(const ArithArgs A) {
             }
         }
     }
-    auto is_num = [](uint32_t t) { return t == T_INT || t == T_FLOAT; };
-    uint32_t rt = T_NULL;
-    uint64_t rp = 0;
-    if (A.op == AR_ADD || A.op == AR_MULT) {
-        bool null = false, missing = false;
-        Num acc = num_int(A.op == AR_ADD ? 0 : 1);
-        for (uint32_t k = 0; k < A.nops; k++) {
-            if (!null && is_num(tg[k])) acc = A.op == AR_ADD ? num_add(acc, Num{tg[k], pv[k]}) : num_mult(acc, Num{tg[k], pv[k]});
-            else if (tg[k] == T_MISSING) missing = true;
-            else null = true;
-        }
-        if (missing) rt = T_MISSING;
-        else if (null) rt = T_NULL;
-        else { rt = acc.tag; rp = acc.p; }
-    } else if (A.op == AR_NEG) {
-        if (is_num(tg[0])) { Num r = num_neg(Num{tg[0], pv[0]}); rt = r.tag; rp = r.p; }
-        else rt = tg[0] == T_MISSING ? (uint32_t)T_MISSING : (uint32_t)T_NULL;
-    } else if (A.op >= AR_ROUND) {
-        // expression/func_num.go: the argument goes through float64 (intValue.Actual() is float64(this),
-        // value/integer.go:57-59) and the result through value.NewValue (integral results fold back to int)
-        if (tg[0] == T_MISSING) rt = T_MISSING;
-        else if (is_num(tg[0])) {
-            const double v = num_actual(tg[0], pv[0]);
-            int prec = 0;
-            bool ok = true;
-            if ((A.op == AR_ROUND || A.op == AR_TRUNC) && A.nops == 2) {  // Round.Apply / Trunc.Apply: the digits argument
-                if (tg[1] == T_MISSING) { rt = T_MISSING; ok = false; }
-                else if (!is_num(tg[1])) ok = false;  // NULL
-                else {
-                    const double pf = num_actual(tg[1], pv[1]);
-                    if (pf != trunc(pf)) ok = false;  // NULL
-                    else prec = pf > 400.0 ? 400 : (pf < -400.0 ? -400 : (int)pf);
-                }
-            }
-            if (ok) {
-                double r;
-                switch (A.op) {
-                    case AR_ROUND: r = round_float(v, prec); break;
-                    case AR_TRUNC: { const double pw = pow10_go(prec); r = trunc(v * pw) / pw; break; }  // truncateFloat
-                    case AR_ABS: r = fabs(v); break;
-                    case AR_CEIL: r = ceil(v); break;
-                    case AR_FLOOR: r = floor(v); break;
-                    case AR_SIGN: r = v < 0.0 ? -1.0 : (v > 0.0 ? 1.0 : 0.0); break;
-                    default: r = sqrt(v); break;
-                }
-                Num n = num_new_value(r);
-                rt = n.tag;
-                rp = n.p;
-            }
-        }
-    } else {
-        bool both = is_num(tg[0]) && is_num(tg[1]);
-        if (tg[0] == T_MISSING || tg[1] == T_MISSING) rt = T_MISSING;
-        else if (A.op == AR_SUB) {
-            if (both) { Num r = num_sub(Num{tg[0], pv[0]}, Num{tg[1], pv[1]}); rt = r.tag; rp = r.p; }
-        } else if (A.op == AR_DIV || A.op == AR_MOD) {
-            if (is_num(tg[1])) {
-                double d = num_actual(tg[1], pv[1]);
-                if (d != 0.0 && is_num(tg[0])) {
-                    double x = num_actual(tg[0], pv[0]);
-                    Num r = num_new_value(A.op == AR_DIV ? x / d : fmod(x, d));
-                    rt = r.tag;
-                    rp = r.p;
-                }
-            }
-        } else if (both) {  // IDIV / IMOD
-            Num r = num_idiv_imod(Num{tg[0], pv[0]}, Num{tg[1], pv[1]}, A.op == AR_IMOD);
-            rt = r.tag;
-            rp = r.p;
-        }
-    }
+    uint32_t rt;
+    uint64_t rp;
+    arith_apply(A.op, A.nops, tg, pv, rt, rp);
     A.out_tags[i] = (uint8_t)rt;
     A.out_payload[i] = rp;
 }

@@ -20,9 +20,12 @@ namespace n1k {
 //   static constexpr SpecTerm terms[kFastTerms];
 //   static constexpr uint32_t key_col[kFastKeys];
 //   static constexpr SpecAgg aggs[kFastAggs];
+//   static constexpr int nderived; static constexpr SpecDerived derived[kFastDerived];   (fused arithmetic nodes: column
+//   slots ncols .. ncols + nderived - 1, evaluated in registers from the loaded columns — run-time-built shapes only)
 #define N1K_DEFINE_SPEC(NAME, NCOLS, K0, K1, K2, NTERMS, T0, T1, NKEYS, KC0, KC1, NAGGS, A0, A1, A2, A3, A4) \
     struct NAME {                                                                                            \
-        static constexpr int ncols = NCOLS, nterms = NTERMS, nkeys = NKEYS, naggs = NAGGS;                    \
+        static constexpr int ncols = NCOLS, nterms = NTERMS, nkeys = NKEYS, naggs = NAGGS, nderived = 0;      \
+        static constexpr SpecDerived derived[kFastDerived] = {};                                              \
         static constexpr uint32_t col_kind[kFastCols] = {K0, K1, K2};                                         \
         static constexpr SpecTerm terms[kFastTerms] = {T0, T1};                                               \
         static constexpr uint32_t key_col[kFastKeys] = {KC0, KC1};                                            \
@@ -176,8 +179,8 @@ N1K_DEV void spec_pair_log(const Program& P, const GlobalTable& G, const WordLog
 
 template <class Spec>
 N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
-                      uint64_t* lds, uint32_t S, uint32_t* lds_fill, const uint32_t (&tg)[kFastCols],
-                      const uint64_t (&pv)[kFastCols], uint32_t& selected, uint32_t& unpackable, const WordLogArgs& L,
+                      uint64_t* lds, uint32_t S, uint32_t* lds_fill, const uint32_t (&tg)[kSpecCols],
+                      const uint64_t (&pv)[kSpecCols], uint32_t& selected, uint32_t& unpackable, const WordLogArgs& L,
                       uint64_t* dcache, uint64_t (&words)[kSpecDistinct], uint32_t (&bins)[kSpecDistinct]) {
     constexpr int kND = spec_ndistinct<Spec>();
     bool pass = true;
@@ -260,7 +263,7 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
 // second item's loads: two memory latencies per tile instead of one, config 2's scan 237 -> 283 us.)
 template <class Spec, int R, int BLOCK, bool WIDE>
 N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, uint32_t tid,
-                            uint32_t (&tg)[R][WIDE ? 2 : 1][kFastCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kFastCols], bool (&valid)[R]) {
+                            uint32_t (&tg)[R][WIDE ? 2 : 1][kSpecCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kSpecCols], bool (&valid)[R]) {
     constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
     uint32_t tt[R][kFastCols];  // TAGGED64 columns: the item's tag bytes as loaded (WIDE: two rows' tags in one 16-bit load)
 #pragma unroll
@@ -304,17 +307,46 @@ N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, u
 #pragma unroll
     for (int j = 0; j < R; j++) {
 #pragma unroll
-        for (int c = 0; c < kFastCols; c++) {
+        for (int c = 0; c < kSpecCols; c++) {
 #pragma unroll
             for (int h = 0; h < (int)kRowsPerItem; h++) {
                 if (c >= Spec::ncols) {
                     tg[j][h][c] = T_MISSING;
+                    if (c >= kFastCols) pv[j][h][c] = 0;
                 } else if (Spec::col_kind[c] == COLK_DICT32) {
                     const uint32_t code = (uint32_t)pv[j][h][c];
                     tg[j][h][c] = code == 0xFFFFFFFFu ? (uint32_t)T_MISSING : (code == 0xFFFFFFFEu ? (uint32_t)T_NULL : (uint32_t)T_STRING);
                 } else {
                     tg[j][h][c] = WIDE ? (h == 0 ? (tt[j][c] & 255u) : (tt[j][c] >> 8)) : tt[j][c];
                 }
+            }
+        }
+        // fused arithmetic nodes (expression/arith_*.go, func_num.go): column slot ncols + d from the slots before it,
+        // in registers — no derived column in HBM (the element-wise arith_kernel writes 9 B per row and node and the scan
+        // reads them back)
+#pragma unroll
+        for (int d = 0; d < Spec::nderived; d++) {
+#pragma unroll
+            for (int h = 0; h < (int)kRowsPerItem; h++) {
+                uint32_t ot[4] = {T_MISSING, T_MISSING, T_MISSING, T_MISSING};
+                uint64_t op[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < (int)Spec::derived[d].nops) {
+                        if (Spec::derived[d].ops[k].is_const) {
+                            ot[k] = Spec::derived[d].ops[k].v;
+                            op[k] = F.dconst[d][k];
+                        } else {
+                            ot[k] = tg[j][h][Spec::derived[d].ops[k].v];
+                            op[k] = pv[j][h][Spec::derived[d].ops[k].v];
+                        }
+                    }
+                }
+                uint32_t rt;
+                uint64_t rp;
+                arith_apply(Spec::derived[d].op, Spec::derived[d].nops, ot, op, rt, rp);
+                tg[j][h][Spec::ncols + d] = rt;
+                pv[j][h][Spec::ncols + d] = rp;
             }
         }
     }
@@ -360,7 +392,7 @@ constexpr int spec_operand_col() {
 N1K_DEV uint32_t rec16_region(const Rec16& r) { return part_hash(r.k & ~kRecIntFlag) >> 24; }
 
 template <class Spec>
-N1K_DEV void spec_row_record(const Program& P, const FastArgs& F, const uint32_t (&tg)[kFastCols], const uint64_t (&pv)[kFastCols],
+N1K_DEV void spec_row_record(const Program& P, const FastArgs& F, const uint32_t (&tg)[kSpecCols], const uint64_t (&pv)[kSpecCols],
                              uint32_t& selected, uint32_t& unpackable, Rec16& rec, uint32_t& bin) {
     bool pass = true;
 #pragma unroll
@@ -399,7 +431,7 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
     const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
     const uint32_t tile = BLOCK * R;
     uint32_t* const flag = L.rec_overflow;
-    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kFastCols], const uint64_t (&pv)[R][kRowsPerItem][kFastCols],
+    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kSpecCols], const uint64_t (&pv)[R][kRowsPerItem][kSpecCols],
                        const bool (&valid)[R], uint32_t base) {
         Rec16 recs[kNW];
         uint32_t bins[kNW];
@@ -421,8 +453,8 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
     };
     // Two tiles in flight: the columns of tile t + 1 are requested before tile t's records go through LDS (three barriers
     // and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
-    uint32_t tgA[R][kRowsPerItem][kFastCols], tgB[R][kRowsPerItem][kFastCols];
-    uint64_t pvA[R][kRowsPerItem][kFastCols], pvB[R][kRowsPerItem][kFastCols];
+    uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+    uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
     bool vA[R], vB[R];
     const uint32_t stride = gridDim.x * tile;
     uint32_t base = blockIdx.x * tile;
@@ -482,7 +514,7 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
     const uint32_t tile = BLOCK * R;
 
-    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kFastCols], const uint64_t (&pv)[R][kRowsPerItem][kFastCols],
+    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kSpecCols], const uint64_t (&pv)[R][kRowsPerItem][kSpecCols],
                        const bool (&valid)[R], uint32_t base) {
         uint64_t mw[kSpecDistinct][kNW];  // this thread's member words of the tile (kEmptyKey = none) and their hash regions
         uint32_t mb[kSpecDistinct][kNW];
@@ -517,8 +549,8 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     if constexpr (kND > 0 || N1K_SPEC_PIPE_ALL) {
         // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
         // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
-        uint32_t tgA[R][kRowsPerItem][kFastCols], tgB[R][kRowsPerItem][kFastCols];
-        uint64_t pvA[R][kRowsPerItem][kFastCols], pvB[R][kRowsPerItem][kFastCols];
+        uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+        uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
         bool vA[R], vB[R];
         uint32_t base = blockIdx.x * tile;
         if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
@@ -534,8 +566,8 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     } else {
         for (uint32_t base = blockIdx.x * tile; base < nitems; base += stride) {
             // issue every load of the tile first (R items x ncols columns), then compute
-            uint32_t tg[R][kRowsPerItem][kFastCols];
-            uint64_t pv[R][kRowsPerItem][kFastCols];
+            uint32_t tg[R][kRowsPerItem][kSpecCols];
+            uint64_t pv[R][kRowsPerItem][kSpecCols];
             bool valid[R];
             spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
             process(tg, pv, valid, base);

@@ -343,6 +343,9 @@ struct DistinctArgs {
 // <= 4 columns (each loaded once per row into registers), <= 2 cheap terms combined by AND, <= 2 dictionary
 // keys addressed by perfect hash (DIRECT), <= 5 non-DISTINCT aggregates over columns.
 constexpr int kFastCols = 3, kFastTerms = 2, kFastKeys = 2, kFastAggs = 5;
+// Arithmetic nodes a plan-specialised kernel evaluates in registers (fused derived columns): column slots
+// [ncols, ncols + nderived) of the shape; kSpecCols bounds the per-row register arrays of those kernels.
+constexpr int kFastDerived = 3, kSpecCols = kFastCols + kFastDerived;
 
 struct FastTerm {
     uint32_t op;    // TERM_NUM_* / TERM_IS_* / TERM_STR_EQ
@@ -365,7 +368,8 @@ struct FastArgs {
     FastTerm terms[kFastTerms];
     FastKey keys[kFastKeys];
     uint32_t agg_col[kFastAggs];  // column slot of each aggregate's operand (unused when has_operand == 0)
-    uint32_t pad;
+    uint32_t nderived;            // fused arithmetic nodes (plan-specialised kernels only; their shape is in the SpecSig)
+    uint64_t dconst[kFastDerived][4];  // payloads of the nodes' constant operands (the tags are part of the shape)
     uint32_t* err_flags;
     unsigned long long* rows_selected;
     uint64_t* slabs;  // when non-null: workgroup b stores its LDS table at slabs[b * lds_words * S ..] instead of merging
@@ -420,13 +424,22 @@ struct SpecAgg {
     uint32_t col;
     uint32_t distinct;  // COUNT(DISTINCT col): one-word members scattered into the hash regions (WordLogArgs)
 };
+struct SpecOperand {
+    uint32_t is_const;  // 1: constant (tag below, payload in FastArgs::dconst); 0: column slot (input or earlier derived)
+    uint32_t v;         // column slot, or the constant's tag
+};
+struct SpecDerived {
+    uint32_t op, nops;  // AR_*
+    SpecOperand ops[4];
+};
 struct SpecSig {
     int ncols, nterms, nkeys, naggs;
-    int hashed, pad;  // 1: keys go through the open-addressed LDS table
+    int hashed, nderived;  // hashed 1: keys go through the open-addressed LDS table; nderived: fused arithmetic nodes
     uint32_t col_kind[kFastCols];
     SpecTerm terms[kFastTerms];
     uint32_t key_col[kFastKeys];
     SpecAgg aggs[kFastAggs];
+    SpecDerived derived[kFastDerived];
 };
 
 }  // namespace n1k

@@ -89,6 +89,30 @@ def test_runtime_specialisation_compiles_without_a_gpu():
     op.done()
 
 
+FUSED_ARITH_SHAPES = [
+    # (condition, keys, aggregates, column kinds by order of first use)
+    ("(100 < ((`d`.`x`) + (`d`.`y`)))", ["(`d`.`k`)"], ["count(*)", "sum(((`d`.`x`) * (`d`.`y`)))"], "TTD"),
+    ("(((`d`.`x`) * 2) < 51)", ["(`d`.`k`)"], ["avg(((`d`.`x`) - 10))", "max((-(`d`.`x`)))"], "TD"),
+    (None, ["(`d`.`k`)"], ["count(*)", "min(((`d`.`x`) / ((`d`.`y`) - 7)))", "sum(idiv((`d`.`y`), 4))"], "DTT"),
+    (None, ["(`d`.`k`)"], ["sum(round(((`d`.`x`) * 1.5), 2))"], "DT"),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FUSED_ARITH_SHAPES)))
+def test_fused_arithmetic_shapes_compile_without_a_gpu(case):
+    """expression/arith_*.go inside the run-time-built scan: the plan's arithmetic nodes are part of the kernel's shape
+    (evaluated in registers, no derived column); the instantiation compiles for gfx950 through hiprtc."""
+    import numpy as np
+    cond, keys, aggs, kinds = FUSED_ARITH_SHAPES[case]
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(cond, keys, sorted(aggs)))
+    assert len(op.column_paths) == len(kinds)
+    k = np.array([_ffi.COL_TAGGED64 if c == "T" else _ffi.COL_DICT32 for c in kinds], dtype=np.uint32)
+    log = C.create_string_buffer(8192)
+    st = _ffi.lib().n1k_jit_check(op._h, k.ctypes.data, len(kinds), log, 8192)
+    assert st == _ffi.OK, log.value.decode(errors="replace")
+    op.done()
+
+
 def test_order_limit_nodes_are_part_of_the_plan_contract():
     """plan/order.go:51-79, plan/limit.go:46-53: Order / Offset / Limit after the group operators are accepted when
     their terms are keys or aggregates of the plan; anything else keeps the reference operators (N1K_UNSUPPORTED)."""

@@ -317,6 +317,49 @@ def test_arithmetic_operands_as_derived_columns(case):
     pu.assert_same_groups(gpu, ora, aggs=aggs)
 
 
+# which of ARITH_CASES the run-time-built scan takes with its arithmetic in registers (<= 3 nodes over <= 3 input columns,
+# a bounded shape): the others keep their derived columns
+ARITH_FUSED = {0: True, 1: True, 2: False, 3: False, 4: False}
+
+
+@pytest.mark.parametrize("case", range(len(ARITH_CASES)))
+@pytest.mark.parametrize("resident", [False, True])
+def test_arithmetic_fused_into_the_runtime_built_scan(case, resident):
+    """expression/arith_*.go evaluated in registers by the run-time-built plan-specialised scan (no derived column in
+    HBM): same groups as the oracle and as the derived-column path, in one batch and in two (odd sizes: the narrow tail)."""
+    cond, keys, aggs = ARITH_CASES[case]
+    aggs = sorted(aggs)
+    t = n1o.synth_table(70_001, k_cat=12)
+    ora = n1o.run(t, cond, keys, aggs)
+    for batches in (1, 2):
+        gpu, st = pu.run_gpu(t, cond, keys, aggs, batches=batches, device_resident=resident, jit=2)
+        pu.assert_same_groups(gpu, ora, aggs=aggs)
+        assert (st["spec_kernel"] == 3) == ARITH_FUSED[case], st
+    unfused, st = pu.run_gpu(t, cond, keys, aggs, batches=2, device_resident=resident, jit=2, fuse_arith=0)
+    pu.assert_same_groups(unfused, ora, aggs=aggs)
+    assert st["spec_kernel"] != 3
+
+
+FUSED_EXTRA = [
+    # ROUND and IDIV nodes, a node over a node, a computed (hashed) key, string operands (NULL)
+    ("(((%s * 3) - 7) >= 100)" % D("price"), [D("cat")], ["count(*)", "sum(round((%s * 1.5), 1))" % D("price")]),
+    (None, [D("cat")], ["avg((%s / %s))" % (D("price"), D("region_id")), "countn((%s + %s))" % (D("price"), D("cat"))]),
+    ("(idiv(%s, 7) = 3)" % D("price"), [D("cat")], ["max((%s %% 5))" % D("user_id"), "min((-%s))" % D("user_id")]),
+    (None, ["(%s + 1)" % D("region_id")], ["sum((%s * %s))" % (D("price"), D("price")), "count(*)"]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FUSED_EXTRA)))
+def test_fused_arithmetic_directed_shapes(case):
+    cond, keys, aggs = FUSED_EXTRA[case]
+    aggs = sorted(aggs)
+    t = n1o.synth_table(50_003, k_cat=9)
+    ora = n1o.run(t, cond, keys, aggs)
+    gpu, st = pu.run_gpu(t, cond, keys, aggs, batches=2, jit=2)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert st["spec_kernel"] == 3, st
+
+
 def test_filter_only_selected_rows():
     t = n1o.synth_table(100_003, k_cat=10)
     for cond in ["(50 < %s)" % D("price"), "(%s is missing)" % D("price"), "(%s = \"cat_3\")" % D("cat")]:

@@ -195,3 +195,78 @@ def test_random_order_having_limit_agree_with_the_oracle(seed):
         pu.assert_ordered_groups(gpu, ora, keys, aggs, order, limit, offset)
     except AssertionError as e:
         raise AssertionError("%s | %r %r %r order %r limit %r offset %r having %r opts %r" % (e, cond, keys, aggs, order, limit, offset, having, opts))
+
+
+# ---- arithmetic evaluated in registers by the run-time-built scan (fused nodes) ---------------------------------------
+
+def rand_fused_node(rng, budget):
+    """An arithmetic expression of at most `budget` nodes over the mixed-type columns; returns (text, nodes used)."""
+    leaf = lambda: [D("a"), D("b"), D("f"), D("a"), D("b"), "3", "-2", "2.5", "0", "\"ab\""][rng.integers(0, 10)]
+    small = lambda: [D("b"), "3", "2.5", "-2"][rng.integers(0, 4)]
+    pos = lambda: [D("b"), D("f"), "3", "2.5"][rng.integers(0, 4)]
+    used = 1
+    inner = leaf()
+    if budget >= 2 and rng.random() < 0.5:
+        inner, u = rand_fused_node(rng, budget - 1)
+        used += u
+    r = rng.integers(0, 9)
+    if r == 0: return "(%s + %s)" % (inner, leaf()), used
+    if r == 1: return "(%s - %s)" % (leaf(), inner), used
+    if r == 2: return "(%s * %s)" % (small(), small()), 1       # (small products only: see rand_operand)
+    if r == 3: return "(%s / %s)" % (inner, pos()), used
+    if r == 4: return "(%s %% %s)" % (inner, pos()), used
+    if r == 5: return "idiv(%s, %s)" % (inner, pos()), used
+    if r == 6: return "(-%s)" % inner, used
+    if r == 7: return "round(%s, %s)" % (inner, ["1", "0", "-1", D("b")][rng.integers(0, 4)]), used
+    return "%s(%s)" % (["abs", "ceil", "floor", "sign", "trunc"][rng.integers(0, 5)], inner), used
+
+
+def rand_fused_plan(rng):
+    budget = 3
+    cond = None
+    if rng.random() < 0.6:
+        e, u = rand_fused_node(rng, 1 if rng.random() < 0.7 else 2)
+        budget -= u
+        cond = "(%s %s %s)" % (e, ["<", "<=", "="][rng.integers(0, 3)], ["3", "0", "2.5", "-1"][rng.integers(0, 4)])
+        if rng.random() < 0.3:
+            cond = "(%s and (%s is not null))" % (cond, D("f"))
+    keys = [[D("s")], [D("s")], [], [D("b")]][rng.integers(0, 4)]
+    if budget >= 2 and rng.random() < 0.15:
+        keys = ["(%s %% 3)" % D("b")]   # a computed key: a fused node feeding the open-addressed LDS table
+        budget -= 1
+    aggs = set()
+    while budget > 0 and len(aggs) < 3:
+        e, u = rand_fused_node(rng, min(budget, 2))
+        budget -= u
+        aggs.add("%s(%s)" % (["sum", "avg", "min", "max", "count", "countn"][rng.integers(0, 6)], e))
+    aggs.add(["count(*)", "sum(%s)" % D("b"), "max(%s)" % D("a")][rng.integers(0, 3)])
+    return cond, keys, sorted(aggs)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("N1K_FUSED_SEEDS", "24"))))
+def test_random_fused_arithmetic_agrees_with_the_oracle(seed):
+    """Bounded plan shapes with <= 3 arithmetic nodes, forced through the run-time-built scan (jit=2): the nodes are
+    evaluated in registers (stats.spec_kernel == 3) and must give what expression/arith_*.go gives row by row."""
+    rng = np.random.default_rng(77000 + seed)
+    t = make_table(rng, int(rng.integers(1, 9000)))
+    cond, keys, aggs = rand_fused_plan(rng)
+    batches = int(rng.integers(1, 3))
+    resident = bool(rng.random() < 0.5)
+    try:
+        gpu, st = pu.run_gpu(t, cond, keys, aggs, batches=batches, device_resident=resident, jit=2)
+    except query_amd.N1kError as e:
+        if e.status == _ffi.UNSUPPORTED:
+            pytest.skip("outside the device subset: " + e.message)
+        raise AssertionError("%s | plan: %r %r %r" % (e, cond, keys, aggs))
+    try:
+        ora = n1o.run(t, cond, keys, aggs, threads=2)
+    except n1o.OracleError as e:
+        pytest.skip("outside the oracle's restated subset: %s" % e)
+    try:
+        pu.assert_same_groups(gpu, ora, aggs=aggs)
+    except AssertionError as e:
+        raise AssertionError("%s | plan: %r %r %r batches %d kernel %d" % (e, cond, keys, aggs, batches, st["spec_kernel"]))
+    # the same plan with derived columns (element-wise arith_kernel per node) must agree too
+    gpu2, st2 = pu.run_gpu(t, cond, keys, aggs, batches=batches, device_resident=resident, jit=2, fuse_arith=0)
+    pu.assert_same_groups(gpu2, ora, aggs=aggs)
+    assert st2["spec_kernel"] != 3
