@@ -196,9 +196,16 @@ struct n1k_handle {
     uint64_t merged_groups_bound = 0;  // groups that may have arrived through merges (bounds the table like rows do)
 
     // staging for host batches
-    std::vector<DevBuf<uint8_t>> st_tags;
-    std::vector<DevBuf<uint64_t>> st_payload;
-    std::vector<DevBuf<uint32_t>> st_codes;
+    // Two sets, used in turn: the H2D copies of batch k + 1 run on their own stream while the kernels of batch k still read
+    // the other set; n1k_push_batch waits for its copies only (the caller's memory is free on return), never for kernels.
+    std::vector<DevBuf<uint8_t>> st_tags[2];
+    std::vector<DevBuf<uint64_t>> st_payload[2];
+    std::vector<DevBuf<uint32_t>> st_codes[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t st_free[2] = {nullptr, nullptr};  // recorded on the compute stream behind the kernels that read the set
+    bool st_busy[2] = {false, false};
+    hipEvent_t st_copied = nullptr;
+    int st_cur = 0;
 
     // filter-only path
     DevBuf<uint64_t> d_mask, d_tile_off, d_sel;
@@ -731,7 +738,8 @@ uint64_t batch_bytes_per_row(const n1k_handle* h) {
 // Can this plan run on the fast kernel (bounded shape, every descriptor static)?  Fills F when it can.
 // fuse: the plan's arithmetic nodes stay out of HBM — the kernel (a run-time-built plan-specialised one) evaluates them in
 // registers from the input columns; otherwise they are materialised derived columns and count as inputs.
-bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F, bool fuse = false) {
+// partition_only: only columns, terms and keys matter (the row exchange's partition kernels: no aggregate runs there).
+bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F, bool fuse = false, bool partition_only = false) {
     const Program& P = h->prog;
     memset(&F, 0, sizeof F);
     const uint32_t ni = (uint32_t)h->plan.paths.size(), nd = (uint32_t)h->derived.size();
@@ -746,7 +754,7 @@ bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F, bool fuse =
         F.nderived = nd;
     }
     if (h->opt_fast == 0 || P.want_rep_row || P.ncols == 0 || (!fuse && P.ncols > (uint32_t)kFastCols)) return false;
-    if (P.nkeys > (uint32_t)kFastKeys || P.naggs > (uint32_t)kFastAggs || P.naggs == 0) return false;
+    if (P.nkeys > (uint32_t)kFastKeys || (!partition_only && (P.naggs > (uint32_t)kFastAggs || P.naggs == 0))) return false;
     // predicate: none, one term, or AND of two terms
     uint32_t term_ix[2] = {0, 0};
     if (P.nlogic == 0) F.nterms = 0;
@@ -799,9 +807,9 @@ bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F, bool fuse =
         F.lds_slots = slots;
         F.lds_max_fill = std::max(1u, (uint32_t)((uint64_t)slots * 5 / 8));
     }
-    F.naggs = P.naggs;
+    F.naggs = partition_only ? 0u : P.naggs;
     uint32_t ndist = 0;
-    for (uint32_t a = 0; a < P.naggs; a++) {
+    for (uint32_t a = 0; a < F.naggs; a++) {
         const AggSpec& ag = P.aggs[a];
         if (ag.distinct) {
             // COUNT(DISTINCT column) whose members leave as one word: the specialised kernels scatter them into hash
@@ -1740,32 +1748,54 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
 // host columns -> the handle's staging buffers on the device (the caller's memory is not retained after return: cgo rule)
 n1k_status stage_host_batch(n1k_handle* h, const n1k_batch* batch, std::vector<n1k_col>& dcols) {
     uint32_t nc = batch->ncols;
-    h->st_tags.resize(std::max<size_t>(h->st_tags.size(), nc));
-    h->st_payload.resize(std::max<size_t>(h->st_payload.size(), nc));
-    h->st_codes.resize(std::max<size_t>(h->st_codes.size(), nc));
-    // the previous batch's kernels may still read the staging buffers
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int set = h->st_cur;
+    auto& s_tags = h->st_tags[set];
+    auto& s_payload = h->st_payload[set];
+    auto& s_codes = h->st_codes[set];
+    s_tags.resize(std::max<size_t>(s_tags.size(), nc));
+    s_payload.resize(std::max<size_t>(s_payload.size(), nc));
+    s_codes.resize(std::max<size_t>(s_codes.size(), nc));
+    if (!h->copy_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->st_copied, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(h, hipEventCreateWithFlags(&h->st_free[i], hipEventDisableTiming));
+    }
+    // the kernels of the batch before last may still read this set: the COPIES wait for them on the device, the host
+    // does not (a buffer that has to grow is freed by hipFree, which waits for the device itself)
+    if (h->st_busy[set]) HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->st_free[set], 0));
     dcols.assign(nc, n1k_col{});
     uint64_t n = batch->nrows;
     for (uint32_t c = 0; c < nc; c++) {
         const n1k_col& col = batch->cols[c];
         dcols[c] = col;
         if (col.kind == N1K_COL_DICT32) {
-            HIP_TRY(h, h->st_codes[c].ensure(n));
-            if (n) HIP_TRY(h, hipMemcpyAsync(h->st_codes[c].p, col.codes, n * 4, hipMemcpyHostToDevice, h->stream));
-            dcols[c].codes = h->st_codes[c].p;
+            HIP_TRY(h, s_codes[c].ensure(n));
+            if (n) HIP_TRY(h, hipMemcpyAsync(s_codes[c].p, col.codes, n * 4, hipMemcpyHostToDevice, h->copy_stream));
+            dcols[c].codes = s_codes[c].p;
         } else {
-            HIP_TRY(h, h->st_tags[c].ensure(n));
-            HIP_TRY(h, h->st_payload[c].ensure(n));
+            HIP_TRY(h, s_tags[c].ensure(n));
+            HIP_TRY(h, s_payload[c].ensure(n));
             if (n) {
-                HIP_TRY(h, hipMemcpyAsync(h->st_tags[c].p, col.tags, n, hipMemcpyHostToDevice, h->stream));
-                HIP_TRY(h, hipMemcpyAsync(h->st_payload[c].p, col.payload, n * 8, hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(s_tags[c].p, col.tags, n, hipMemcpyHostToDevice, h->copy_stream));
+                HIP_TRY(h, hipMemcpyAsync(s_payload[c].p, col.payload, n * 8, hipMemcpyHostToDevice, h->copy_stream));
             }
-            dcols[c].tags = h->st_tags[c].p;
-            dcols[c].payload = h->st_payload[c].p;
+            dcols[c].tags = s_tags[c].p;
+            dcols[c].payload = s_payload[c].p;
         }
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // the caller's memory is not retained after return (cgo rule): wait for the copies — not for the compute stream
+    HIP_TRY(h, hipEventRecord(h->st_copied, h->copy_stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->st_copied, 0));
+    HIP_TRY(h, hipEventSynchronize(h->st_copied));
+    return N1K_OK;
+}
+
+// behind the kernels of a staged batch: its set may be overwritten once this event has passed
+n1k_status staged_batch_issued(n1k_handle* h) {
+    const int set = h->st_cur;
+    HIP_TRY(h, hipEventRecord(h->st_free[set], h->stream));
+    h->st_busy[set] = true;
+    h->st_cur ^= 1;
     return N1K_OK;
 }
 
@@ -2035,9 +2065,14 @@ static void destroy_handle(n1k_handle* h) {
         h->d_cand.release();
         h->d_topk.release();
         h->d_out2.release();
-        for (auto& b : h->st_tags) b.release();
-        for (auto& b : h->st_payload) b.release();
-        for (auto& b : h->st_codes) b.release();
+        for (int i = 0; i < 2; i++) {
+            for (auto& b : h->st_tags[i]) b.release();
+            for (auto& b : h->st_payload[i]) b.release();
+            for (auto& b : h->st_codes[i]) b.release();
+            if (h->st_free[i]) (void)hipEventDestroy(h->st_free[i]);
+        }
+        if (h->st_copied) (void)hipEventDestroy(h->st_copied);
+        if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
         h->d_mask.release();
         h->d_tile_off.release();
         h->d_sel.release();
@@ -2330,7 +2365,9 @@ n1k_status n1k_push_batch(n1k_handle* h, const n1k_batch* batch) {
     if (st != N1K_OK) return st;
     n1k_batch db = *batch;
     db.cols = dcols.data();
-    return push_device(h, &db);
+    st = push_device(h, &db);
+    n1k_status st2 = staged_batch_issued(h);
+    return st != N1K_OK ? st : st2;
     });
 }
 
@@ -3156,6 +3193,12 @@ n1k_status n1k_jit_check(n1k_handle* h, const uint32_t* col_kinds, uint32_t ncol
     SpecSig sig = make_plan_sig(h, F);
     std::string l;
     bool ok = jit_compile_check(sig, &l);
+    if (ok && build_fast_args(h, 1u << 15, F, fuse, true)) {  // the same shape's partition kernels (multi-GPU row exchange)
+        SpecSig ps = make_plan_sig(h, F);
+        ps.mode = 1;
+        ps.hashed = 0;
+        ok = jit_compile_check(ps, &l);
+    }
     if (log && loglen) snprintf(log, loglen, "%s", l.c_str());
     return ok ? N1K_OK : fail(h, N1K_DEVICE_ERROR, "run-time compilation failed: %s", l.substr(0, 300).c_str());
     });
@@ -3179,6 +3222,61 @@ n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
     });
 }
 
+// Filter + hash partition of a bound batch (bind_columns(h, b, defer = true) came first): the run-time-built kernel of the
+// plan's shape when there is one (large batches, or jit = 2: n1k_spec.h scan_spec_partition_body — wide loads, arithmetic
+// in registers, survivors written in runs), else the interpreting partition_kernel over materialised derived columns.
+static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) {
+    if (b->nrows == 0) return materialize_derived(h, b);
+    const uint64_t n = b->nrows;
+    FastArgs F;
+    const JitKernel* jit = nullptr;
+    const bool fuse = !h->derived.empty() && !h->derived_ready;
+    if (h->opt_spec && h->opt_jit && (h->opt_jit == 2 || n >= h->opt_jit_min_rows) && n < (1ull << 31) && (!fuse || h->opt_fuse_arith) &&
+        sizeof(Program) + sizeof(FastArgs) + sizeof(PartArgs) + 64 <= 4096 && build_fast_args(h, 1u << 15, F, fuse, true)) {
+        // what the staging needs in LDS (n1k_spec.h PartLds: 2048 rows x (9 B per TAGGED64 column, 4 B per DICT32 column, 1))
+        size_t lds = 2048 + 2048;
+        for (uint32_t c = 0; c < F.ncols; c++) lds += 2048u * (F.cols[c].kind == COLK_DICT32 ? 4u : 9u);
+        if (lds <= 60 * 1024) {
+            SpecSig sig = make_plan_sig(h, F);
+            sig.mode = 1;
+            sig.hashed = 0;  // (no table in this mode)
+            jit = jit_get(sig);
+            if (jit->failed || !jit->part_wide) {
+                h->jit_log = jit->log;
+                jit = nullptr;
+            }
+        }
+    }
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    if (jit) {
+        bool aligned = true;
+        for (uint32_t c = 0; c < F.ncols; c++) {
+            F.cols[c] = h->prog.cols[c];
+            aligned &= ((uintptr_t)F.cols[c].tags % 2 == 0) && ((uintptr_t)F.cols[c].payload % 16 == 0) && ((uintptr_t)F.cols[c].codes % 8 == 0);
+        }
+        const bool wide = aligned && h->opt_wide && n >= 2;
+        F.nrows = (uint32_t)n;
+        F.row_base = h->row_base;
+        F.err_flags = h->d_errp;
+        const uint64_t tiles = (n + 2047) / 2048;
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 2, tiles));
+        if (e0) (void)hipEventRecord(e0, h->stream);
+        HIP_TRY(h, jit_launch_partition(jit, h->prog, F, A, grid, wide, h->stream));
+        h->stats.spec_kernel = F.nderived ? 3u : 2u;
+    } else {
+        n1k_status st = materialize_derived(h, b);
+        if (st != N1K_OK) return st;
+        const uint64_t ntiles = (n + 2047) / 2048;  // partition_kernel<4, 512>
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 4, ntiles));
+        if (e0) (void)hipEventRecord(e0, h->stream);
+        HIP_TRY(h, launch_partition(h->prog, A, grid, h->stream));
+        h->stats.spec_kernel = 0;
+    }
+    if (e1) (void)hipEventRecord(e1, h->stream);
+    h->events.emplace_back(e0, e1);
+    return N1K_OK;
+}
+
 n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uint32_t nparts, uint64_t capacity_rows,
                                       const n1k_col* out_cols, uint64_t* out_counts) {
     return guarded(h, [&]() -> n1k_status {
@@ -3195,9 +3293,8 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
         st = fix_layout(h, batch);
         if (st != N1K_OK) return st;
     }
-    Program& P = h->prog;
     PartArgs A{};
-    st = bind_columns(h, batch);
+    st = bind_columns(h, batch, true);
     if (st != N1K_OK) return st;
     A.ncopy = (uint32_t)h->plan.paths.size();  // derived columns are recomputed by the receiver
     for (uint32_t c = 0; c < A.ncopy; c++) {
@@ -3214,15 +3311,8 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
     A.counts = (unsigned long long*)out_counts;
     A.err_flags = h->d_errp;
     HIP_TRY(h, hipMemsetAsync(out_counts, 0, nparts * sizeof(uint64_t), h->stream));
-    if (batch->nrows) {
-        uint64_t ntiles = (batch->nrows + 2047) / 2048;  // partition_kernel<4, 512>
-        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 4, ntiles));
-        hipEvent_t e0 = get_event(h), e1 = get_event(h);
-        if (e0) (void)hipEventRecord(e0, h->stream);
-        HIP_TRY(h, launch_partition(P, A, grid, h->stream));
-        if (e1) (void)hipEventRecord(e1, h->stream);
-        h->events.emplace_back(e0, e1);
-    }
+    st = run_partition(h, batch, A);
+    if (st != N1K_OK) return st;
     uint32_t err_flags = 0;
     HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -3607,8 +3697,7 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
         HIP_TRY(sender, c->recv.ensure(region * P));
         // 1. Filter + hash partition on the group key values into the packed regions (headers zeroed first)
         for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * region, 0, 128, sender->stream));
-        Program& Pg = sender->prog;
-        st = bind_columns(sender, batch);
+        st = bind_columns(sender, batch, true);
         if (st != N1K_OK) return st;
         st = ensure_rank(sender);
         if (st != N1K_OK) return st;
@@ -3628,15 +3717,8 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
                 A.out_tags[i] = (uint8_t*)(c->send.p + off_b[i]);
             }
         }
-        if (batch->nrows) {
-            const uint64_t ntiles = (batch->nrows + 2047) / 2048;
-            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)sender->num_cus * 4, ntiles));
-            hipEvent_t e0 = get_event(sender), e1 = get_event(sender);
-            if (e0) (void)hipEventRecord(e0, sender->stream);
-            HIP_TRY(sender, launch_partition(Pg, A, grid, sender->stream));
-            if (e1) (void)hipEventRecord(e1, sender->stream);
-            sender->events.emplace_back(e0, e1);
-        }
+        st = run_partition(sender, batch, A);
+        if (st != N1K_OK) return st;
         sender->stats.rows_in += batch->nrows;
         sender->stats.batches += 1;
         // 2. ONE all-to-all: counts, verdicts and rows of every column travel in the same region

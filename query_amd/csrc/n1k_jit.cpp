@@ -94,8 +94,15 @@ std::string jit_source(const SpecSig& g) {
       << "    static constexpr SpecTerm terms[kFastTerms] = {" << term(0) << ", " << term(1) << "};\n"
       << "    static constexpr uint32_t key_col[kFastKeys] = {" << g.key_col[0] << "u, " << g.key_col[1] << "u};\n"
       << "    static constexpr SpecAgg aggs[kFastAggs] = {" << agg(0) << ", " << agg(1) << ", " << agg(2) << ", " << agg(3)
-      << ", " << agg(4) << "};\n};\n}  // namespace n1k\n"
-      << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_wide(const n1k::Program P, const n1k::FastArgs F,\n"
+      << ", " << agg(4) << "};\n};\n}  // namespace n1k\n";
+    if (g.mode == 1) {
+        o << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_part_wide(const n1k::Program P, const n1k::FastArgs F,\n"
+          << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 2, 512, true>(P, F, A);\n}\n"
+          << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_part_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
+          << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 4, 512, false>(P, F, A);\n}\n";
+        return o.str();
+    }
+    o << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_wide(const n1k::Program P, const n1k::FastArgs F,\n"
       << "        const n1k::GlobalTable G, unsigned long long* ngroups, const n1k::WordLogArgs L) {\n"
       << "    n1k::scan_spec_body<n1k::SpecJ, 2, 512, true>(P, F, G, ngroups, L);\n}\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
@@ -128,6 +135,15 @@ const JitKernel* jit_get(const SpecSig& sig) {
         k->failed = true;
         return k;
     }
+    if (sig.mode == 1) {
+        if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
+            hipModuleGetFunction(&k->part_wide, k->module, "n1k_jit_part_wide") != hipSuccess ||
+            hipModuleGetFunction(&k->part_narrow, k->module, "n1k_jit_part_narrow") != hipSuccess) {
+            k->failed = true;
+            k->log += "\nhipModuleLoadData / hipModuleGetFunction failed";
+        }
+        return k;
+    }
     if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
         hipModuleGetFunction(&k->wide, k->module, "n1k_jit_wide") != hipSuccess ||
         hipModuleGetFunction(&k->narrow, k->module, "n1k_jit_narrow") != hipSuccess ||
@@ -152,6 +168,12 @@ hipError_t jit_launch_records(const JitKernel* k, const Program& P, const FastAr
     hipFunction_t f = wide ? k->rec_wide : k->rec_narrow;
     void* args[] = {(void*)&P, (void*)&F, (void*)&L};
     return hipModuleLaunchKernel(f, grid, 1, 1, 512, 1, 1, shmem, st, args, nullptr);
+}
+
+hipError_t jit_launch_partition(const JitKernel* k, const Program& P, const FastArgs& F, const PartArgs& A, uint32_t grid, bool wide,
+                                hipStream_t st) {
+    void* args[] = {(void*)&P, (void*)&F, (void*)&A};
+    return hipModuleLaunchKernel(wide ? k->part_wide : k->part_narrow, grid, 1, 1, 512, 1, 1, 0, st, args, nullptr);
 }
 
 }  // namespace n1k

@@ -483,6 +483,178 @@ __global__ __launch_bounds__(BLOCK) void scan_spec_records_kernel(const Program 
     scan_spec_records_body<Spec, R, BLOCK, WIDE>(P, F, L);
 }
 
+// ---- partition mode: Filter + destination of the plan shape, the survivors' input columns leave in destination order
+//
+// The multi-GPU row exchange (n1k_exchange_rows; no reference analogue: the reference fans in through one in-memory
+// queue, execution/exchange.go:161-251).  Same contract as the interpreting partition_kernel (n1k_kernels.hip): row r of
+// destination d = hash of the group key VALUES; survivors appended to d's region, one count per region.  Here the tile's
+// survivors are ranked per destination (wave ballots, one LDS atomic per wave and destination, ONE global atomic per tile
+// and destination), staged in LDS in destination order, and every shipped column is then written in runs: consecutive
+// lanes store consecutive rows of one destination (the interpreter kernel reads every column twice and stores row by row).
+template <class Spec>
+constexpr int spec_ncols_of(uint32_t kind) {
+    int n = 0;
+    for (int c = 0; c < Spec::ncols; c++) n += Spec::col_kind[c] == kind ? 1 : 0;
+    return n;
+}
+template <class Spec>
+constexpr int spec_col_slot(int c) {  // index of column c among the columns of its kind
+    int n = 0;
+    for (int i = 0; i < c; i++) n += Spec::col_kind[i] == Spec::col_kind[c] ? 1 : 0;
+    return n;
+}
+
+template <class Spec, int TILE>
+struct PartLds {
+    uint64_t pay[spec_ncols_of<Spec>(COLK_TAGGED64) ? spec_ncols_of<Spec>(COLK_TAGGED64) : 1][TILE];
+    uint32_t code[spec_ncols_of<Spec>(COLK_DICT32) ? spec_ncols_of<Spec>(COLK_DICT32) : 1][TILE];
+    uint8_t tag[spec_ncols_of<Spec>(COLK_TAGGED64) ? spec_ncols_of<Spec>(COLK_TAGGED64) : 1][TILE];
+    uint8_t sdest[TILE];
+    uint32_t cnt[2][64];  // survivors per destination in this tile (the other copy is zeroed for the next tile)
+    uint32_t pre[64];     // first staged position of the destination
+    unsigned long long gbase[64];  // first row of the tile's run in the destination's region
+    uint32_t total;
+};
+
+template <class Spec, int R, int BLOCK, bool WIDE>
+N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const PartArgs& A) {
+    constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
+    constexpr int kNW = R * (int)kRowsPerItem;
+    constexpr int TILE = BLOCK * kNW;
+    __shared__ PartLds<Spec, TILE> S;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t i = tid; i < 128; i += BLOCK) (&S.cnt[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t par = 0, unpackable = 0;
+    const uint32_t nrows = F.nrows;
+    const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
+    const uint32_t tile = BLOCK * R;
+    const uint32_t nparts = A.nparts;
+    const uint32_t cstride = A.count_stride ? A.count_stride : 1u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kSpecCols], const uint64_t (&pv)[R][kRowsPerItem][kSpecCols],
+                       const bool (&valid)[R], uint32_t base) {
+        bool pass[kNW];
+        uint32_t dest[kNW], rk[kNW];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+#pragma unroll
+            for (int h = 0; h < (int)kRowsPerItem; h++) {
+                const int at = j * (int)kRowsPerItem + h;
+                bool ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nrows);
+#pragma unroll
+                for (int t = 0; t < Spec::nterms; t++) ok = ok && spec_term_true<Spec>(t, F, tg[j][h][Spec::terms[t].col], pv[j][h][Spec::terms[t].col]);
+                // the destination is a function of the key VALUES (the same function as partition_kernel's)
+                uint64_t key = 0;
+#pragma unroll
+                for (int k = 0; k < Spec::nkeys; k++) {
+                    uint64_t f = 0, canon = 0;
+                    if (ok && !pack_key_field(P, P.keys[k], tg[j][h][Spec::key_col[k]], pv[j][h][Spec::key_col[k]], f, canon)) {
+                        unpackable = 1;
+                        ok = false;
+                    }
+                    key = mix64(key ^ canon) + (uint64_t)k;
+                }
+                pass[at] = ok;
+                dest[at] = ok ? (uint32_t)(((key >> 32) * (uint64_t)nparts) >> 32) : 0u;
+                rk[at] = 0;
+            }
+        }
+        // ranks: per destination the wave's survivors in (item, lane) order; lane d keeps the wave's total for d
+        uint32_t mytotal = 0;
+        for (uint32_t d = 0; d < nparts; d++) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int at = 0; at < kNW; at++) {
+                const bool mine = pass[at] && dest[at] == d;
+                const unsigned long long m = __ballot(mine);
+                if (mine) rk[at] = run + (uint32_t)__popcll(m & lt_mask);
+                run += (uint32_t)__popcll(m);
+            }
+            if (lane == d) mytotal = run;
+        }
+        uint32_t mybase = 0;
+        if (mytotal) mybase = atomicAdd(&S.cnt[par][lane], mytotal);
+#pragma unroll
+        for (int at = 0; at < kNW; at++) rk[at] += (uint32_t)__shfl((int)mybase, (int)dest[at], 64);
+        lds_barrier();
+        unsigned long long gb = 0;
+        if (tid < 64) {
+            const uint32_t c = tid < nparts ? S.cnt[par][tid] : 0u;
+            if (c) gb = atomicAdd(&A.counts[(size_t)tid * cstride], (unsigned long long)c);
+            uint32_t incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off, 64);
+                if ((int)tid >= off) incl += t;
+            }
+            S.pre[tid] = incl - c;
+            S.cnt[par ^ 1u][tid] = 0;
+            if (tid == 63) S.total = incl;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+#pragma unroll
+            for (int h = 0; h < (int)kRowsPerItem; h++) {
+                const int at = j * (int)kRowsPerItem + h;
+                if (!pass[at]) continue;
+                const uint32_t q = S.pre[dest[at]] + rk[at];
+                S.sdest[q] = (uint8_t)dest[at];
+#pragma unroll
+                for (int c = 0; c < Spec::ncols; c++) {
+                    if (Spec::col_kind[c] == COLK_DICT32) S.code[spec_col_slot<Spec>(c)][q] = (uint32_t)pv[j][h][c];
+                    else {
+                        S.pay[spec_col_slot<Spec>(c)][q] = pv[j][h][c];
+                        S.tag[spec_col_slot<Spec>(c)][q] = (uint8_t)tg[j][h][c];
+                    }
+                }
+            }
+        }
+        if (tid < 64) S.gbase[tid] = gb;
+        lds_barrier();
+        const uint32_t staged = S.total;
+        for (uint32_t q = tid; q < staged; q += BLOCK) {
+            const uint32_t d = S.sdest[q];
+            const unsigned long long r = S.gbase[d] + (q - S.pre[d]);
+            if (r >= A.capacity) {
+                if (!(atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL) & ERR_TABLE_FULL) && A.region_bytes)
+                    for (uint32_t z = 0; z < nparts; z++)  // every receiver reads the verdict in the header it gets
+                        atomicOr(&A.counts[(size_t)z * A.count_stride + 1], 1ull);
+                continue;
+            }
+            const size_t shift = (size_t)d * A.region_bytes;  // (0 without packed regions)
+            const uint64_t pos = A.region_bytes ? r : (uint64_t)d * A.capacity + r;
+#pragma unroll
+            for (int c = 0; c < Spec::ncols; c++) {
+                if (Spec::col_kind[c] == COLK_DICT32) ((uint32_t*)((char*)A.out_codes[c] + shift))[pos] = S.code[spec_col_slot<Spec>(c)][q];
+                else {
+                    ((uint64_t*)((char*)A.out_payload[c] + shift))[pos] = S.pay[spec_col_slot<Spec>(c)][q];
+                    ((uint8_t*)((char*)A.out_tags[c] + shift))[pos] = S.tag[spec_col_slot<Spec>(c)][q];
+                }
+            }
+        }
+        par ^= 1u;
+        // (the next tile writes pre / gbase / total / the staging arrays only behind its first barrier, which every wave
+        //  reaches after it has left this loop)
+    };
+    uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+    uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
+    bool vA[R], vB[R];
+    const uint32_t stride = gridDim.x * tile;
+    uint32_t base = blockIdx.x * tile;
+    if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
+    while (base < nitems) {
+        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgB, pvB, vB);  // (beyond the end: no loads)
+        process(tgA, pvA, vA, base);
+        base += stride;
+        if (base >= nitems) break;
+        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgA, pvA, vA);
+        process(tgB, pvB, vB, base);
+        base += stride;
+    }
+    if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+}
+
 template <class Spec, int R, int BLOCK, bool WIDE>
 N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                             const WordLogArgs& L) {

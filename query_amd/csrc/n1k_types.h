@@ -435,6 +435,7 @@ struct SpecDerived {
 struct SpecSig {
     int ncols, nterms, nkeys, naggs;
     int hashed, nderived;  // hashed 1: keys go through the open-addressed LDS table; nderived: fused arithmetic nodes
+    int mode, pad;         // 0: scan kernels (+ records front end); 1: partition kernels of the row exchange (aggregates left out)
     uint32_t col_kind[kFastCols];
     SpecTerm terms[kFastTerms];
     uint32_t key_col[kFastKeys];

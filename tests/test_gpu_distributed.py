@@ -43,13 +43,22 @@ def _device_cols(t, paths):
     return dev, keep
 
 
-@pytest.mark.parametrize("keys", [KEYS, [D("price")], [D("cat"), D("region_id")]], ids=["dict", "float", "dict+int"])
+ARITH_COND = "(40 < (%s - %s))" % (D("price"), D("region_id"))
+
+
+@pytest.mark.parametrize("jit", [0, 2], ids=["interpreter", "runtime-built"])
+@pytest.mark.parametrize("keys", [KEYS, [D("price")], [D("cat"), D("region_id")], ["(%s %% 5)" % D("region_id"), D("cat")]],
+                         ids=["dict", "float", "dict+int", "computed+dict"])
 @pytest.mark.parametrize("nparts", [1, 3, 8])
-def test_partition_kernel_routes_every_survivor_once(nparts, keys):
+def test_partition_kernel_routes_every_survivor_once(nparts, keys, jit):
+    """Both partition kernels — the interpreting one and the plan shape's run-time-built one (tile-sorted survivors written
+    in runs, arithmetic in registers) — route every survivor exactly once, and a group key to exactly one part."""
     import torch
     n = 90_001
     t = n1o.synth_table(n, k_cat=29, zipf=True)
-    sender = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, keys, AGGS))
+    cond = ARITH_COND if "%" in keys[0] else COND  # (the computed key comes with arithmetic in the Filter)
+    sender = query_amd.GpuFilterGroup(plan.filter_group_plan(cond, keys, AGGS))
+    sender.set_option("jit", jit)
     sender.intern(list(t.dictionary))
     paths = sender.column_paths
     dev, keep = _device_cols(t, paths)
@@ -73,11 +82,12 @@ def test_partition_kernel_routes_every_survivor_once(nparts, keys):
     torch.cuda.synchronize()
     st = sender._lib.n1k_partition_device_batch(sender._h, C.byref(batch), nparts, cap, out, counts.data_ptr())
     sender._check(st)
+    assert (sender.stats()["spec_kernel"] != 0) == (jit == 2)
     cnt = counts.cpu().numpy()
-    ora_sel = n1o.run(t, COND, [], [], has_group=False).selected
+    ora_sel = n1o.run(t, cond, [], [], has_group=False).selected
     assert int(cnt.sum()) == len(ora_sel)  # every survivor exactly once
     # a group key lives in exactly one part, and the union of the parts' groups is the oracle's answer
-    ora = n1o.run(t, COND, keys, AGGS)
+    ora = n1o.run(t, cond, keys, AGGS)
     seen = {}
     merged_keys, merged_aggs = [], []
     for d in range(nparts):
@@ -162,7 +172,8 @@ def test_rank_pipeline_partials_world1_rccl(mode):
         dist.destroy_process_group()
 
 
-def test_rank_pipeline_world1_rccl():
+@pytest.mark.parametrize("jit", [0, 2], ids=["interpreter", "runtime-built"])
+def test_rank_pipeline_world1_rccl(jit):
     import torch
     import torch.distributed as dist
     from query_amd import distributed as qd
@@ -177,6 +188,7 @@ def test_rank_pipeline_world1_rccl():
         n = 120_000
         t = n1o.synth_table(n, k_cat=50)
         op = qd.ShardedFilterGroup(COND, KEYS, AGGS, t.dictionary, 0, 1, 0)
+        op.sender.set_option("jit", jit)
         dev, keep = _device_cols(t, op.send_paths)
         ora = n1o.run(t, COND, KEYS, AGGS)
         for step in range(3):  # the first step sizes the regions for the whole shard, the later ones for what arrived

@@ -340,9 +340,34 @@ def test_arithmetic_fused_into_the_runtime_built_scan(case, resident):
     assert st["spec_kernel"] != 3
 
 
+@pytest.mark.parametrize("opts", [{}, {"jit": 2}], ids=["derived-columns", "fused"])
+def test_int64_multiplication_overflow_corners(opts):
+    """intValue.Mult (value/integer.go:318-329) keeps the int64 when `x == 0 || rv / x == y`, else multiplies as floats;
+    the device decides from the high half of the 128-bit product.  Every pair of corner values, one row per group."""
+    corners = [0, 1, -1, 2, -2, 3, 7, -7, 2 ** 31, -(2 ** 31), 2 ** 32, 2 ** 32 + 1, 3037000499, 3037000500, -3037000500,
+               2 ** 62, -(2 ** 62), 2 ** 63 - 1, -(2 ** 63), -(2 ** 63) + 1, 4611686018427387904, 6148914691236517205]
+    xs = np.array([a for a in corners for _ in corners], dtype=object)
+    ys = np.array([b for _ in corners for b in corners], dtype=object)
+    n = len(xs)
+    as_u64 = lambda v: np.array([int(t) & (2 ** 64 - 1) for t in v], dtype=np.uint64)
+    ints = np.full(n, n1o.T_INT, np.uint8)
+    t = n1o.Table([n1o.Column(D("id"), n1o.COL_TAGGED64, tags=ints, payload=np.arange(n, dtype=np.uint64)),
+                   n1o.Column(D("x"), n1o.COL_TAGGED64, tags=ints, payload=as_u64(xs)),
+                   n1o.Column(D("y"), n1o.COL_TAGGED64, tags=ints, payload=as_u64(ys))], [])
+    aggs = ["max((%s * %s))" % (D("x"), D("y"))]
+    ora = n1o.run(t, None, [D("id")], aggs)
+    gpu, _ = pu.run_gpu(t, None, [D("id")], aggs, **opts)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    got = dict(zip([k[0][1] for k in gpu.keys], [a[0] for a in gpu.aggs]))
+    for i in range(n):
+        exact = int(xs[i]) * int(ys[i])
+        fits = -(2 ** 63) <= exact < 2 ** 63 or (int(xs[i]) == -1 and int(ys[i]) == -(2 ** 63))
+        assert (got[i][0] == n1o.T_INT) == fits, (int(xs[i]), int(ys[i]), got[i])
+
+
 FUSED_EXTRA = [
     # ROUND and IDIV nodes, a node over a node, a computed (hashed) key, string operands (NULL)
-    ("(((%s * 3) - 7) >= 100)" % D("price"), [D("cat")], ["count(*)", "sum(round((%s * 1.5), 1))" % D("price")]),
+    ("(100 <= ((%s * 3) - 7))" % D("price"), [D("cat")], ["count(*)", "sum(round((%s * 1.5), 1))" % D("price")]),
     (None, [D("cat")], ["avg((%s / %s))" % (D("price"), D("region_id")), "countn((%s + %s))" % (D("price"), D("cat"))]),
     ("(idiv(%s, 7) = 3)" % D("price"), [D("cat")], ["max((%s %% 5))" % D("user_id"), "min((-%s))" % D("user_id")]),
     (None, ["(%s + 1)" % D("region_id")], ["sum((%s * %s))" % (D("price"), D("price")), "count(*)"]),
