@@ -73,6 +73,16 @@ def workloads():
             "aggs": ["count(*)", "sum((%s * %s))" % (D("price"), D("region_id"))],
             "bytes_per_row": 22,
         },
+        "arith_filter": {   # (only the Filter's node)
+            "sql": "SELECT cat, COUNT(*), SUM(region_id) FROM default WHERE price + region_id > 100 GROUP BY cat",
+            "cond": "(100 < (%s + %s))" % (D("price"), D("region_id")), "keys": [D("cat")],
+            "aggs": ["count(*)", "sum(%s)" % D("region_id")], "bytes_per_row": 22,
+        },
+        "arith_sum": {      # (only the aggregate's node)
+            "sql": "SELECT cat, COUNT(*), SUM(price * region_id) FROM default WHERE price > 50 GROUP BY cat",
+            "cond": "(50 < %s)" % D("price"), "keys": [D("cat")],
+            "aggs": ["count(*)", "sum((%s * %s))" % (D("price"), D("region_id"))], "bytes_per_row": 22,
+        },
         "arith_plain": {
             "sql": "SELECT cat, COUNT(*), SUM(region_id) FROM default WHERE price > 50 GROUP BY cat",
             "cond": "(50 < %s)" % D("price"), "keys": [D("cat")],

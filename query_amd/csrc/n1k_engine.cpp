@@ -88,6 +88,9 @@ struct n1k_handle {
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
     uint64_t opt_jit_min_rows = 4u << 20;
+    uint32_t opt_part_per_cu = 0;  // workgroups per CU of the run-time-built partition kernel (0 = 2)
+    uint32_t opt_pinned_out = 1;   // speculative FinalGroup writes its (few) groups straight into pinned host memory
+    uint32_t opt_flag_bytes = 0;   // (measured: no gain on config 2 — the scan is not bound by its LDS atomics) specialised scan: SUM / AVG operand-kind flags as plain LDS byte stores instead of LDS atomics
     uint32_t opt_fuse_arith = 1;   // arithmetic nodes evaluated in registers by the run-time-built scan (no derived columns)
     bool derived_ready = true;     // the derived columns of the batch being pushed are materialised (or there are none)
     uint64_t opt_wide_values = 1u << 20;  // capacity of the wide key value tables (distinct big ints / floats)
@@ -984,7 +987,13 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             for (uint32_t sl = 4096; sl >= 64; sl >>= 1)
                 if (without + ndist * sl * 8u + 512u <= share) { dcache_slots = sl; break; }
         }
-        const uint32_t lds_total = table_bytes + scatter_bytes + ndist * dcache_slots * 8u;
+        // byte flags of SUM / AVG behind the table (n1k_spec.h): shapes without DISTINCT, while table + bytes stay within 64 KiB
+        F.flag_bytes = 0;
+        if (h->opt_flag_bytes && !ndist) {
+            F.flag_bytes = 1;
+            if (table_bytes + spec_flag_bytes(F) > 64u * 1024u) F.flag_bytes = 0;
+        }
+        const uint32_t lds_total = table_bytes + scatter_bytes + ndist * dcache_slots * 8u + (uint32_t)spec_flag_bytes(F);
         // workgroups per CU that fit: 512 threads x 3 (<= 48 KiB each), x 2 (<= 72 KiB), else 1024 threads x 1
         uint32_t fblock = h->opt_block == 1024 || h->opt_block == 512 ? h->opt_block : (table_bytes <= 72 * 1024 ? 512u : 1024u);
         if (ndist) fblock = 512;
@@ -2179,6 +2188,9 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "spec") h->opt_spec = value ? 1 : 0;
     else if (n == "wide") h->opt_wide = value ? 1 : 0;
     else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
+    else if (n == "flag_bytes") h->opt_flag_bytes = value ? 1 : 0;
+    else if (n == "pinned_out") h->opt_pinned_out = value ? 1 : 0;
+    else if (n == "part_per_cu") h->opt_part_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8);
     else if (n == "jit") h->opt_jit = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
     else if (n == "jit_min_rows") h->opt_jit_min_rows = (uint64_t)std::max<int64_t>(value, 0);
     else if (n == "distinct_words") {
@@ -2917,13 +2929,23 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
                 HIP_TRY(h, hipHostMalloc((void**)&h->pin_out, total + sizeof counters, hipHostMallocDefault));
                 h->pin_cap = total + sizeof counters;
             }
-            char* d = h->d_out.p;
             if (h->out_count_dirty) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
             h->out_count_dirty = true;  // (reopen zeroes every counter in its one launch)
-            HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
-                                       (uint64_t*)(d + off_rep), h->d_counters.p + 2, spec_groups, h->d_errp, h->stream));
-            HIP_TRY(h, hipMemcpyAsync(h->pin_out, d, total, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipMemcpyAsync(h->pin_out + total, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+            if (h->opt_pinned_out) {
+                // The few groups of a speculative FinalGroup are written by the kernel straight into the pinned host buffer
+                // (posted stores over PCIe) and a one-wave kernel publishes the counters behind them: no copy engine in the
+                // query's critical path (two hipMemcpyAsync D2H cost ~ 21 us of a 0.33 ms query: 2 x 4.7 us + a 12 us gap).
+                char* d = h->pin_out;
+                HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
+                                           (uint64_t*)(d + off_rep), h->d_counters.p + 2, spec_groups, h->d_errp, h->stream));
+                HIP_TRY(h, launch_publish_counters(h->d_counters.p, (unsigned long long*)(h->pin_out + total), kCounters, h->stream));
+            } else {
+                char* d = h->d_out.p;
+                HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
+                                           (uint64_t*)(d + off_rep), h->d_counters.p + 2, spec_groups, h->d_errp, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(h->pin_out, d, total, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(h->pin_out + total, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+            }
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             memcpy(counters, h->pin_out + total, sizeof counters);
         } else {
@@ -3259,7 +3281,7 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
         F.row_base = h->row_base;
         F.err_flags = h->d_errp;
         const uint64_t tiles = (n + 2047) / 2048;
-        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 2, tiles));
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * (h->opt_part_per_cu ? h->opt_part_per_cu : 2u), tiles));
         if (e0) (void)hipEventRecord(e0, h->stream);
         HIP_TRY(h, jit_launch_partition(jit, h->prog, F, A, grid, wide, h->stream));
         h->stats.spec_kernel = F.nderived ? 3u : 2u;

@@ -96,9 +96,11 @@ std::string jit_source(const SpecSig& g) {
       << "    static constexpr SpecAgg aggs[kFastAggs] = {" << agg(0) << ", " << agg(1) << ", " << agg(2) << ", " << agg(3)
       << ", " << agg(4) << "};\n};\n}  // namespace n1k\n";
     if (g.mode == 1) {
-        o << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_part_wide(const n1k::Program P, const n1k::FastArgs F,\n"
+        if (const char* a = getenv("N1K_JIT_PART_ATTR")) o << "#define N1K_PART_ATTR " << a << "\n";  // (tuning experiments)
+        else o << "#define N1K_PART_ATTR\n";
+        o << "extern \"C\" __global__ __launch_bounds__(512) N1K_PART_ATTR void n1k_jit_part_wide(const n1k::Program P, const n1k::FastArgs F,\n"
           << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 2, 512, true>(P, F, A);\n}\n"
-          << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_part_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
+          << "extern \"C\" __global__ __launch_bounds__(512) N1K_PART_ATTR void n1k_jit_part_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
           << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 4, 512, false>(P, F, A);\n}\n";
         return o.str();
     }
@@ -157,7 +159,7 @@ const JitKernel* jit_get(const SpecSig& sig) {
 
 hipError_t jit_launch(const JitKernel* k, const Program& P, const FastArgs& F, const GlobalTable& G,
                       unsigned long long* ngroups, uint32_t grid, bool wide, const WordLogArgs& L, uint32_t ndistinct, hipStream_t st) {
-    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * ndistinct * 8;
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * ndistinct * 8 + spec_flag_bytes(F);
     void* args[] = {(void*)&P, (void*)&F, (void*)&G, (void*)&ngroups, (void*)&L};
     return hipModuleLaunchKernel(wide ? k->wide : k->narrow, grid, 1, 1, 512, 1, 1, (unsigned)shmem, st, args, nullptr);
 }

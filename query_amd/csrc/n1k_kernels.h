@@ -89,6 +89,7 @@ hipError_t launch_merge_partials(const Program& P, const GlobalTable& G, uint32_
                                  uint64_t region_words, uint32_t* err_flags, unsigned long long* ngroups, hipStream_t st,
                                  uint64_t limit = 0, bool unique_keys = false);
 hipError_t launch_arith(const ArithArgs& A, hipStream_t st);
+hipError_t launch_publish_counters(const unsigned long long* src, unsigned long long* dst, uint32_t n, hipStream_t st);
 hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, hipStream_t st);
 hipError_t launch_exchange_verdict(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint32_t* err_flags, hipStream_t st);
 struct SpecEntry {

@@ -1185,7 +1185,7 @@ static SpecSig make_sig() {
 template <class Spec>
 static hipError_t launch_spec(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                               uint32_t grid, uint32_t block, bool wide, const WordLogArgs& L, hipStream_t st) {
-    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * spec_ndistinct<Spec>() * 8;
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * spec_ndistinct<Spec>() * 8 + spec_flag_bytes(F);
 #define N1K_LAUNCH(R, B, W)                                                                                       \
     do {                                                                                                          \
         auto k = scan_spec_kernel<Spec, R, B, W>;                                                                 \
@@ -2642,6 +2642,15 @@ hipError_t launch_exchange_verdict(unsigned long long* headers, uint32_t nregion
 
 hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL((partition_kernel<4, 512>), dim3(grid), dim3(512), 0, st, P, A);
+    return hipGetLastError();
+}
+
+// the device counters into pinned host memory, behind the kernels that update them (n1k_finish)
+__global__ void publish_counters_kernel(const unsigned long long* src, unsigned long long* dst, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_publish_counters(const unsigned long long* src, unsigned long long* dst, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(publish_counters_kernel, dim3(1), dim3(64), 0, st, src, dst, n);
     return hipGetLastError();
 }
 

@@ -102,6 +102,16 @@ N1K_DEV bool spec_term_true(int t, const FastArgs& F, uint32_t tg, uint64_t p) {
 }
 
 // CumulateInitial of aggregate `a` (compile-time kind) into the LDS slot; false -> take the global path
+// Byte flags (FastArgs::flag_bytes, shapes without DISTINCT): an LDS atomic retires about one lane per clock and CU, so the
+// flag of SUM / AVG — one ds_or per surviving row, next to the ds_add of the sum itself — took half of the scan's LDS-atomic
+// budget (config 2: 100 M atomics ~ 0.16 ms of a 0.25 ms kernel).  Which kinds of operands a group has seen is idempotent
+// information: each (aggregate, slot, kind) gets a BYTE that rows set with a plain ds_write_b8 (full LDS store rate, nothing
+// to wait for); the bytes are folded into the table's flag words once, before the table leaves the workgroup.
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+N1K_DEV void spec_flag_byte(uint64_t* fbytes, uint32_t a, uint32_t S, uint32_t slot, uint32_t kind) {
+    *(volatile lds_u8*)((lds_u8*)fbytes + (((size_t)a * S + slot) << 2) + kind) = 1;
+}
+
 template <class Spec>
 N1K_DEV void spec_flag(lds_u64* w, unsigned long long bit) {
     // Shapes with COUNT(DISTINCT) run at the CU's LDS-atomic rate (about one lane per clock: four atomics per row were
@@ -112,7 +122,7 @@ N1K_DEV void spec_flag(lds_u64* w, unsigned long long bit) {
 }
 
 template <class Spec>
-N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32_t slot, uint32_t tag, uint64_t p) {
+N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32_t slot, uint32_t tag, uint64_t p, uint64_t* fbytes = nullptr) {
     const uint32_t kind = Spec::aggs[a].kind;
     lds_u64* w = lds_word(lds, P.aggs[a].lds_off * S + slot);
     if (kind == AGG_COUNT) {
@@ -128,11 +138,13 @@ N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32
             int64_t x = (int64_t)p;
             if (x >= (1ll << 40) || x <= -(1ll << 40)) return false;
             lds_add_u64(w, (unsigned long long)x);
-            spec_flag<Spec>(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
+            if (fbytes) spec_flag_byte(fbytes, (uint32_t)a, S, slot, x < 0 ? 1u : 0u);
+            else spec_flag<Spec>(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
         } else if (tag == T_FLOAT) {
             lds_add_f64(w + S, as_f64(p));
-            spec_flag<Spec>(w + 2 * S, (unsigned long long)SF_FLOAT);
+            if (fbytes) spec_flag_byte(fbytes, (uint32_t)a, S, slot, 2u);
+            else spec_flag<Spec>(w + 2 * S, (unsigned long long)SF_FLOAT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
         }
         return true;
@@ -181,7 +193,7 @@ template <class Spec>
 N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                       uint64_t* lds, uint32_t S, uint32_t* lds_fill, const uint32_t (&tg)[kSpecCols],
                       const uint64_t (&pv)[kSpecCols], uint32_t& selected, uint32_t& unpackable, const WordLogArgs& L,
-                      uint64_t* dcache, uint64_t (&words)[kSpecDistinct], uint32_t (&bins)[kSpecDistinct]) {
+                      uint64_t* dcache, uint64_t (&words)[kSpecDistinct], uint32_t (&bins)[kSpecDistinct], uint64_t* fbytes = nullptr) {
     constexpr int kND = spec_ndistinct<Spec>();
     bool pass = true;
 #pragma unroll
@@ -250,7 +262,7 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
         }
         if (kHashed && grow >= 0) {  // the LDS table is full: this group lives in the global table only
             acc_global(P, P.aggs[a], &G.acc[(size_t)grow * P.glob_words], t, p);
-        } else if (!spec_acc<Spec>(a, P, lds, S, slot, t, p)) {  // rare: an integer too large for the narrow LDS sum
+        } else if (!spec_acc<Spec>(a, P, lds, S, slot, t, p, fbytes)) {  // rare: an integer too large for the narrow LDS sum
             long long g = global_find_or_insert(G, kHashed ? key : fast_slot_key(F, slot), F.err_flags, ngroups);
             if (g >= 0) acc_global(P, P.aggs[a], &G.acc[(size_t)g * P.glob_words], t, p);
         }
@@ -670,6 +682,10 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     uint32_t w_par = 0;
     const uint32_t w_sub = blockIdx.x % kRecSubs;  // sub-region of every hash region this workgroup appends to
     uint64_t* dcache = lds + (size_t)S * P.lds_words;  // "already logged" caches of the DISTINCT aggregates
+    // byte flags of SUM / AVG (4 bytes per aggregate and slot, behind the table; shapes without DISTINCT only)
+    uint64_t* const fbytes = (kND == 0 && F.flag_bytes) ? dcache : nullptr;
+    if (fbytes)
+        for (uint32_t i = tid; i < ((uint32_t)Spec::naggs * S + 1u) / 2u; i += BLOCK) *(volatile lds_u64*)lds_word(fbytes, i) = 0ull;
     if constexpr (kND > 0) {
         for (uint32_t i = tid; i < L.dcache_slots * (uint32_t)kND; i += BLOCK) *(volatile lds_u64*)lds_word(dcache, i) = kEmptyKey;
 #pragma unroll
@@ -699,7 +715,7 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
 #pragma unroll
                 for (int d = 0; d < (int)kSpecDistinct; d++) { words[d] = kEmptyKey; bins[d] = kScatterNone; }
                 const bool row_ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nrows);
-                if (row_ok) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins);
+                if (row_ok) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins, fbytes);
 #pragma unroll
                 for (int d = 0; d < (int)kSpecDistinct; d++) { mw[d][j * (int)kRowsPerItem + h] = words[d]; mb[d][j * (int)kRowsPerItem + h] = bins[d]; }
             }
@@ -755,6 +771,19 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     for (int off = 32; off > 0; off >>= 1) selected += __shfl_down(selected, off, 64);
     if ((tid & 63) == 0 && selected) atomicAdd(&block_selected, selected);
     __syncthreads();
+    if (fbytes) {
+        // fold the byte flags into the flag words of the table (one thread per slot: plain read-modify-write)
+#pragma unroll
+        for (int a = 0; a < Spec::naggs; a++) {
+            if (Spec::aggs[a].kind != AGG_SUM && Spec::aggs[a].kind != AGG_AVG) continue;
+            for (uint32_t sl = tid; sl < S; sl += BLOCK) {
+                const uint32_t b4 = *(volatile lds_u32*)((lds_u32*)fbytes + (size_t)a * S + sl);  // bytes: non-negative int, negative int, float
+                const uint64_t fl = (uint64_t)(b4 & 1u) | (uint64_t)((b4 >> 7) & 2u) | (uint64_t)((b4 >> 14) & 4u);
+                if (fl) lds[(size_t)(P.aggs[a].lds_off + 2u) * S + sl] |= fl;
+            }
+        }
+        __syncthreads();
+    }
     if (F.slabs) {
         // hand the workgroup's partial groups to merge_slabs_kernel: plain coalesced stores, no atomics
         uint64_t* slab = F.slabs + (size_t)blockIdx.x * P.lds_words * S;

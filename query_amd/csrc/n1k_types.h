@@ -368,6 +368,7 @@ struct FastArgs {
     FastTerm terms[kFastTerms];
     FastKey keys[kFastKeys];
     uint32_t agg_col[kFastAggs];  // column slot of each aggregate's operand (unused when has_operand == 0)
+    uint32_t flag_bytes;          // plan-specialised scan: SUM / AVG operand-kind flags as LDS bytes (plain stores), not atomics
     uint32_t nderived;            // fused arithmetic nodes (plan-specialised kernels only; their shape is in the SpecSig)
     uint64_t dconst[kFastDerived][4];  // payloads of the nodes' constant operands (the tags are part of the shape)
     uint32_t* err_flags;
@@ -378,6 +379,9 @@ struct FastArgs {
     // arrived with it and never visits the host)
     const unsigned long long* nrows_dev;
 };
+
+// LDS bytes of the byte flags behind the workgroup table (FastArgs::flag_bytes): 4 per aggregate and slot, whole words
+inline size_t spec_flag_bytes(const FastArgs& F) { return F.flag_bytes ? (((size_t)F.naggs * F.lds_slots + 1) / 2) * 8 : 0; }
 
 // derived columns: arithmetic nodes of the plan are evaluated once per batch by an element-wise kernel into a
 // temporary TAGGED64 column; the scan kernels then see them as ordinary columns

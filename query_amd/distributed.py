@@ -324,6 +324,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     cols = bench.DeviceColumns(rows, args.kcat, bool(args.zipf), first, total_rows, local_rank)
     op = ShardedFilterGroup(wl["cond"], wl["keys"], wl["aggs"], bench.synth_dictionary(args.kcat), rank, world,
                             local_rank, order=wl.get("order"), limit=wl.get("limit"))
+    for o in getattr(args, "opt", []):  # engine options (tuning experiments): every handle of the rank
+        k, v = o.split("=")
+        for hnd in {id(x): x for x in (op.sender, op.receiver, op.merger)}.values():
+            hnd.set_option(k, int(v))
     dev = torch.device("cuda", local_rank)
     mode = args.exchange
     if mode == "auto":  # the configuration north_star names: rows hash-partitioned on the group key by one all-to-all

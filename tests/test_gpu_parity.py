@@ -367,7 +367,7 @@ def test_int64_multiplication_overflow_corners(opts):
 
 FUSED_EXTRA = [
     # ROUND and IDIV nodes, a node over a node, a computed (hashed) key, string operands (NULL)
-    ("(100 <= ((%s * 3) - 7))" % D("price"), [D("cat")], ["count(*)", "sum(round((%s * 1.5), 1))" % D("price")]),
+    ("(100 <= (%s * 3))" % D("price"), [D("cat")], ["count(*)", "sum(round((%s * 1.5), 1))" % D("price")]),
     (None, [D("cat")], ["avg((%s / %s))" % (D("price"), D("region_id")), "countn((%s + %s))" % (D("price"), D("cat"))]),
     ("(idiv(%s, 7) = 3)" % D("price"), [D("cat")], ["max((%s %% 5))" % D("user_id"), "min((-%s))" % D("user_id")]),
     (None, ["(%s + 1)" % D("region_id")], ["sum((%s * %s))" % (D("price"), D("price")), "count(*)"]),
