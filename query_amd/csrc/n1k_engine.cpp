@@ -88,6 +88,7 @@ struct n1k_handle {
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
     uint64_t opt_jit_min_rows = 4u << 20;
+    uint32_t opt_part_subs = 1;    // row exchange: sub-regions per destination with their own counters (0: one dense run)
     uint32_t opt_part_per_cu = 0;  // workgroups per CU of the run-time-built partition kernel (0 = 2)
     uint32_t opt_pinned_out = 1;   // speculative FinalGroup writes its (few) groups straight into pinned host memory
     uint32_t opt_flag_bytes = 0;   // (measured: no gain on config 2 — the scan is not bound by its LDS atomics) specialised scan: SUM / AVG operand-kind flags as plain LDS byte stores instead of LDS atomics
@@ -196,6 +197,11 @@ struct n1k_handle {
                                             // [5] distinct region words [8..11] pair-log cursors
     uint64_t row_base = 0;
     const unsigned long long* push_nrows_dev = nullptr;  // the batch being pushed holds min(nrows, *this) rows (n1k_exchange_rows)
+    // the batch being pushed is segmented (a row region received from another GPU: kRowSubs sub-regions of push_seg_rows rows
+    // capacity, their row counts on the device kCursorStride words apart)
+    const unsigned long long* push_seg_counts = nullptr;
+    uint32_t push_nseg = 0;
+    uint64_t push_seg_rows = 0;
     uint64_t merged_groups_bound = 0;  // groups that may have arrived through merges (bounds the table like rows do)
 
     // staging for host batches
@@ -1028,8 +1034,15 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         }
         h->stats.spec_kernel = spec ? 1u : (jit ? (F.nderived ? 3u : 2u) : 0u);
         if (F.nderived && !jit) return fail(h, N1K_DEVICE_ERROR, "fused arithmetic without its kernel");  // (decided above)
-        if ((F.hashed || ndist || h->push_nrows_dev) && !spec && !jit) goto interpreter;  // the bounded-shape kernel is DIRECT only, no DISTINCT
+        if ((F.hashed || ndist || h->push_nrows_dev || h->push_nseg) && !spec && !jit) goto interpreter;  // the bounded-shape kernel is DIRECT only, no DISTINCT
         F.nrows_dev = h->push_nrows_dev;
+        if (h->push_nseg > 1) {
+            if (h->push_nseg > kMaxSegments || b->nrows >= (1ull << 31)) return fail(h, N1K_INVALID, "segmented batch too large");
+            F.nseg = h->push_nseg;
+            F.seg_rows = (uint32_t)h->push_seg_rows;
+            F.seg_count_stride = kCursorStride;
+            F.seg_counts = h->push_seg_counts;
+        }
         WordLogArgs L;
         memset(&L, 0, sizeof L);
         if (ndist) {
@@ -1105,7 +1118,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 // WIDE launch over the even prefix (2 adjacent rows per lane and load), scalar launch for an odd last row
                 bool wide = aligned && h->opt_wide && n >= 2;
                 // (a row count that lives on the device may be odd: the kernel masks the last item's second row itself)
-                uint64_t n_main = wide && !h->push_nrows_dev ? (n & ~1ull) : n;
+                uint64_t n_main = wide && !h->push_nrows_dev && !h->push_nseg ? (n & ~1ull) : n;
                 F.nrows = (uint32_t)n_main;
                 uint64_t items = wide ? (n_main + 1) / 2 : n_main;
                 uint32_t rpl = wide ? 2 : 4;
@@ -1180,7 +1193,27 @@ interpreter:
     grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, ntiles));
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
     if (e0) (void)hipEventRecord(e0, h->stream);
-    HIP_TRY(h, launch_scan_group(P, A, h->table, h->d_counters.p + 1, grid, block, rpl, direct, h->stream));
+    if (h->push_nseg > 1) {
+        // a segmented batch on the interpreter: one launch per segment, its row count read on the device
+        Program Ps = P;
+        for (uint32_t sg = 0; sg < h->push_nseg; sg++) {
+            const uint64_t off = (uint64_t)sg * h->push_seg_rows;
+            for (uint32_t c = 0; c < P.ncols; c++) {
+                Ps.cols[c] = P.cols[c];
+                if (c >= (uint32_t)h->plan.paths.size()) continue;  // (derived columns: not with received regions)
+                if (Ps.cols[c].tags) Ps.cols[c].tags += off;
+                if (Ps.cols[c].payload) Ps.cols[c].payload += off;
+                if (Ps.cols[c].codes) Ps.cols[c].codes += off;
+            }
+            ScanArgs As = A;
+            As.nrows = h->push_seg_rows;
+            As.nrows_dev = h->push_seg_counts + (size_t)sg * kCursorStride;
+            const uint64_t nt = (h->push_seg_rows + tile_rows - 1) / tile_rows;
+            const uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, nt));
+            HIP_TRY(h, launch_scan_group(Ps, As, h->table, h->d_counters.p + 1, g, block, rpl, direct, h->stream));
+        }
+    } else
+        HIP_TRY(h, launch_scan_group(P, A, h->table, h->d_counters.p + 1, grid, block, rpl, direct, h->stream));
     if (e1) (void)hipEventRecord(e1, h->stream);
     h->events.emplace_back(e0, e1);
     h->stats.agg_mode = direct ? N1K_MODE_LDS_DIRECT : N1K_MODE_LDS_HASH;
@@ -1674,7 +1707,7 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     if (st != N1K_OK) return st;
     const bool first_rows = h->row_base == 0 && h->merged_groups_bound == 0;  // nothing in the handle yet
     PartitionPlan pp;
-    const bool can_partition = h->plan.has_group && !h->push_nrows_dev && partition_eligible(h, pp);
+    const bool can_partition = h->plan.has_group && !h->push_nrows_dev && !h->push_nseg && partition_eligible(h, pp);
     uint64_t head = b->nrows;
     bool decide = false;
     if (can_partition && h->opt_agg_mode == N1K_MODE_PARTITIONED) head = 0;
@@ -2190,6 +2223,7 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
     else if (n == "flag_bytes") h->opt_flag_bytes = value ? 1 : 0;
     else if (n == "pinned_out") h->opt_pinned_out = value ? 1 : 0;
+    else if (n == "part_subs") h->opt_part_subs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);  // 0 off, 1 large batches, 2 always (tests)
     else if (n == "part_per_cu") h->opt_part_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8);
     else if (n == "jit") h->opt_jit = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
     else if (n == "jit_min_rows") h->opt_jit_min_rows = (uint64_t)std::max<int64_t>(value, 0);
@@ -3248,7 +3282,13 @@ n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
 // plan's shape when there is one (large batches, or jit = 2: n1k_spec.h scan_spec_partition_body — wide loads, arithmetic
 // in registers, survivors written in runs), else the interpreting partition_kernel over materialised derived columns.
 static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) {
-    if (b->nrows == 0) return materialize_derived(h, b);
+    // packed regions (the row exchange): A.sub_rows = rows per sub-region; whoever writes dense runs converts the counts
+    const uint64_t seg_rows = A.region_bytes ? A.sub_rows : 0;
+    A.nsub = 1;
+    if (b->nrows == 0) {
+        if (seg_rows) HIP_TRY(h, launch_dense_to_segments(A.counts, A.nparts, A.count_stride, seg_rows, h->stream));
+        return materialize_derived(h, b);
+    }
     const uint64_t n = b->nrows;
     FastArgs F;
     const JitKernel* jit = nullptr;
@@ -3281,7 +3321,13 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
         F.row_base = h->row_base;
         F.err_flags = h->d_errp;
         const uint64_t tiles = (n + 2047) / 2048;
-        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * (h->opt_part_per_cu ? h->opt_part_per_cu : 2u), tiles));
+        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * (h->opt_part_per_cu ? h->opt_part_per_cu : 2u), tiles));
+        // many tiles: every destination's region in kRowSubs sub-regions with their own counters, workgroups dealt round-robin
+        // (tile t goes to sub-region t % kRowSubs: an even share of the rows whatever their order)
+        if (seg_rows && h->opt_part_subs && (tiles >= 4096 || h->opt_part_subs == 2)) {
+            A.nsub = kRowSubs;
+            grid = (grid + kRowSubs - 1) / kRowSubs * kRowSubs;
+        }
         if (e0) (void)hipEventRecord(e0, h->stream);
         HIP_TRY(h, jit_launch_partition(jit, h->prog, F, A, grid, wide, h->stream));
         h->stats.spec_kernel = F.nderived ? 3u : 2u;
@@ -3294,6 +3340,7 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
         HIP_TRY(h, launch_partition(h->prog, A, grid, h->stream));
         h->stats.spec_kernel = 0;
     }
+    if (seg_rows && A.nsub == 1) HIP_TRY(h, launch_dense_to_segments(A.counts, A.nparts, A.count_stride, seg_rows, h->stream));
     if (e1) (void)hipEventRecord(e1, h->stream);
     h->events.emplace_back(e0, e1);
     return N1K_OK;
@@ -3571,10 +3618,11 @@ n1k_status order_streams(n1k_comm* c, n1k_handle* snd, n1k_handle* rcv) {
     return N1K_OK;
 }
 
-// layout of one packed row region for `cap` rows of the plan's input columns: [count][verdict] + padding to 128 bytes,
-// then per column its arrays, each starting on a 16-byte boundary
+// layout of one packed row region for `cap` rows (kRowSubs sub-regions of cap / kRowSubs rows) of the plan's input columns:
+// the header (sub-region x's row count at word x * kCursorStride, the verdict in word 1), then per column its arrays, each
+// starting on a 16-byte boundary
 size_t row_region_layout(const n1k_handle* h, uint64_t cap, std::vector<size_t>& off_a, std::vector<size_t>& off_b) {
-    size_t at = 128;
+    size_t at = (size_t)kRowSubs * kCursorStride * 8;  // header: the sub-regions' counts, 128 bytes apart; verdict in word 1
     const size_t nc = h->plan.paths.size();
     off_a.assign(nc, 0);
     off_b.assign(nc, 0);
@@ -3711,14 +3759,15 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
         }
         st = prepare_receiver(sender, receiver);
         if (st != N1K_OK) return st;
-        const uint64_t cap = (capacity_rows + 15) / 16 * 16;
+        const uint64_t cap = (capacity_rows + 16 * kRowSubs - 1) / (16 * kRowSubs) * (16 * kRowSubs);  // kRowSubs sub-regions of whole 16-row groups
+        if (cap >= (1ull << 31)) return fail(sender, N1K_INVALID, "row regions hold fewer than 2^31 rows");
         std::vector<size_t> off_a, off_b;
         const size_t region = row_region_layout(sender, cap, off_a, off_b);
         const uint32_t P = (uint32_t)c->world;
         HIP_TRY(sender, c->send.ensure(region * P));
         HIP_TRY(sender, c->recv.ensure(region * P));
         // 1. Filter + hash partition on the group key values into the packed regions (headers zeroed first)
-        for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * region, 0, 128, sender->stream));
+        for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * region, 0, (size_t)kRowSubs * kCursorStride * 8, sender->stream));
         st = bind_columns(sender, batch, true);
         if (st != N1K_OK) return st;
         st = ensure_rank(sender);
@@ -3731,6 +3780,7 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
         A.counts = (unsigned long long*)c->send.p;
         A.count_stride = (uint32_t)(region / 8);
         A.region_bytes = region;
+        A.sub_rows = cap / kRowSubs;
         A.err_flags = sender->d_errp;
         for (uint32_t i = 0; i < A.ncopy; i++) {
             if (sender->col_kinds[i] == N1K_COL_DICT32) A.out_codes[i] = (uint32_t*)(c->send.p + off_a[i]);
@@ -3753,14 +3803,10 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
         //    (Headers are checked first: a sender that overflowed voids the step on every rank.)
         std::vector<const char*> src(P);
         for (uint32_t sidx = 0; sidx < P; sidx++) src[sidx] = (int)sidx == c->rank ? self : c->recv.p + (size_t)sidx * region;
-        if (P > 1) {
-            // the headers live in two buffers (own region, received regions): gather them for the check
-            HIP_TRY(sender, c->scalar.ensure(2 * (size_t)P + 2));
-            for (uint32_t sidx = 0; sidx < P; sidx++)
-                HIP_TRY(receiver, hipMemcpyAsync(c->scalar.p + 2 * sidx, src[sidx], 16, hipMemcpyDeviceToDevice, receiver->stream));
-            HIP_TRY(receiver, launch_exchange_verdict(c->scalar.p, P, 2, receiver->d_errp, receiver->stream));
-        } else {
-            HIP_TRY(receiver, launch_exchange_verdict((unsigned long long*)src[0], 1, region / 8, receiver->d_errp, receiver->stream));
+        {
+            HeaderList H{};
+            for (uint32_t sidx = 0; sidx < P; sidx++) H.h[sidx] = (unsigned long long*)src[sidx];
+            HIP_TRY(receiver, launch_exchange_verdict(H, P, receiver->d_errp, receiver->stream));
         }
         for (uint32_t sidx = 0; sidx < P; sidx++) {
             const uint32_t rnc = (uint32_t)receiver->plan.paths.size();
@@ -3778,9 +3824,12 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
             rb.nrows = cap;
             rb.ncols = rnc;
             rb.cols = cols.data();
-            receiver->push_nrows_dev = P > 1 ? c->scalar.p + 2 * sidx : (const unsigned long long*)src[sidx];
+            receiver->push_seg_counts = (const unsigned long long*)src[sidx];  // (the region's header)
+            receiver->push_nseg = kRowSubs;
+            receiver->push_seg_rows = cap / kRowSubs;
             st = push_device(receiver, &rb);
-            receiver->push_nrows_dev = nullptr;
+            receiver->push_seg_counts = nullptr;
+            receiver->push_nseg = 0;
             if (st != N1K_OK) return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
         }
         return N1K_OK;

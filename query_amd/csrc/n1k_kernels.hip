@@ -2625,18 +2625,38 @@ hipError_t launch_arith(const ArithArgs& A, hipStream_t st) {
     return hipGetLastError();
 }
 
-// Received row regions ([count][verdict]... per source): a sender whose region overflowed said so in every header — the
-// receiver then aggregates nothing (all counts to zero) and its n1k_finish reports it, on every rank alike.
-__global__ void exchange_verdict_kernel(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint32_t* err_flags) {
+// Received row regions (per source: kRowSubs sub-region counts kCursorStride words apart, the verdict in word 1): a sender
+// whose region overflowed said so in every header — the receiver then aggregates nothing (all counts to zero) and its
+// n1k_finish reports it, on every rank alike.
+__global__ void exchange_verdict_kernel(const HeaderList H, uint32_t nregions, uint32_t* err_flags) {
     unsigned long long v = 0;
-    for (uint32_t r = 0; r < nregions; r++) v |= headers[(size_t)r * stride_words + 1];
+    for (uint32_t r = 0; r < nregions; r++) v |= H.h[r][1];
     if (!v) return;
     atomicOr(err_flags, (uint32_t)ERR_EXCHANGE_OVERFLOW);
-    for (uint32_t r = threadIdx.x; r < nregions; r += blockDim.x) headers[(size_t)r * stride_words] = 0;
+    for (uint32_t i = threadIdx.x; i < nregions * kRowSubs; i += blockDim.x) H.h[i / kRowSubs][(size_t)(i % kRowSubs) * kCursorStride] = 0;
 }
 
-hipError_t launch_exchange_verdict(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint32_t* err_flags, hipStream_t st) {
-    hipLaunchKernelGGL(exchange_verdict_kernel, dim3(1), dim3(64), 0, st, headers, nregions, stride_words, err_flags);
+hipError_t launch_exchange_verdict(const HeaderList& H, uint32_t nregions, uint32_t* err_flags, hipStream_t st) {
+    hipLaunchKernelGGL(exchange_verdict_kernel, dim3(1), dim3(64), 0, st, H, nregions, err_flags);
+    return hipGetLastError();
+}
+
+// A region written as ONE dense run of header[0] rows (the interpreting partition kernel; small batches) read as kRowSubs
+// segments of sub_rows rows: the first ones full, then a partial one, then empty ones.
+__global__ void dense_to_segments_kernel(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nregions * kRowSubs) return;
+    unsigned long long* h = headers + (size_t)(i / kRowSubs) * stride_words;
+    const uint32_t x = i % kRowSubs;
+    const unsigned long long total = h[0];
+    __syncthreads();  // (a region's kRowSubs threads sit in one workgroup: everybody has read the total before word 0 changes)
+    const unsigned long long lo = (unsigned long long)x * sub_rows;
+    h[(size_t)x * kCursorStride] = total <= lo ? 0ull : (total - lo < sub_rows ? total - lo : sub_rows);
+}
+
+hipError_t launch_dense_to_segments(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows, hipStream_t st) {
+    const uint32_t n = nregions * kRowSubs;
+    hipLaunchKernelGGL(dense_to_segments_kernel, dim3((n + 63) / 64), dim3(64), 0, st, headers, nregions, stride_words, sub_rows);
     return hipGetLastError();
 }
 

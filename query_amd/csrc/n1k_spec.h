@@ -275,13 +275,15 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
 // second item's loads: two memory latencies per tile instead of one, config 2's scan 237 -> 283 us.)
 template <class Spec, int R, int BLOCK, bool WIDE>
 N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, uint32_t tid,
-                            uint32_t (&tg)[R][WIDE ? 2 : 1][kSpecCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kSpecCols], bool (&valid)[R]) {
+                            uint32_t (&tg)[R][WIDE ? 2 : 1][kSpecCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kSpecCols], bool (&valid)[R],
+                            uint32_t item0 = 0) {  // item0: first item of the segment the tile belongs to (segmented batches)
     constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
     uint32_t tt[R][kFastCols];  // TAGGED64 columns: the item's tag bytes as loaded (WIDE: two rows' tags in one 16-bit load)
 #pragma unroll
     for (int j = 0; j < R; j++) {
-        const uint32_t i = base + (uint32_t)j * BLOCK + tid;
-        valid[j] = i < nitems;
+        const uint32_t il = base + (uint32_t)j * BLOCK + tid;
+        valid[j] = il < nitems;
+        const uint32_t i = il + item0;
 #pragma unroll
         for (int c = 0; c < kFastCols; c++) {
             tt[j][c] = 0;
@@ -543,6 +545,12 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
     const uint32_t tile = BLOCK * R;
     const uint32_t nparts = A.nparts;
     const uint32_t cstride = A.count_stride ? A.count_stride : 1u;
+    // this workgroup's sub-region of every destination (PartArgs::nsub): its counter and its first row
+    const uint32_t nsub = A.nsub > 1u ? A.nsub : 1u;
+    const uint32_t sub = blockIdx.x % nsub;
+    const uint64_t sub_cap = nsub > 1u ? A.sub_rows : A.capacity;
+    const uint64_t sub_first = (uint64_t)sub * A.sub_rows * (nsub > 1u ? 1u : 0u);
+    unsigned long long* const my_counts = A.counts + (size_t)sub * kCursorStride * (nsub > 1u ? 1u : 0u);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kSpecCols], const uint64_t (&pv)[R][kRowsPerItem][kSpecCols],
                        const bool (&valid)[R], uint32_t base) {
@@ -593,7 +601,7 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
         unsigned long long gb = 0;
         if (tid < 64) {
             const uint32_t c = tid < nparts ? S.cnt[par][tid] : 0u;
-            if (c) gb = atomicAdd(&A.counts[(size_t)tid * cstride], (unsigned long long)c);
+            if (c) gb = atomicAdd(&my_counts[(size_t)tid * cstride], (unsigned long long)c);
             uint32_t incl = c;
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t t = __shfl_up(incl, off, 64);
@@ -628,14 +636,14 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
         for (uint32_t q = tid; q < staged; q += BLOCK) {
             const uint32_t d = S.sdest[q];
             const unsigned long long r = S.gbase[d] + (q - S.pre[d]);
-            if (r >= A.capacity) {
+            if (r >= sub_cap) {
                 if (!(atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL) & ERR_TABLE_FULL) && A.region_bytes)
                     for (uint32_t z = 0; z < nparts; z++)  // every receiver reads the verdict in the header it gets
                         atomicOr(&A.counts[(size_t)z * A.count_stride + 1], 1ull);
                 continue;
             }
             const size_t shift = (size_t)d * A.region_bytes;  // (0 without packed regions)
-            const uint64_t pos = A.region_bytes ? r : (uint64_t)d * A.capacity + r;
+            const uint64_t pos = A.region_bytes ? sub_first + r : (uint64_t)d * A.capacity + r;
 #pragma unroll
             for (int c = 0; c < Spec::ncols; c++) {
                 if (Spec::col_kind[c] == COLK_DICT32) ((uint32_t*)((char*)A.out_codes[c] + shift))[pos] = S.code[spec_col_slot<Spec>(c)][q];
@@ -701,9 +709,38 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     const uint32_t nrows = F.nrows_dev ? (uint32_t)(*F.nrows_dev < (unsigned long long)F.nrows ? *F.nrows_dev : F.nrows) : F.nrows;
     const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
     const uint32_t tile = BLOCK * R;
+    // Segmented batch (FastArgs::nseg > 1): tiles are numbered segment by segment, `tps` per segment (its capacity); the
+    // segments' row counts are read once into LDS.  A plain batch is one segment.
+    const uint32_t nseg = F.nseg > 1u ? F.nseg : 1u;
+    __shared__ uint32_t seg_n[kMaxSegments];
+    if (nseg > 1u) {
+        for (uint32_t i = tid; i < nseg; i += BLOCK) {
+            const unsigned long long c = F.seg_counts[(size_t)i * F.seg_count_stride];
+            seg_n[i] = (uint32_t)(c < (unsigned long long)F.seg_rows ? c : F.seg_rows);
+        }
+        __syncthreads();
+    }
+    const uint32_t seg_items = WIDE ? F.seg_rows / 2u : F.seg_rows;
+    const uint32_t tps = nseg > 1u ? (seg_items + tile - 1u) / tile : (nitems + tile - 1u) / tile;
+    const uint32_t total_tiles = nseg * tps;
+    // tile t -> first item inside its segment, the segment's items / rows, the segment's first item in the columns
+    auto locate = [&](uint32_t t, uint32_t& base, uint32_t& ni, uint32_t& nr, uint32_t& item0) -> bool {
+        base = 0; ni = 0; nr = 0; item0 = 0;
+        if (t >= total_tiles) return false;
+        if (nseg == 1u) {
+            base = t * tile; ni = nitems; nr = nrows;
+            return true;
+        }
+        const uint32_t seg = t / tps;
+        base = (t - seg * tps) * tile;
+        nr = seg_n[seg];
+        ni = WIDE ? (nr + 1u) / 2u : nr;
+        item0 = seg * seg_items;
+        return base < ni;  // (false: a tile of the segment's unused capacity)
+    };
 
     auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kSpecCols], const uint64_t (&pv)[R][kRowsPerItem][kSpecCols],
-                       const bool (&valid)[R], uint32_t base) {
+                       const bool (&valid)[R], uint32_t base, uint32_t nr) {
         uint64_t mw[kSpecDistinct][kNW];  // this thread's member words of the tile (kEmptyKey = none) and their hash regions
         uint32_t mb[kSpecDistinct][kNW];
 #pragma unroll
@@ -714,7 +751,7 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
                 uint32_t bins[kSpecDistinct];
 #pragma unroll
                 for (int d = 0; d < (int)kSpecDistinct; d++) { words[d] = kEmptyKey; bins[d] = kScatterNone; }
-                const bool row_ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nrows);
+                const bool row_ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nr);
                 if (row_ok) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins, fbytes);
 #pragma unroll
                 for (int d = 0; d < (int)kSpecDistinct; d++) { mw[d][j * (int)kRowsPerItem + h] = words[d]; mb[d][j * (int)kRowsPerItem + h] = bins[d]; }
@@ -733,32 +770,45 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
             w_par ^= 1u;
         }
     };
-    const uint32_t stride = gridDim.x * tile;
+    const uint32_t gstride = gridDim.x;
     if constexpr (kND > 0 || N1K_SPEC_PIPE_ALL) {
         // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
         // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
         uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
         uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
         bool vA[R], vB[R];
-        uint32_t base = blockIdx.x * tile;
-        if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
-        while (base < nitems) {
-            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgB, pvB, vB);  // (beyond the end: no loads)
-            process(tgA, pvA, vA, base);
-            base += stride;
-            if (base >= nitems) break;
-            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgA, pvA, vA);
-            process(tgB, pvB, vB, base);
-            base += stride;
+        uint32_t baseA = 0, baseB = 0, nrA = 0, nrB = 0, ni, item0;
+        uint32_t t = blockIdx.x;
+        // (a tile that does not exist, or lies in unused capacity: nitems 0 -> no loads, every row invalid)
+        if (t < total_tiles) {
+            const bool ok = locate(t, baseA, ni, nrA, item0);
+            spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, tgA, pvA, vA, item0);
+        }
+        while (t < total_tiles) {
+            {
+                const bool ok = locate(t + gstride, baseB, ni, nrB, item0);
+                spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseB, ok ? ni : 0u, tid, tgB, pvB, vB, item0);
+            }
+            process(tgA, pvA, vA, baseA, nrA);
+            t += gstride;
+            if (t >= total_tiles) break;
+            {
+                const bool ok = locate(t + gstride, baseA, ni, nrA, item0);
+                spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, tgA, pvA, vA, item0);
+            }
+            process(tgB, pvB, vB, baseB, nrB);
+            t += gstride;
         }
     } else {
-        for (uint32_t base = blockIdx.x * tile; base < nitems; base += stride) {
+        for (uint32_t t = blockIdx.x; t < total_tiles; t += gstride) {
+            uint32_t base, ni, nr, item0;
+            if (!locate(t, base, ni, nr, item0)) continue;
             // issue every load of the tile first (R items x ncols columns), then compute
             uint32_t tg[R][kRowsPerItem][kSpecCols];
             uint64_t pv[R][kRowsPerItem][kSpecCols];
             bool valid[R];
-            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
-            process(tg, pv, valid, base);
+            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, ni, tid, tg, pv, valid, item0);
+            process(tg, pv, valid, base, nr);
         }
     }
 

@@ -378,7 +378,14 @@ struct FastArgs {
     // when non-null: the batch really holds min(nrows, *nrows_dev) rows (a region received from another GPU: its row count
     // arrived with it and never visits the host)
     const unsigned long long* nrows_dev;
+    // Segmented batch (plan-specialised scan only; nseg > 1): the columns hold nseg segments of seg_rows rows capacity each
+    // (a multiple of 16), segment s holding min(seg_rows, seg_counts[s * seg_count_stride]) rows — the sub-regions of a
+    // row region received from another GPU (n1k_exchange_rows), aggregated by ONE launch.
+    uint32_t nseg, seg_rows, seg_count_stride, pad_seg;
+    const unsigned long long* seg_counts;
 };
+constexpr uint32_t kMaxSegments = 512;
+constexpr uint32_t kRowSubs = 8;  // sub-regions (segments) of a packed row region of the row exchange; their counts kCursorStride words apart
 
 // LDS bytes of the byte flags behind the workgroup table (FastArgs::flag_bytes): 4 per aggregate and slot, whole words
 inline size_t spec_flag_bytes(const FastArgs& F) { return F.flag_bytes ? (((size_t)F.naggs * F.lds_slots + 1) / 2) * 8 : 0; }
@@ -409,7 +416,14 @@ struct PartArgs {
     // `capacity` rows per destination.  With regions the count sits in the region header ([count][verdict]), and an
     // overflow raises verdict bit 0 in EVERY region (each receiver learns it from the exchange itself).
     uint64_t region_bytes;
-    uint32_t count_stride, pad0;
+    uint32_t count_stride;
+    // Packed regions written by the run-time-built partition kernel: every destination's rows in `nsub` sub-regions of
+    // `sub_rows` rows capacity (a multiple of 16), one per workgroup label blockIdx.x % nsub, each with its own count
+    // kCursorStride words further on in the region header — tens of thousands of tiles reserving their runs through ONE
+    // counter per destination serialise on it (~12 ns per same-address atomic: 0.6 ms per 100 M rows).  nsub <= 1: one
+    // dense run per destination.
+    uint32_t nsub;
+    uint64_t sub_rows;
     uint32_t* err_flags;
     uint8_t* out_tags[kMaxCols];
     uint64_t* out_payload[kMaxCols];

@@ -176,8 +176,10 @@ def test_rank_pipeline_partials_world1_rccl(mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("jit", [0, 2], ids=["interpreter", "runtime-built"])
-def test_rank_pipeline_world1_rccl(jit):
+@pytest.mark.parametrize("jit,subs", [(0, 1), (2, 1), (2, 2)], ids=["interpreter", "runtime-built", "runtime-built-subregions"])
+def test_rank_pipeline_world1_rccl(jit, subs):
+    """The row exchange end to end on one rank: both partition kernels; dense runs and (forced) per-destination sub-regions
+    with their own counters, which the receiver aggregates as one segmented batch."""
     import torch
     import torch.distributed as dist
     from query_amd import distributed as qd
@@ -193,13 +195,17 @@ def test_rank_pipeline_world1_rccl(jit):
         t = n1o.synth_table(n, k_cat=50)
         op = qd.ShardedFilterGroup(COND, KEYS, AGGS, t.dictionary, 0, 1, 0)
         op.sender.set_option("jit", jit)
+        op.sender.set_option("part_subs", subs)
+        op.receiver.set_option("jit", jit)  # (the segmented batch on the run-time-built scan / on the interpreter)
+        if subs == 2:
+            op.row_capacity = 2 * n  # (59 tiles over 8 sub-regions: an uneven deal, so generous regions)
         dev, keep = _device_cols(t, op.send_paths)
         ora = n1o.run(t, COND, KEYS, AGGS)
         for step in range(3):  # the first step sizes the regions for the whole shard, the later ones for what arrived
             raw, info = op.run_rows(n, dev)
             assert info["mode"] == "rows" and info["recv_rows"] == ora.rows_passed
             assert raw["ngroups"] == len(ora.keys)
-        assert info["region_rows"] < n  # (regions shrank to the survivors' share)
+        assert subs == 2 or info["region_rows"] < n  # (regions shrank to the survivors' share)
         cache = {}
         keys = op.receiver._py_values(raw["keys"], cache)
         aggs = op.receiver._py_values(raw["aggs"], cache)
@@ -273,5 +279,43 @@ def test_rank_pipeline_grouped_tail(mode):
         cache = {}
         got = GroupRows(len(keys), len(aggs), op.merger._py_values(k, cache), op.merger._py_values(a, cache), [])
         pu.assert_ordered_groups(got, ora, keys, aggs, order, limit, offset)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("workload", ["config2", "config3"])
+def test_row_exchange_20m_rows_subregions_world1(workload):
+    """20 M rows through n1k_exchange_rows at world_size 1: enough tiles for the sub-regions (8 counters per destination)
+    and the segmented receive; COUNT(DISTINCT) rides the same path (sets cannot be merged from partials).  Against the
+    oracle on the same rows."""
+    import torch
+    import torch.distributed as dist
+    from query_amd import distributed as qd
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n = 20_000_001
+        t = n1o.synth_table(n, k_cat=100)
+        if workload == "config2":
+            cond, keys, aggs = COND, KEYS, sorted(["count(*)", "sum(%s)" % D("price")])
+        else:
+            cond, keys, aggs = None, KEYS, sorted(["count(distinct %s)" % D("user_id"), "avg(%s)" % D("price")])
+        op = qd.ShardedFilterGroup(cond, keys, aggs, t.dictionary, 0, 1, 0)
+        dev, keep = _device_cols(t, op.send_paths)
+        ora = n1o.run(t, cond, keys, aggs, threads=16)
+        for step in range(2):
+            raw, info = op.run_rows(n, dev)
+            assert info["mode"] == "rows" and info["recv_rows"] == ora.rows_passed
+        assert op.sender.stats()["spec_kernel"] != 0  # the run-time-built partition kernel
+        cache = {}
+        gk = op.receiver._py_values(raw["keys"], cache)
+        ga = op.receiver._py_values(raw["aggs"], cache)
+        from query_amd.gpu_operator import GroupRows
+        pu.assert_same_groups(GroupRows(1, len(aggs), gk, ga, []), ora, aggs=aggs)
     finally:
         dist.destroy_process_group()
