@@ -266,6 +266,7 @@ def main():
     ap.add_argument("--zipf", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--three-calls", action="store_true", help="n1k_reset / n1k_push_device_batch / n1k_finish as three calls from Python")
     ap.add_argument("--no-ingest", action="store_true", help="skip the h2d_inclusive / json_end_to_end sub-records")
     ap.add_argument("--ingest-rows", type=int, default=40_000_000, help="rows pushed from host buffers for h2d_inclusive")
     ap.add_argument("--json-docs", type=int, default=1_000_000, help="documents pushed as raw JSON for json_end_to_end")
@@ -308,9 +309,14 @@ def main():
     batch = op.make_device_batch(args.rows, [cols.by_path[p] for p in op.column_paths])
 
     def step():
-        op.reopen()                     # n1k_reset: groups dropped (one kernel, no host sync)
-        op.process_device_batch(batch)  # n1k_push_device_batch: scan (+ merge) kernels, asynchronous
-        return op.after_items_raw()     # n1k_finish: FinalGroup + groups copied to the host (one sync)
+        # n1k_run_device_batch = n1k_reset (groups dropped: one kernel, no host sync) + n1k_push_device_batch (scan + merge
+        # kernels, asynchronous) + n1k_finish (FinalGroup, groups on the host: the one sync) — one call through the ABI, as
+        # a compiled host would issue them back to back; --three-calls drives the three entry points from Python instead
+        if args.three_calls:
+            op.reopen()
+            op.process_device_batch(batch)
+            return op.after_items_raw()
+        return op.run_device_batch_raw(batch)
 
     for _ in range(args.warmup):
         rows = step()

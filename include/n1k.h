@@ -295,6 +295,11 @@ n1k_status n1k_push_batch(n1k_handle *h, const n1k_batch *batch);
  * n1k_finish / n1k_sync. */
 n1k_status n1k_push_device_batch(n1k_handle *h, const n1k_batch *batch);
 
+/* One whole execution of the operator over a device-resident batch: n1k_reset + n1k_push_device_batch + n1k_finish in one
+ * call (≙ reopen() + processItem()* + afterItems() of a re-opened operator, execution/base.go:119-135: what a prepared
+ * statement executed again over the same resident columns does).  Same results and errors as the three calls. */
+n1k_status n1k_run_device_batch(n1k_handle *h, const n1k_batch *batch, n1k_result *out);
+
 /* Wait for all queued device work of the handle. */
 n1k_status n1k_sync(n1k_handle *h);
 

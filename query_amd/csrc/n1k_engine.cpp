@@ -88,10 +88,10 @@ struct n1k_handle {
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
     uint64_t opt_jit_min_rows = 4u << 20;
+    uint32_t opt_part_block = 256; // workgroup size of the run-time-built partition kernel (256 | 512; measured 0.49 vs 0.58 ms per 100 M rows)
     uint32_t opt_part_subs = 1;    // row exchange: sub-regions per destination with their own counters (0: one dense run)
     uint32_t opt_part_per_cu = 0;  // workgroups per CU of the run-time-built partition kernel (0 = 2)
     uint32_t opt_pinned_out = 1;   // speculative FinalGroup writes its (few) groups straight into pinned host memory
-    uint32_t opt_flag_bytes = 0;   // (measured: no gain on config 2 — the scan is not bound by its LDS atomics) specialised scan: SUM / AVG operand-kind flags as plain LDS byte stores instead of LDS atomics
     uint32_t opt_fuse_arith = 1;   // arithmetic nodes evaluated in registers by the run-time-built scan (no derived columns)
     bool derived_ready = true;     // the derived columns of the batch being pushed are materialised (or there are none)
     uint64_t opt_wide_values = 1u << 20;  // capacity of the wide key value tables (distinct big ints / floats)
@@ -954,7 +954,9 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             bool kh = false;
             for (uint32_t k = 0; k < F.nkeys; k++) kh |= F.keys[k].col >= F.ncols || F.cols[F.keys[k].col].kind != COLK_DICT32;
             if ((size_t)F.lds_slots * P.lds_words * 8 <= 64 * 1024 && kh == (F.hashed != 0)) {
-                const JitKernel* k = jit_get(make_plan_sig(h, F));
+                SpecSig fs = make_plan_sig(h, F);
+                fs.seg = h->push_nseg > 1 ? 1 : 0;
+                const JitKernel* k = jit_get(fs);
                 if (k->failed) h->jit_log = k->log;
                 else fuse = true;
             }
@@ -993,13 +995,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
             for (uint32_t sl = 4096; sl >= 64; sl >>= 1)
                 if (without + ndist * sl * 8u + 512u <= share) { dcache_slots = sl; break; }
         }
-        // byte flags of SUM / AVG behind the table (n1k_spec.h): shapes without DISTINCT, while table + bytes stay within 64 KiB
-        F.flag_bytes = 0;
-        if (h->opt_flag_bytes && !ndist) {
-            F.flag_bytes = 1;
-            if (table_bytes + spec_flag_bytes(F) > 64u * 1024u) F.flag_bytes = 0;
-        }
-        const uint32_t lds_total = table_bytes + scatter_bytes + ndist * dcache_slots * 8u + (uint32_t)spec_flag_bytes(F);
+        const uint32_t lds_total = table_bytes + scatter_bytes + ndist * dcache_slots * 8u;
         // workgroups per CU that fit: 512 threads x 3 (<= 48 KiB each), x 2 (<= 72 KiB), else 1024 threads x 1
         uint32_t fblock = h->opt_block == 1024 || h->opt_block == 512 ? h->opt_block : (table_bytes <= 72 * 1024 ? 512u : 1024u);
         if (ndist) fblock = 512;
@@ -1013,8 +1009,11 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
         F.err_flags = h->d_errp;
         F.rows_selected = h->d_counters.p + 0;
         // a prebuilt plan-specialised kernel of exactly this shape?
-        const SpecSig sig = make_plan_sig(h, F);
-        const SpecEntry* spec = h->opt_spec ? find_spec(sig) : nullptr;
+        // (segmented batches — a received row region — run on the run-time-built variant of the shape only: the prebuilt
+        //  kernels carry none of the segment bookkeeping)
+        SpecSig sig = make_plan_sig(h, F);
+        sig.seg = h->push_nseg > 1 ? 1 : 0;
+        const SpecEntry* spec = h->opt_spec && !sig.seg ? find_spec(sig) : nullptr;
         // no prebuilt kernel of this shape: instantiate the same template at run time (large batches, or forced)
         const JitKernel* jit = nullptr;
         bool key_kinds_hashed = false;
@@ -2221,8 +2220,8 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "spec") h->opt_spec = value ? 1 : 0;
     else if (n == "wide") h->opt_wide = value ? 1 : 0;
     else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
-    else if (n == "flag_bytes") h->opt_flag_bytes = value ? 1 : 0;
     else if (n == "pinned_out") h->opt_pinned_out = value ? 1 : 0;
+    else if (n == "part_block") h->opt_part_block = value == 256 ? 256 : 512;
     else if (n == "part_subs") h->opt_part_subs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);  // 0 off, 1 large batches, 2 always (tests)
     else if (n == "part_per_cu") h->opt_part_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8);
     else if (n == "jit") h->opt_jit = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
@@ -2309,6 +2308,14 @@ n1k_status n1k_push_device_batch(n1k_handle* h, const n1k_batch* batch) {
     if (!h) return N1K_INVALID;
     return push_device(h, batch);
     });
+}
+
+n1k_status n1k_run_device_batch(n1k_handle* h, const n1k_batch* batch, n1k_result* out) {
+    if (!h || !batch || !out) return N1K_INVALID;
+    n1k_status st = n1k_reset(h);
+    if (st == N1K_OK) st = n1k_push_device_batch(h, batch);
+    if (st == N1K_OK) st = n1k_finish(h, out);
+    return st;
 }
 
 n1k_status n1k_extract_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offsets, const char* bytes, n1k_batch* out) {
@@ -3320,8 +3327,11 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
         F.nrows = (uint32_t)n;
         F.row_base = h->row_base;
         F.err_flags = h->d_errp;
-        const uint64_t tiles = (n + 2047) / 2048;
-        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * (h->opt_part_per_cu ? h->opt_part_per_cu : 2u), tiles));
+        // 512-thread workgroups (tiles of 2048 rows, two per CU) or 256-thread ones (1024 rows, five per CU: more independent
+        // workgroups to overlap the wait for each tile's reservation)
+        const uint32_t pblock = wide && h->opt_part_block == 256 ? 256u : 512u;
+        const uint64_t tiles = (n + pblock * 4 - 1) / (pblock * 4);
+        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * (h->opt_part_per_cu ? h->opt_part_per_cu : (pblock == 256 ? 5u : 2u)), tiles));
         // many tiles: every destination's region in kRowSubs sub-regions with their own counters, workgroups dealt round-robin
         // (tile t goes to sub-region t % kRowSubs: an even share of the rows whatever their order)
         if (seg_rows && h->opt_part_subs && (tiles >= 4096 || h->opt_part_subs == 2)) {
@@ -3329,7 +3339,7 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
             grid = (grid + kRowSubs - 1) / kRowSubs * kRowSubs;
         }
         if (e0) (void)hipEventRecord(e0, h->stream);
-        HIP_TRY(h, jit_launch_partition(jit, h->prog, F, A, grid, wide, h->stream));
+        HIP_TRY(h, jit_launch_partition(jit, h->prog, F, A, grid, wide, pblock, h->stream));
         h->stats.spec_kernel = F.nderived ? 3u : 2u;
     } else {
         n1k_status st = materialize_derived(h, b);

@@ -100,16 +100,18 @@ std::string jit_source(const SpecSig& g) {
         else o << "#define N1K_PART_ATTR\n";
         o << "extern \"C\" __global__ __launch_bounds__(512) N1K_PART_ATTR void n1k_jit_part_wide(const n1k::Program P, const n1k::FastArgs F,\n"
           << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 2, 512, true>(P, F, A);\n}\n"
+          << "extern \"C\" __global__ __launch_bounds__(256) N1K_PART_ATTR void n1k_jit_part_wide256(const n1k::Program P, const n1k::FastArgs F,\n"
+          << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 2, 256, true>(P, F, A);\n}\n"
           << "extern \"C\" __global__ __launch_bounds__(512) N1K_PART_ATTR void n1k_jit_part_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
           << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 4, 512, false>(P, F, A);\n}\n";
         return o.str();
     }
     o << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_wide(const n1k::Program P, const n1k::FastArgs F,\n"
       << "        const n1k::GlobalTable G, unsigned long long* ngroups, const n1k::WordLogArgs L) {\n"
-      << "    n1k::scan_spec_body<n1k::SpecJ, 2, 512, true>(P, F, G, ngroups, L);\n}\n"
+      << "    n1k::scan_spec_body<n1k::SpecJ, 2, 512, true, " << (g.seg ? "true" : "false") << ">(P, F, G, ngroups, L);\n}\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
       << "        const n1k::GlobalTable G, unsigned long long* ngroups, const n1k::WordLogArgs L) {\n"
-      << "    n1k::scan_spec_body<n1k::SpecJ, 4, 512, false>(P, F, G, ngroups, L);\n}\n"
+      << "    n1k::scan_spec_body<n1k::SpecJ, 4, 512, false, " << (g.seg ? "true" : "false") << ">(P, F, G, ngroups, L);\n}\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_rec_wide(const n1k::Program P, const n1k::FastArgs F,\n"
       << "        const n1k::WordLogArgs L) {\n    n1k::scan_spec_records_body<n1k::SpecJ, 2, 512, true>(P, F, L);\n}\n"
       << "extern \"C\" __global__ __launch_bounds__(512) void n1k_jit_rec_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
@@ -140,6 +142,7 @@ const JitKernel* jit_get(const SpecSig& sig) {
     if (sig.mode == 1) {
         if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
             hipModuleGetFunction(&k->part_wide, k->module, "n1k_jit_part_wide") != hipSuccess ||
+            hipModuleGetFunction(&k->part_wide256, k->module, "n1k_jit_part_wide256") != hipSuccess ||
             hipModuleGetFunction(&k->part_narrow, k->module, "n1k_jit_part_narrow") != hipSuccess) {
             k->failed = true;
             k->log += "\nhipModuleLoadData / hipModuleGetFunction failed";
@@ -159,7 +162,7 @@ const JitKernel* jit_get(const SpecSig& sig) {
 
 hipError_t jit_launch(const JitKernel* k, const Program& P, const FastArgs& F, const GlobalTable& G,
                       unsigned long long* ngroups, uint32_t grid, bool wide, const WordLogArgs& L, uint32_t ndistinct, hipStream_t st) {
-    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * ndistinct * 8 + spec_flag_bytes(F);
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * ndistinct * 8;
     void* args[] = {(void*)&P, (void*)&F, (void*)&G, (void*)&ngroups, (void*)&L};
     return hipModuleLaunchKernel(wide ? k->wide : k->narrow, grid, 1, 1, 512, 1, 1, (unsigned)shmem, st, args, nullptr);
 }
@@ -173,8 +176,9 @@ hipError_t jit_launch_records(const JitKernel* k, const Program& P, const FastAr
 }
 
 hipError_t jit_launch_partition(const JitKernel* k, const Program& P, const FastArgs& F, const PartArgs& A, uint32_t grid, bool wide,
-                                hipStream_t st) {
+                                uint32_t block, hipStream_t st) {
     void* args[] = {(void*)&P, (void*)&F, (void*)&A};
+    if (wide && block == 256) return hipModuleLaunchKernel(k->part_wide256, grid, 1, 1, 256, 1, 1, 0, st, args, nullptr);
     return hipModuleLaunchKernel(wide ? k->part_wide : k->part_narrow, grid, 1, 1, 512, 1, 1, 0, st, args, nullptr);
 }
 

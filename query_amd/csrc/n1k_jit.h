@@ -16,7 +16,7 @@ struct JitKernel {
     hipFunction_t wide = nullptr;    // scan_spec_body<Spec, 2, 512, true>
     hipFunction_t narrow = nullptr;  // scan_spec_body<Spec, 4, 512, false>
     hipFunction_t rec_wide = nullptr, rec_narrow = nullptr;  // scan_spec_records_body<Spec, 2 / 4, 512, true / false> (partitioned GROUP BY front end)
-    hipFunction_t part_wide = nullptr, part_narrow = nullptr;  // scan_spec_partition_body<...> (SpecSig::mode 1: the row exchange)
+    hipFunction_t part_wide = nullptr, part_narrow = nullptr, part_wide256 = nullptr;  // scan_spec_partition_body<...> (SpecSig::mode 1: the row exchange)
     bool failed = false;
     std::string log;
 };
@@ -35,6 +35,6 @@ hipError_t jit_launch_records(const JitKernel* k, const Program& P, const FastAr
                               hipStream_t st);
 
 hipError_t jit_launch_partition(const JitKernel* k, const Program& P, const FastArgs& F, const PartArgs& A, uint32_t grid, bool wide,
-                                hipStream_t st);
+                                uint32_t block, hipStream_t st);
 
 }  // namespace n1k

@@ -1185,7 +1185,7 @@ static SpecSig make_sig() {
 template <class Spec>
 static hipError_t launch_spec(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                               uint32_t grid, uint32_t block, bool wide, const WordLogArgs& L, hipStream_t st) {
-    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * spec_ndistinct<Spec>() * 8 + spec_flag_bytes(F);
+    size_t shmem = (size_t)F.lds_slots * P.lds_words * 8 + (size_t)L.dcache_slots * spec_ndistinct<Spec>() * 8;
 #define N1K_LAUNCH(R, B, W)                                                                                       \
     do {                                                                                                          \
         auto k = scan_spec_kernel<Spec, R, B, W>;                                                                 \

@@ -102,16 +102,6 @@ N1K_DEV bool spec_term_true(int t, const FastArgs& F, uint32_t tg, uint64_t p) {
 }
 
 // CumulateInitial of aggregate `a` (compile-time kind) into the LDS slot; false -> take the global path
-// Byte flags (FastArgs::flag_bytes, shapes without DISTINCT): an LDS atomic retires about one lane per clock and CU, so the
-// flag of SUM / AVG — one ds_or per surviving row, next to the ds_add of the sum itself — took half of the scan's LDS-atomic
-// budget (config 2: 100 M atomics ~ 0.16 ms of a 0.25 ms kernel).  Which kinds of operands a group has seen is idempotent
-// information: each (aggregate, slot, kind) gets a BYTE that rows set with a plain ds_write_b8 (full LDS store rate, nothing
-// to wait for); the bytes are folded into the table's flag words once, before the table leaves the workgroup.
-typedef __attribute__((address_space(3))) unsigned char lds_u8;
-N1K_DEV void spec_flag_byte(uint64_t* fbytes, uint32_t a, uint32_t S, uint32_t slot, uint32_t kind) {
-    *(volatile lds_u8*)((lds_u8*)fbytes + (((size_t)a * S + slot) << 2) + kind) = 1;
-}
-
 template <class Spec>
 N1K_DEV void spec_flag(lds_u64* w, unsigned long long bit) {
     // Shapes with COUNT(DISTINCT) run at the CU's LDS-atomic rate (about one lane per clock: four atomics per row were
@@ -122,7 +112,7 @@ N1K_DEV void spec_flag(lds_u64* w, unsigned long long bit) {
 }
 
 template <class Spec>
-N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32_t slot, uint32_t tag, uint64_t p, uint64_t* fbytes = nullptr) {
+N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32_t slot, uint32_t tag, uint64_t p) {
     const uint32_t kind = Spec::aggs[a].kind;
     lds_u64* w = lds_word(lds, P.aggs[a].lds_off * S + slot);
     if (kind == AGG_COUNT) {
@@ -138,13 +128,11 @@ N1K_DEV bool spec_acc(int a, const Program& P, uint64_t* lds, uint32_t S, uint32
             int64_t x = (int64_t)p;
             if (x >= (1ll << 40) || x <= -(1ll << 40)) return false;
             lds_add_u64(w, (unsigned long long)x);
-            if (fbytes) spec_flag_byte(fbytes, (uint32_t)a, S, slot, x < 0 ? 1u : 0u);
-            else spec_flag<Spec>(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
+            spec_flag<Spec>(w + 2 * S, x < 0 ? (unsigned long long)SF_NEG_INT : (unsigned long long)SF_NONNEG_INT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
         } else if (tag == T_FLOAT) {
             lds_add_f64(w + S, as_f64(p));
-            if (fbytes) spec_flag_byte(fbytes, (uint32_t)a, S, slot, 2u);
-            else spec_flag<Spec>(w + 2 * S, (unsigned long long)SF_FLOAT);
+            spec_flag<Spec>(w + 2 * S, (unsigned long long)SF_FLOAT);
             if (kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
         }
         return true;
@@ -193,7 +181,7 @@ template <class Spec>
 N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                       uint64_t* lds, uint32_t S, uint32_t* lds_fill, const uint32_t (&tg)[kSpecCols],
                       const uint64_t (&pv)[kSpecCols], uint32_t& selected, uint32_t& unpackable, const WordLogArgs& L,
-                      uint64_t* dcache, uint64_t (&words)[kSpecDistinct], uint32_t (&bins)[kSpecDistinct], uint64_t* fbytes = nullptr) {
+                      uint64_t* dcache, uint64_t (&words)[kSpecDistinct], uint32_t (&bins)[kSpecDistinct]) {
     constexpr int kND = spec_ndistinct<Spec>();
     bool pass = true;
 #pragma unroll
@@ -262,7 +250,7 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
         }
         if (kHashed && grow >= 0) {  // the LDS table is full: this group lives in the global table only
             acc_global(P, P.aggs[a], &G.acc[(size_t)grow * P.glob_words], t, p);
-        } else if (!spec_acc<Spec>(a, P, lds, S, slot, t, p, fbytes)) {  // rare: an integer too large for the narrow LDS sum
+        } else if (!spec_acc<Spec>(a, P, lds, S, slot, t, p)) {  // rare: an integer too large for the narrow LDS sum
             long long g = global_find_or_insert(G, kHashed ? key : fast_slot_key(F, slot), F.err_flags, ngroups);
             if (g >= 0) acc_global(P, P.aggs[a], &G.acc[(size_t)g * P.glob_words], t, p);
         }
@@ -675,7 +663,10 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
     if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
 }
 
-template <class Spec, int R, int BLOCK, bool WIDE>
+// SEG: the batch is segmented (FastArgs::nseg > 1; run-time-built kernels only: the receiving side of the row exchange) —
+// a compile-time switch, so that plain batches carry none of the segment bookkeeping (its scalar registers alone cost the
+// config-2 scan 12 %: 16 SGPR spills instead of 2).
+template <class Spec, int R, int BLOCK, bool WIDE, bool SEG = false>
 N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                             const WordLogArgs& L) {
     extern __shared__ uint64_t lds[];
@@ -690,10 +681,6 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     uint32_t w_par = 0;
     const uint32_t w_sub = blockIdx.x % kRecSubs;  // sub-region of every hash region this workgroup appends to
     uint64_t* dcache = lds + (size_t)S * P.lds_words;  // "already logged" caches of the DISTINCT aggregates
-    // byte flags of SUM / AVG (4 bytes per aggregate and slot, behind the table; shapes without DISTINCT only)
-    uint64_t* const fbytes = (kND == 0 && F.flag_bytes) ? dcache : nullptr;
-    if (fbytes)
-        for (uint32_t i = tid; i < ((uint32_t)Spec::naggs * S + 1u) / 2u; i += BLOCK) *(volatile lds_u64*)lds_word(fbytes, i) = 0ull;
     if constexpr (kND > 0) {
         for (uint32_t i = tid; i < L.dcache_slots * (uint32_t)kND; i += BLOCK) *(volatile lds_u64*)lds_word(dcache, i) = kEmptyKey;
 #pragma unroll
@@ -711,14 +698,17 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     const uint32_t tile = BLOCK * R;
     // Segmented batch (FastArgs::nseg > 1): tiles are numbered segment by segment, `tps` per segment (its capacity); the
     // segments' row counts are read once into LDS.  A plain batch is one segment.
-    const uint32_t nseg = F.nseg > 1u ? F.nseg : 1u;
-    __shared__ uint32_t seg_n[kMaxSegments];
-    if (nseg > 1u) {
-        for (uint32_t i = tid; i < nseg; i += BLOCK) {
-            const unsigned long long c = F.seg_counts[(size_t)i * F.seg_count_stride];
-            seg_n[i] = (uint32_t)(c < (unsigned long long)F.seg_rows ? c : F.seg_rows);
+    const uint32_t nseg = SEG ? (F.nseg > 1u ? F.nseg : 1u) : 1u;
+    uint32_t seg_n[SEG ? kMaxSegments : 1];  // (wave-uniform: scalar registers)
+    if constexpr (SEG) {
+#pragma unroll
+        for (int i = 0; i < (int)kMaxSegments; i++) {
+            seg_n[i] = 0;
+            if (nseg > 1u && (uint32_t)i < nseg) {
+                const unsigned long long c = F.seg_counts[(size_t)i * F.seg_count_stride];
+                seg_n[i] = (uint32_t)(c < (unsigned long long)F.seg_rows ? c : F.seg_rows);
+            }
         }
-        __syncthreads();
     }
     const uint32_t seg_items = WIDE ? F.seg_rows / 2u : F.seg_rows;
     const uint32_t tps = nseg > 1u ? (seg_items + tile - 1u) / tile : (nitems + tile - 1u) / tile;
@@ -727,15 +717,19 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     auto locate = [&](uint32_t t, uint32_t& base, uint32_t& ni, uint32_t& nr, uint32_t& item0) -> bool {
         base = 0; ni = 0; nr = 0; item0 = 0;
         if (t >= total_tiles) return false;
-        if (nseg == 1u) {
+        if (!SEG || nseg == 1u) {
             base = t * tile; ni = nitems; nr = nrows;
             return true;
         }
-        const uint32_t seg = t / tps;
-        base = (t - seg * tps) * tile;
-        nr = seg_n[seg];
-        ni = WIDE ? (nr + 1u) / 2u : nr;
-        item0 = seg * seg_items;
+        if constexpr (SEG) {
+            const uint32_t seg = t / tps;
+            base = (t - seg * tps) * tile;
+#pragma unroll
+            for (int i = 0; i < (int)kMaxSegments; i++)
+                if (seg == (uint32_t)i) nr = seg_n[i];
+            ni = WIDE ? (nr + 1u) / 2u : nr;
+            item0 = seg * seg_items;
+        }
         return base < ni;  // (false: a tile of the segment's unused capacity)
     };
 
@@ -752,7 +746,7 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
 #pragma unroll
                 for (int d = 0; d < (int)kSpecDistinct; d++) { words[d] = kEmptyKey; bins[d] = kScatterNone; }
                 const bool row_ok = valid[j] && (!WIDE || h == 0 || 2u * (base + (uint32_t)j * BLOCK + tid) + 1u < nr);
-                if (row_ok) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins, fbytes);
+                if (row_ok) spec_row<Spec>(P, F, G, ngroups, lds, S, &lds_fill, tg[j][h], pv[j][h], selected, unpackable, L, dcache, words, bins);
 #pragma unroll
                 for (int d = 0; d < (int)kSpecDistinct; d++) { mw[d][j * (int)kRowsPerItem + h] = words[d]; mb[d][j * (int)kRowsPerItem + h] = bins[d]; }
             }
@@ -770,45 +764,78 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
             w_par ^= 1u;
         }
     };
-    const uint32_t gstride = gridDim.x;
-    if constexpr (kND > 0 || N1K_SPEC_PIPE_ALL) {
-        // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
-        // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
-        uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
-        uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
-        bool vA[R], vB[R];
-        uint32_t baseA = 0, baseB = 0, nrA = 0, nrB = 0, ni, item0;
-        uint32_t t = blockIdx.x;
-        // (a tile that does not exist, or lies in unused capacity: nitems 0 -> no loads, every row invalid)
-        if (t < total_tiles) {
-            const bool ok = locate(t, baseA, ni, nrA, item0);
-            spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, tgA, pvA, vA, item0);
-        }
-        while (t < total_tiles) {
-            {
-                const bool ok = locate(t + gstride, baseB, ni, nrB, item0);
-                spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseB, ok ? ni : 0u, tid, tgB, pvB, vB, item0);
+    if constexpr (!SEG) {
+        // plain batch: tiles at base = blockIdx.x * tile, + gridDim.x * tile, ...
+        const uint32_t stride = gridDim.x * tile;
+        if constexpr (kND > 0 || N1K_SPEC_PIPE_ALL) {
+            // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
+            // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
+            uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+            uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
+            bool vA[R], vB[R];
+            uint32_t base = blockIdx.x * tile;
+            if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
+            while (base < nitems) {
+                spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgB, pvB, vB);  // (beyond the end: no loads)
+                process(tgA, pvA, vA, base, nrows);
+                base += stride;
+                if (base >= nitems) break;
+                spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgA, pvA, vA);
+                process(tgB, pvB, vB, base, nrows);
+                base += stride;
             }
-            process(tgA, pvA, vA, baseA, nrA);
-            t += gstride;
-            if (t >= total_tiles) break;
-            {
-                const bool ok = locate(t + gstride, baseA, ni, nrA, item0);
-                spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, tgA, pvA, vA, item0);
+        } else {
+            for (uint32_t base = blockIdx.x * tile; base < nitems; base += stride) {
+                // issue every load of the tile first (R items x ncols columns), then compute
+                uint32_t tg[R][kRowsPerItem][kSpecCols];
+                uint64_t pv[R][kRowsPerItem][kSpecCols];
+                bool valid[R];
+                spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
+                process(tg, pv, valid, base, nrows);
             }
-            process(tgB, pvB, vB, baseB, nrB);
-            t += gstride;
         }
     } else {
-        for (uint32_t t = blockIdx.x; t < total_tiles; t += gstride) {
-            uint32_t base, ni, nr, item0;
-            if (!locate(t, base, ni, nr, item0)) continue;
-            // issue every load of the tile first (R items x ncols columns), then compute
-            uint32_t tg[R][kRowsPerItem][kSpecCols];
-            uint64_t pv[R][kRowsPerItem][kSpecCols];
-            bool valid[R];
-            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, ni, tid, tg, pv, valid, item0);
-            process(tg, pv, valid, base, nr);
+        // segmented batch: tiles numbered segment by segment (locate)
+        const uint32_t gstride = gridDim.x;
+        if constexpr (kND > 0 || N1K_SPEC_PIPE_ALL) {
+            // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
+            // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
+            uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+            uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
+            bool vA[R], vB[R];
+            uint32_t baseA = 0, baseB = 0, nrA = 0, nrB = 0, ni, item0;
+            uint32_t t = blockIdx.x;
+            // (a tile that does not exist, or lies in unused capacity: nitems 0 -> no loads, every row invalid)
+            if (t < total_tiles) {
+                const bool ok = locate(t, baseA, ni, nrA, item0);
+                spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, tgA, pvA, vA, item0);
+            }
+            while (t < total_tiles) {
+                {
+                    const bool ok = locate(t + gstride, baseB, ni, nrB, item0);
+                    spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseB, ok ? ni : 0u, tid, tgB, pvB, vB, item0);
+                }
+                process(tgA, pvA, vA, baseA, nrA);
+                t += gstride;
+                if (t >= total_tiles) break;
+                {
+                    const bool ok = locate(t + gstride, baseA, ni, nrA, item0);
+                    spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, tgA, pvA, vA, item0);
+                }
+                process(tgB, pvB, vB, baseB, nrB);
+                t += gstride;
+            }
+        } else {
+            for (uint32_t t = blockIdx.x; t < total_tiles; t += gstride) {
+                uint32_t base, ni, nr, item0;
+                if (!locate(t, base, ni, nr, item0)) continue;
+                // issue every load of the tile first (R items x ncols columns), then compute
+                uint32_t tg[R][kRowsPerItem][kSpecCols];
+                uint64_t pv[R][kRowsPerItem][kSpecCols];
+                bool valid[R];
+                spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, ni, tid, tg, pv, valid, item0);
+                process(tg, pv, valid, base, nr);
+            }
         }
     }
 
@@ -821,19 +848,6 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     for (int off = 32; off > 0; off >>= 1) selected += __shfl_down(selected, off, 64);
     if ((tid & 63) == 0 && selected) atomicAdd(&block_selected, selected);
     __syncthreads();
-    if (fbytes) {
-        // fold the byte flags into the flag words of the table (one thread per slot: plain read-modify-write)
-#pragma unroll
-        for (int a = 0; a < Spec::naggs; a++) {
-            if (Spec::aggs[a].kind != AGG_SUM && Spec::aggs[a].kind != AGG_AVG) continue;
-            for (uint32_t sl = tid; sl < S; sl += BLOCK) {
-                const uint32_t b4 = *(volatile lds_u32*)((lds_u32*)fbytes + (size_t)a * S + sl);  // bytes: non-negative int, negative int, float
-                const uint64_t fl = (uint64_t)(b4 & 1u) | (uint64_t)((b4 >> 7) & 2u) | (uint64_t)((b4 >> 14) & 4u);
-                if (fl) lds[(size_t)(P.aggs[a].lds_off + 2u) * S + sl] |= fl;
-            }
-        }
-        __syncthreads();
-    }
     if (F.slabs) {
         // hand the workgroup's partial groups to merge_slabs_kernel: plain coalesced stores, no atomics
         uint64_t* slab = F.slabs + (size_t)blockIdx.x * P.lds_words * S;

@@ -368,7 +368,7 @@ struct FastArgs {
     FastTerm terms[kFastTerms];
     FastKey keys[kFastKeys];
     uint32_t agg_col[kFastAggs];  // column slot of each aggregate's operand (unused when has_operand == 0)
-    uint32_t flag_bytes;          // plan-specialised scan: SUM / AVG operand-kind flags as LDS bytes (plain stores), not atomics
+    uint32_t pad_f;
     uint32_t nderived;            // fused arithmetic nodes (plan-specialised kernels only; their shape is in the SpecSig)
     uint64_t dconst[kFastDerived][4];  // payloads of the nodes' constant operands (the tags are part of the shape)
     uint32_t* err_flags;
@@ -384,11 +384,8 @@ struct FastArgs {
     uint32_t nseg, seg_rows, seg_count_stride, pad_seg;
     const unsigned long long* seg_counts;
 };
-constexpr uint32_t kMaxSegments = 512;
+constexpr uint32_t kMaxSegments = 8;  // (= kRowSubs: the counts live in scalar registers)
 constexpr uint32_t kRowSubs = 8;  // sub-regions (segments) of a packed row region of the row exchange; their counts kCursorStride words apart
-
-// LDS bytes of the byte flags behind the workgroup table (FastArgs::flag_bytes): 4 per aggregate and slot, whole words
-inline size_t spec_flag_bytes(const FastArgs& F) { return F.flag_bytes ? (((size_t)F.naggs * F.lds_slots + 1) / 2) * 8 : 0; }
 
 // derived columns: arithmetic nodes of the plan are evaluated once per batch by an element-wise kernel into a
 // temporary TAGGED64 column; the scan kernels then see them as ordinary columns
@@ -453,7 +450,7 @@ struct SpecDerived {
 struct SpecSig {
     int ncols, nterms, nkeys, naggs;
     int hashed, nderived;  // hashed 1: keys go through the open-addressed LDS table; nderived: fused arithmetic nodes
-    int mode, pad;         // 0: scan kernels (+ records front end); 1: partition kernels of the row exchange (aggregates left out)
+    int mode, seg;         // mode 0: scan kernels (+ records front end); 1: partition kernels of the row exchange (aggregates left out); seg 1: the scan kernels take segmented batches (scan_spec_body's SEG)
     uint32_t col_kind[kFastCols];
     SpecTerm terms[kFastTerms];
     uint32_t key_col[kFastKeys];

@@ -220,10 +220,17 @@ class GpuFilterGroup:
         self._check(self._lib.n1k_finish(self._h, C.byref(res)))
         return res
 
-    def after_items_raw(self) -> dict:
+    def run_device_batch_raw(self, batch) -> dict:
+        """n1k_run_device_batch: reopen + process_device_batch + after_items_raw in ONE call through the ABI."""
+        res = _ffi.Result()
+        self._check(self._lib.n1k_run_device_batch(self._h, C.byref(batch[0]), C.byref(res)))
+        return self.after_items_raw(res)
+
+    def after_items_raw(self, res=None) -> dict:
         """FinalGroup output as numpy arrays (copies): keys/aggs are structured (tag, v) arrays of shape
         [ngroups, nkeys] / [ngroups, naggs]; string values are dictionary codes."""
-        res = self._finish()
+        if res is None:
+            res = self._finish()
         ng, nk, na = int(res.ngroups), int(res.nkeys), int(res.naggs)
 
         def arr(ptr, count, dt):

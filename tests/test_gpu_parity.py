@@ -385,6 +385,43 @@ def test_fused_arithmetic_directed_shapes(case):
     assert st["spec_kernel"] == 3, st
 
 
+def test_run_device_batch_is_reset_push_finish():
+    """n1k_run_device_batch = n1k_reset + n1k_push_device_batch + n1k_finish: same groups as the three calls, every time."""
+    import torch
+    cond, keys = "(50 < %s)" % D("price"), [D("cat")]
+    aggs = sorted(["sum(%s)" % D("price"), "count(*)", "min(%s)" % D("user_id")])
+    t = n1o.synth_table(200_003, k_cat=40)
+    ora = n1o.run(t, cond, keys, aggs)
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(cond, keys, aggs))
+    op.intern(list(t.dictionary))
+    by = {c.name: c for c in t.columns}
+    keep, cols = [], []
+    for p in op.column_paths:
+        c = by[p]
+        if c.kind == n1o.COL_DICT32:
+            x = torch.from_numpy(c.codes.view(np.int32)).cuda()
+            keep.append(x)
+            cols.append((_ffi.COL_DICT32, None, None, x.data_ptr()))
+        else:
+            a, b = torch.from_numpy(c.tags).cuda(), torch.from_numpy(c.payload.view(np.int64)).cuda()
+            keep += [a, b]
+            cols.append((_ffi.COL_TAGGED64, a.data_ptr(), b.data_ptr(), None))
+    torch.cuda.synchronize()
+    batch = op.make_device_batch(t.nrows, cols)
+    from query_amd.gpu_operator import GroupRows
+    for _ in range(3):
+        raw = op.run_device_batch_raw(batch)
+        cache = {}
+        got = GroupRows(len(keys), len(aggs), op._py_values(raw["keys"], cache), op._py_values(raw["aggs"], cache), [])
+        pu.assert_same_groups(got, ora, aggs=aggs)
+        assert op.stats()["rows_selected"] == ora.rows_passed
+    op.reopen()
+    op.process_device_batch(batch)
+    three = op.after_items()
+    pu.assert_same_groups(three, ora, aggs=aggs)
+    op.done()
+
+
 def test_filter_only_selected_rows():
     t = n1o.synth_table(100_003, k_cat=10)
     for cond in ["(50 < %s)" % D("price"), "(%s is missing)" % D("price"), "(%s = \"cat_3\")" % D("cat")]:

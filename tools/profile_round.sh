@@ -15,4 +15,8 @@ for WL in config2 config3 config5; do
   python3 $ROOT/tools/timeline.py $ROOT/gpurun_out/prof_${TAG}_$WL/stats init_table_kernel $([ $WL = config5 ] && echo 2 || echo 1) > $DST/${TAG}_bench_${WL}_100M_timeline.txt
   echo "$WL done"
 done
+# the multi-GPU row exchange with one rank (the same code path: partition -> all-to-all -> owner's scan -> gather)
+python3 $ROOT/bench.py --force-dist --exchange rows --steps 20 --warmup 3 2>/dev/null | tail -1 > $DST/${TAG}_bench_rows_world1_100M.json.log || true
+bash $ROOT/tools/prof.sh ${TAG}_rows stats -- --force-dist --exchange rows > /dev/null || true
+cp $ROOT/gpurun_out/prof_${TAG}_rows/stats/bench_kernel_stats.csv $DST/${TAG}_bench_rows_world1_100M_kernel_stats.csv || true
 ls -la $DST
