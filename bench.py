@@ -253,6 +253,18 @@ def ingest_rates(args, wl, cols) -> dict:
     return out
 
 
+def kernel_label(st: dict, wl: dict) -> str:
+    """What `roofline.kernel_ms` (the HIP-event time of the batch's kernels) covers for this workload."""
+    if st.get("agg_mode") == 4:
+        return ("partitioned GROUP BY pipeline: key probe + scan_spec_records_kernel + radix_scatter_sub_kernel + agg_bins16_kernel "
+                "(FinalGroup / top-k not included)")
+    if any("distinct" in a for a in wl["aggs"]):
+        return "scan_spec_kernel incl. the member words' first partition pass (second pass and LDS sets run in n1k_finish: not included)"
+    if st.get("spec_kernel") == 3:
+        return "run-time-built scan_spec_body with the plan's arithmetic in registers (+merge_slabs_kernel)"
+    return "scan_spec_kernel(+merge_slabs_kernel)" if st.get("spec_kernel") else "scan_fast/scan_group_kernel"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,6 +288,7 @@ def main():
                          "hash-partitioned on the group key by one RCCL all-to-all); partials = per-GPU partial groups "
                          "hash-partitioned to owners; gathered = partial groups all-gathered while they are few (the "
                          "ablation: G groups travel instead of the rows); plans with DISTINCT always exchange rows")
+    ap.add_argument("--no-ablation", action="store_true", help="multi-GPU: skip the partial-group ablation measured next to the row exchange")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank")
     args = ap.parse_args()
     if args.kcat is None:
@@ -356,7 +369,7 @@ def main():
                    "agg_mode": st["agg_mode"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("scan_spec_kernel(+merge_slabs_kernel)" if st.get("spec_kernel") else "scan_fast/scan_group_kernel"),
+                     "kernel": kernel_label(st, wl),
                      "kernel_ms": scan_ms,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }

@@ -88,6 +88,7 @@ struct n1k_handle {
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
     uint64_t opt_jit_min_rows = 4u << 20;
+    uint32_t opt_lean_topk = 1;    // ORDER BY ... LIMIT over a kept region: order values first, rows for the candidates only
     uint32_t opt_part_block = 256; // workgroup size of the run-time-built partition kernel (256 | 512; measured 0.49 vs 0.58 ms per 100 M rows)
     uint32_t opt_part_subs = 1;    // row exchange: sub-regions per destination with their own counters (0: one dense run)
     uint32_t opt_part_per_cu = 0;  // workgroups per CU of the run-time-built partition kernel (0 = 2)
@@ -2221,6 +2222,7 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "wide") h->opt_wide = value ? 1 : 0;
     else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
     else if (n == "pinned_out") h->opt_pinned_out = value ? 1 : 0;
+    else if (n == "lean_topk") h->opt_lean_topk = value ? 1 : 0;
     else if (n == "part_block") h->opt_part_block = value == 256 ? 256 : 512;
     else if (n == "part_subs") h->opt_part_subs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);  // 0 off, 1 large batches, 2 always (tests)
     else if (n == "part_per_cu") h->opt_part_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8);
@@ -3071,21 +3073,29 @@ redo_sets:
         size_t o_aggs = off_aggs, o_parts = off_parts, o_rep = off_rep;  // layout of the host copy
         h->stats.topk_candidates = 0;
         if (!spec_hit) {
-            HIP_TRY(h, h->d_out.ensure(total + 16));
+            const uint64_t keep = pl.limit >= 0 ? (uint64_t)pl.offset + (uint64_t)pl.limit : ng;
+            const bool topk = pl.has_order && pl.limit >= 0 && !pl.has_having && pl.order[0].proj_index < 0 && keep > 0 && keep < ng &&
+                              ng >= h->opt_topk_min_groups && ng < (1ull << 32);
+            // groups kept in their compact region + a top-k filter: only the first ORDER BY term's value of every group is
+            // written (16 B per group, not the whole output row), the candidates' rows are finalised after the selection
+            const bool lean = topk && h->pending.count && h->opt_lean_topk;
+            HIP_TRY(h, h->d_out.ensure((lean ? ng * sizeof(OutValue) : total) + 16));
             char* d = h->d_out.p;
             if (h->out_count_dirty) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
             h->out_count_dirty = true;  // (reopen zeroes every counter in its one launch)
-            if (h->pending.count)
+            if (lean)
+                HIP_TRY(h, launch_finalize_region(h->prog, h->d_emit.p, h->pending.cap, ng, nullptr, nullptr, nullptr, nullptr, h->d_errp,
+                                                  h->stream, nullptr, (OutValue*)d, pl.order[0].key_index >= 0,
+                                                  (uint32_t)(pl.order[0].key_index >= 0 ? pl.order[0].key_index : pl.order[0].agg_index)));
+            else if (h->pending.count)
                 HIP_TRY(h, launch_finalize_region(h->prog, h->d_emit.p, h->pending.cap, ng, (OutValue*)d, (OutValue*)(d + off_aggs),
                                                   (OutPartial*)(d + off_parts), (uint64_t*)(d + off_rep), h->d_errp, h->stream));
             else
                 HIP_TRY(h, launch_finalize(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
                                            (uint64_t*)(d + off_rep), h->d_counters.p + 2, ng, h->d_errp, h->stream));
-            const uint64_t keep = pl.limit >= 0 ? (uint64_t)pl.offset + (uint64_t)pl.limit : ng;
             size_t copy_bytes = total;
             const char* src = d;
-            if (pl.has_order && pl.limit >= 0 && !pl.has_having && pl.order[0].proj_index < 0 && keep > 0 && keep < ng &&
-                ng >= h->opt_topk_min_groups && ng < (1ull << 32)) {
+            if (topk) {
                 // ORDER BY ... LIMIT: only the groups that can be among the first offset+limit rows leave the device
                 const OrderTerm& t0 = pl.order[0];
                 HIP_TRY(h, h->d_images.ensure(ng));
@@ -3093,9 +3103,9 @@ redo_sets:
                 HIP_TRY(h, h->d_topk.ensure(topk_state_bytes()));
                 n1k_status rst = ensure_rank(h);
                 if (rst != N1K_OK) return rst;
-                const OutValue* vals = t0.key_index >= 0 ? (const OutValue*)d : (const OutValue*)(d + off_aggs);
-                HIP_TRY(h, launch_topk_select(h->prog, vals, t0.key_index >= 0 ? nk : na,
-                                              (uint32_t)(t0.key_index >= 0 ? t0.key_index : t0.agg_index), ng, t0.desc, keep,
+                const OutValue* vals = lean || t0.key_index >= 0 ? (const OutValue*)d : (const OutValue*)(d + off_aggs);
+                HIP_TRY(h, launch_topk_select(h->prog, vals, lean ? 1u : (t0.key_index >= 0 ? nk : na),
+                                              lean ? 0u : (uint32_t)(t0.key_index >= 0 ? t0.key_index : t0.agg_index), ng, t0.desc, keep,
                                               h->d_images.p, h->d_topk.p, h->d_cand.p, h->stream));
                 unsigned long long ncand = 0;
                 HIP_TRY(h, hipMemcpyAsync(&ncand, h->d_topk.p + topk_ncand_offset(), sizeof ncand, hipMemcpyDeviceToHost, h->stream));
@@ -3106,9 +3116,13 @@ redo_sets:
                 copy_bytes = o_rep + ncand * 8;
                 HIP_TRY(h, h->d_out2.ensure(copy_bytes + 16));
                 char* c = h->d_out2.p;
-                HIP_TRY(h, launch_topk_compact(h->d_cand.p, ncand, nk, na, (const OutValue*)d, (const OutValue*)(d + off_aggs),
-                                               (const OutPartial*)(d + off_parts), (const uint64_t*)(d + off_rep), (OutValue*)c,
-                                               (OutValue*)(c + o_aggs), (OutPartial*)(c + o_parts), (uint64_t*)(c + o_rep), h->stream));
+                if (lean)
+                    HIP_TRY(h, launch_finalize_region(h->prog, h->d_emit.p, h->pending.cap, ncand, (OutValue*)c, (OutValue*)(c + o_aggs),
+                                                      (OutPartial*)(c + o_parts), (uint64_t*)(c + o_rep), h->d_errp, h->stream, h->d_cand.p));
+                else
+                    HIP_TRY(h, launch_topk_compact(h->d_cand.p, ncand, nk, na, (const OutValue*)d, (const OutValue*)(d + off_aggs),
+                                                   (const OutPartial*)(d + off_parts), (const uint64_t*)(d + off_rep), (OutValue*)c,
+                                                   (OutValue*)(c + o_aggs), (OutPartial*)(c + o_parts), (uint64_t*)(c + o_rep), h->stream));
                 src = c;
                 h->stats.topk_candidates = ncand;
                 ng = ncand;

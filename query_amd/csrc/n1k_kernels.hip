@@ -1814,24 +1814,47 @@ __global__ __launch_bounds__(256) void finalize_kernel(const Program P, const Gl
 }
 
 // FinalGroup straight from a region of partial groups with unique keys ([count][0][keys: cap][accumulators]): record i
-// is output row i (no table, no position counter)
+// is output row i (no table, no position counter).  Two lean forms for ORDER BY ... LIMIT over millions of groups (only
+// the top-k candidates need rows; writing every group's row was 0.72 GB per 6.4 M groups):
+//   ord != nullptr   every group is finalised (errors are raised as ever) but only the value of the first ORDER BY term
+//                    is stored, ord[i] — what the top-k selection reads;
+//   cand != nullptr  the groups cand[0 .. count) only, group cand[j] as output row j.
 __global__ void finalize_region_kernel(const Program P, const uint64_t* region, uint64_t cap, uint64_t count, OutValue* out_keys,
-                                       OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+                                       OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags,
+                                       const uint32_t* cand, OutValue* ord, uint32_t ord_is_key, uint32_t ord_index) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const uint64_t i = cand ? (uint64_t)cand[j] : j;
     const uint64_t key = region[2 + i];
+    const uint64_t* g = region + 2 + cap + i * P.glob_words;
+    if (ord) {
+        OutValue v;
+        OutPartial part;
+        for (uint32_t a = 0; a < P.naggs; a++) {
+            finalize_agg(P, P.aggs[a], g, &v, &part, err_flags);
+            if (!ord_is_key && a == ord_index) ord[i] = v;
+        }
+        if (ord_is_key) {
+            const KeySpec& ks = P.keys[ord_index];
+            uint64_t field = ks.bits >= 64 ? key : ((key >> ks.shift) & ((1ull << ks.bits) - 1ull));
+            uint32_t tag;
+            uint64_t p;
+            unpack_key_field(P, ks.mode, field, tag, p);
+            put_value(&ord[i], tag, p);
+        }
+        return;
+    }
     for (uint32_t k = 0; k < P.nkeys; k++) {
         const KeySpec& ks = P.keys[k];
         uint64_t field = ks.bits >= 64 ? key : ((key >> ks.shift) & ((1ull << ks.bits) - 1ull));
         uint32_t tag;
         uint64_t p;
         unpack_key_field(P, ks.mode, field, tag, p);
-        put_value(&out_keys[i * P.nkeys + k], tag, p);
+        put_value(&out_keys[j * P.nkeys + k], tag, p);
     }
-    const uint64_t* g = region + 2 + cap + i * P.glob_words;
     for (uint32_t a = 0; a < P.naggs; a++)
-        finalize_agg(P, P.aggs[a], g, &out_aggs[i * P.naggs + a], &out_parts[i * P.naggs + a], err_flags);
-    if (out_rep) out_rep[i] = ~0ull;
+        finalize_agg(P, P.aggs[a], g, &out_aggs[j * P.naggs + a], &out_parts[j * P.naggs + a], err_flags);
+    if (out_rep) out_rep[j] = ~0ull;
 }
 
 // ------------------------------------------------------------------ high-cardinality GROUP BY: partition, then LDS
@@ -2160,21 +2183,51 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const uint64_t* images, 
     if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
+// one wave: lane l owns bins 4l .. 4l + 3 (a serial walk over 256 dependent global loads took 15 us per pass, eight passes
+// per query)
 __global__ void topk_pick_kernel(uint32_t pass, TopkState* st) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const uint32_t lane = threadIdx.x;
     const uint32_t shift = 56 - 8 * pass;
-    unsigned long long rem = st->remaining, run = 0;
-    uint32_t d = 255;
-    for (uint32_t b = 0; b < 256; b++) {
-        if (run + st->hist[b] >= rem) {
-            d = b;
-            break;
-        }
-        run += st->hist[b];
+    const unsigned long long rem = st->remaining;
+    unsigned long long c[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        c[k] = st->hist[lane * 4 + k];
+        mine += c[k];
     }
-    st->prefix |= (unsigned long long)d << shift;
-    st->remaining = rem - run;
-    for (uint32_t b = 0; b < 256; b++) st->hist[b] = 0;
+    unsigned long long incl = mine;  // bins before and including this lane's
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += t;
+    }
+    unsigned long long run = incl - mine;  // images in the bins before this lane's
+    // the first bin b with (images in bins <= b) >= rem; none (rem beyond the total): bin 255, as the serial walk did
+    uint32_t d = 256;
+    unsigned long long before = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (d == 256 && run + c[k] >= rem) {
+            d = lane * 4 + k;
+            before = run;
+        }
+        run += c[k];
+    }
+    const unsigned long long found = __ballot(d != 256);
+    const int src = found ? __ffsll((long long)found) - 1 : 63;
+    uint32_t dd = (uint32_t)__shfl((int)d, src, 64);
+    unsigned long long bb = __shfl(before, src, 64);
+    const unsigned long long total = __shfl(incl, 63, 64);
+    if (!found) {  // (rem beyond the total: what the serial walk left behind)
+        dd = 255;
+        bb = total;
+    }
+    if (lane == 0) {
+        st->prefix |= (unsigned long long)dd << shift;
+        st->remaining = rem - bb;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) st->hist[lane * 4 + k] = 0;
 }
 
 __global__ void topk_gather_kernel(const uint64_t* images, uint64_t n, TopkState* st, uint32_t* cand) {
@@ -2438,10 +2491,11 @@ hipError_t launch_add_counter(unsigned long long* p, unsigned long long v, hipSt
 }
 
 hipError_t launch_finalize_region(const Program& P, const uint64_t* region, uint64_t cap, uint64_t count, OutValue* out_keys,
-                                  OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags, hipStream_t st) {
+                                  OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags, hipStream_t st,
+                                  const uint32_t* cand, OutValue* ord, bool ord_is_key, uint32_t ord_index) {
     if (!count) return hipSuccess;
     hipLaunchKernelGGL(finalize_region_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, st, P, region, cap, count,
-                       out_keys, out_aggs, out_parts, out_rep, err_flags);
+                       out_keys, out_aggs, out_parts, out_rep, err_flags, cand, ord, ord_is_key ? 1u : 0u, ord_index);
     return hipGetLastError();
 }
 

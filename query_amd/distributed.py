@@ -352,6 +352,29 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    # the row all-to-all is the reported configuration; the partial-group exchange (G groups travel instead of
+    # the rows) is measured next to it as the ablation, in the same run and with the same barriers
+    ablation = None
+    if info.get("mode") == "rows" and not op.has_distinct and not getattr(args, "no_ablation", False):
+        try:
+            for _ in range(args.warmup):
+                ares, ainfo = op.run_gathered(rows, cols.by_path)
+            torch.cuda.synchronize()
+            dist.barrier()
+            ta = time.perf_counter()
+            for i in range(args.steps):
+                ares, ainfo = op.run_gathered(rows, cols.by_path)
+            torch.cuda.synchronize()
+            dist.barrier()
+            ael = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+            dist.all_reduce(ael, op=dist.ReduceOp.MAX)
+            ael = float(ael.item())
+            ablation = {"exchange": ainfo.get("mode"), "value": total_rows * args.steps / ael, "unit": "rows/s",
+                        "ms_per_step": ael / args.steps * 1e3, "groups": int(ares["ngroups"]),
+                        "what": "the same query with per-GPU partial groups exchanged instead of rows (SURVEY 8e's alternative for "
+                                "low-cardinality keys); not the reported value"}
+        except Exception as e:  # never costs the headline line
+            ablation = {"error": repr(e)[:200]}
     if rank == 0:
         how = {"gathered partials": "per-GPU partial groups merged after ONE RCCL all-gather (every rank holds the result)",
                "partials": "partial groups hash-partitioned on the group key by ONE RCCL all-to-all, final groups all-gathered",
@@ -382,6 +405,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                "frac": ach / bench.HBM_PEAK_GBS, "traffic": None, "kernel_ms": info["scan_ms"],
                                "kernel": "rank 0: partition_kernel (Filter + hash partition of the shard)" if info.get("mode", "").startswith("rows")
                                else "rank 0: scan kernel of the shard", "algorithmic_bytes_per_launch": alg}
+        if ablation is not None:
+            out["ablation_partial_groups"] = ablation
         if not args.no_cpu:
             out["cpu_baseline"] = bench.cpu_baseline(wl, args.kcat, bool(args.zipf), total_rows, min(args.cpu_sample, total_rows))
         print(json.dumps(out))

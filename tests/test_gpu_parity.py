@@ -859,6 +859,24 @@ def test_device_topk_filter_feeds_the_exact_order(order, limit, offset):
     assert 0 < stats["topk_candidates"] < len(ora.keys)
 
 
+@pytest.mark.parametrize("lean", [1, 0], ids=["order-values-first", "every-row"])
+@pytest.mark.parametrize("order,limit,offset", [
+    ([("sum(%s)" % D("price"), True)], 100, None),
+    ([(D("cat"), True), (D("region_id"), False)], 50, 0),        # a key term: its value is unpacked from the packed key
+    ([("count(*)", False), (D("cat"), True)], 30, 10),
+])
+def test_topk_over_the_partitioned_paths_kept_region(order, limit, offset, lean):
+    """ORDER BY ... LIMIT over groups that stayed in the partitioned path's compact region (one batch, nothing else in
+    the handle): FinalGroup first writes only the first term's value of every group, the top-k filter picks the
+    candidates, and only their rows are finalised (lean_topk, default) — same rows as finalising every group."""
+    t = n1o.synth_table(150_000, k_cat=120)
+    ora = n1o.run(t, None, ORDER_KEYS, ORDER_AGGS, threads=2)
+    gpu, stats = pu.run_gpu(t, None, ORDER_KEYS, ORDER_AGGS, order=order, limit=limit, offset=offset, topk_min_groups=1,
+                            agg_mode=4, lean_topk=lean)
+    pu.assert_ordered_groups(gpu, ora, ORDER_KEYS, ORDER_AGGS, order, limit, offset)
+    assert stats["agg_mode"] == 4 and 0 < stats["topk_candidates"] < len(ora.keys)
+
+
 PART_AGGS = sorted(["sum(%s)" % D("price"), "count(*)", "min(%s)" % D("price"), "avg(%s)" % D("price"),
                     "max(%s)" % D("region_id"), "countn(%s)" % D("price")])
 
