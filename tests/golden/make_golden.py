@@ -347,6 +347,51 @@ def main():
            ("mult", "(9007199254740993 * 1)"), ("neg", "(-9007199254740993)"), ("sub", "(9007199254740993 - 0)")])
     ex(2, [("idiv", "idiv(5, 2)"), ("div", "(5 / 2)"), ("imod", "imod(5, 2)"), ("idiv_zero", "idiv(5, 0)"),
            ("imod_zero", "imod(5, 0)")])
+    # ---------------------------------------------------------------- G7: filestore case_func_num.json (numeric functions)
+    # ROUND / TRUNC / ABS / CEIL / FLOOR / SIGN / SQRT (expression/func_num.go) are arithmetic nodes of the path (WHERE and
+    # aggregate operands, projection over the groups): the constant cases as expression cases, the per-document ones
+    # (`SELECT f(score + 0.5) AS x FROM default:game ORDER BY x`) as "row_expr" cases: one value per document, ascending.
+    # (Left out: trigonometry / EXP / LN / POWER / RANDOM / DEGREES — not in the device subset — and the NaN() / PosInf() /
+    #  NegInf() argument cases, whose argument functions are not.)
+    g7 = "filestore/case_func_num.json"
+    cnum = cases_of(os.path.join(FS, "cases/case_func_num.json"))
+
+    def exn(idx, text):
+        c = cnum[idx]
+        alias = list(c["results"][0].keys())[0]
+        cases.append({"id": "%s#%d" % (g7, idx), "source": g7, "index": idx, "statement": c["statements"], "keyspace": "game",
+                      "plan": {"exprs": [[alias, text]]}, "post": {}, "results": c["results"]})
+
+    def rown(idx, text):
+        c = cnum[idx]
+        alias = list(c["results"][0].keys())[0]
+        cases.append({"id": "%s#%d" % (g7, idx), "source": g7, "index": idx, "statement": c["statements"], "keyspace": "game",
+                      "plan": {"row_expr": [alias, text]}, "post": {}, "results": c["results"]})
+
+    sc = F("game", "score")
+    exn(0, "abs(-4.599)")
+    exn(1, "abs(0.0)")
+    exn(17, "ceil(1.4)")
+    rown(18, "ceil((%s + 0.5))" % sc)
+    rown(33, "floor((%s + 0.5))" % sc)
+    exn(34, "floor(1.7)")
+    rown(40, "round((%s + 0.5))" % sc)
+    exn(41, "round(1.2343534)")
+    exn(42, "round(1.8343534)")
+    exn(43, "round(1.8343534, 0)")
+    exn(44, "round(1.8343534, 3)")
+    exn(45, "round(8.8343534, -1)")
+    exn(46, "round(1.8343534, -1)")
+    exn(47, "sign(-1034.992445)")
+    exn(48, "sign(1034.992445)")
+    exn(49, "sign(0.292445)")
+    exn(50, "sign(0.0000111)")
+    exn(51, "sign(0.0)")
+    rown(55, "trunc((%s + 0.5))" % sc)
+    rown(56, "sqrt(%s)" % sc)
+    exn(57, "sqrt(0)")
+    exn(59, "trunc(-2.2544, 2)")
+    exn(60, "trunc(0.2544, 3)")
     # contact alias differs in case 8 ("FROM default:contacts AS contact")
     used = sorted({c["keyspace"] for c in cases})
     with open(os.path.join(OUT, "cases.json"), "w") as fh:

@@ -477,3 +477,9 @@ def same_json(a, b, rel=0.0) -> bool:
 
 def groups_from_result(res) -> List[tuple]:
     return [([decode_value(k) for k in ks], [decode_value(a) for a in ag]) for ks, ag in zip(res.keys, res.aggs)]
+
+
+def sorted_values(alias: str, values: Sequence[Any]) -> List[dict]:
+    """[{alias: v}] in value.Collate order (execution/order.go:121-169): the result rows of SELECT expr AS alias ... ORDER BY alias."""
+    import functools
+    return [{alias: v} for v in sorted(values, key=functools.cmp_to_key(collate))]

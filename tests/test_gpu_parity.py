@@ -34,6 +34,17 @@ def test_golden_cases_on_device(case):
                 got[0].update({alias: gu.decode_value(tv) for (alias, _t), tv in zip(part, rows.keys[0])})
             assert gu.same_json(got, case["results"]), (got, case["results"])
             return
+        if "row_expr" in plan:
+            # one value per document (case_func_num.json): the expression as the operand of MAX, one group per document —
+            # the device's arith_apply (derived column here; test_fused_* run the same code inside the scan)
+            alias, text = plan["row_expr"]
+            idp = "(`game`.`id`)"
+            table = gu.build_table(docs, gu.leaf_paths({"condition": None, "group_keys": [idp, text], "aggregates": []}))
+            rows, _ = pu.run_gpu(table, None, [idp], ["max(%s)" % text])
+            assert len(rows.keys) == len(docs)
+            got = gu.sorted_values(alias, [gu.decode_value(a[0]) for a in rows.aggs])
+            assert gu.same_json(got, case["results"]), (got, case["results"])
+            return
         table = gu.build_table(docs, gu.leaf_paths(plan))
         if plan.get("filter_only"):
             rows, _ = pu.run_gpu(table, plan["condition"], [], [], filter_only=True)

@@ -22,6 +22,12 @@ def test_oracle_matches_reference_golden(case, threads):
         got = [{alias: gu.decode_value(n1o.eval_expr(one, text)[0]) for alias, text in plan["exprs"]}]
         assert gu.same_json(got, case["results"]), (got, case["results"])
         return
+    if "row_expr" in plan:  # one value per document, ascending (case_func_num.json: SELECT f(score + 0.5) AS x ... ORDER BY x)
+        alias, text = plan["row_expr"]
+        table = gu.build_table(docs, gu.leaf_paths({"condition": None, "group_keys": [text], "aggregates": []}))
+        got = gu.sorted_values(alias, [gu.decode_value(tv) for tv in n1o.eval_expr(table, text)])
+        assert gu.same_json(got, case["results"]), (got, case["results"])
+        return
     table = gu.build_table(docs, gu.leaf_paths(plan))
     if plan.get("filter_only"):
         res = n1o.run(table, plan["condition"], [], [], has_group=False)
