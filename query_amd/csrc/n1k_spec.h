@@ -645,6 +645,17 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
         // (the next tile writes pre / gbase / total / the staging arrays only behind its first barrier, which every wave
         //  reaches after it has left this loop)
     };
+#ifdef N1K_PART_NOPIPE  // (tuning experiments: one tile in flight, fewer registers, more workgroups per CU)
+    for (uint32_t base = blockIdx.x * tile; base < nitems; base += gridDim.x * tile) {
+        uint32_t tg[R][kRowsPerItem][kSpecCols];
+        uint64_t pv[R][kRowsPerItem][kSpecCols];
+        bool valid[R];
+        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
+        process(tg, pv, valid, base);
+    }
+    if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+    return;
+#endif
     uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
     uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
     bool vA[R], vB[R];

@@ -246,7 +246,7 @@ class ShardedFilterGroup:
     # ------------------------------------------------------------------ exchange of rows
     def run_rows(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
         """n1k_exchange_rows: Filter + hash partition + ONE all-to-all + InitialGroup on the owner, then the gather.  The
-        first step ships regions sized for the whole shard; later steps for what the owners really received (+ 30 %)."""
+        first step ships regions sized for the whole shard; later steps for what the owners really received (+ 10 %)."""
         from query_amd import _ffi
         from query_amd.gpu_operator import N1kError
         snd, rcv, lib = self.sender, self.receiver, self.sender._lib
@@ -266,7 +266,9 @@ class ShardedFilterGroup:
             break
         if self.row_capacity is None:
             got = self._max(rcv, int(rcv.stats()["rows_selected"]))
-            self.row_capacity = min(cap, max(4096, int(got / self.world * 1.3) + 4096)) if self.world > 1 else max(4096, int(got * 1.02) + 4096)
+            # `got` is the LARGEST owner's total, and every source sees the same split of the keys over the owners: a source's
+            # region for that owner holds about got / world rows (+ 10 %: shards are not identical; an overflow doubles it)
+            self.row_capacity = min(cap, max(4096, int(got / self.world * 1.1) + 4096)) if self.world > 1 else max(4096, int(got * 1.02) + 4096)
         stats = snd.stats()
         return self._gather(rcv, raw), {"mode": "rows", "region_rows": cap, "scan_ms": float(stats["device_ms"]),
                                         "recv_rows": int(rcv.stats()["rows_selected"])}
