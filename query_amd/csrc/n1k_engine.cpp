@@ -89,7 +89,7 @@ struct n1k_handle {
     uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
     uint64_t opt_jit_min_rows = 4u << 20;
     uint32_t opt_lean_topk = 1;    // ORDER BY ... LIMIT over a kept region: order values first, rows for the candidates only
-    uint32_t opt_part_block = 256; // workgroup size of the run-time-built partition kernel (256 | 512; measured 0.49 vs 0.58 ms per 100 M rows)
+    uint32_t opt_part_block = 256; // workgroup size of the run-time-built partition kernel (256 | 512; measured 0.43 vs 0.58 ms per 100 M rows)
     uint32_t opt_part_subs = 1;    // row exchange: sub-regions per destination with their own counters (0: one dense run)
     uint32_t opt_part_per_cu = 0;  // workgroups per CU of the run-time-built partition kernel (0 = 2)
     uint32_t opt_pinned_out = 1;   // speculative FinalGroup writes its (few) groups straight into pinned host memory
@@ -3341,11 +3341,11 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
         F.nrows = (uint32_t)n;
         F.row_base = h->row_base;
         F.err_flags = h->d_errp;
-        // 512-thread workgroups (tiles of 2048 rows, two per CU) or 256-thread ones (1024 rows, five per CU: more independent
-        // workgroups to overlap the wait for each tile's reservation)
+        // 256-thread workgroups (tiles of 1024 rows, one in flight, six per CU: many independent workgroups overlap the wait
+        // for each tile's reservation) or 512-thread ones (2048 rows, two tiles in flight, two per CU)
         const uint32_t pblock = wide && h->opt_part_block == 256 ? 256u : 512u;
         const uint64_t tiles = (n + pblock * 4 - 1) / (pblock * 4);
-        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * (h->opt_part_per_cu ? h->opt_part_per_cu : (pblock == 256 ? 5u : 2u)), tiles));
+        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * (h->opt_part_per_cu ? h->opt_part_per_cu : (pblock == 256 ? 6u : 2u)), tiles));
         // many tiles: every destination's region in kRowSubs sub-regions with their own counters, workgroups dealt round-robin
         // (tile t goes to sub-region t % kRowSubs: an even share of the rows whatever their order)
         if (seg_rows && h->opt_part_subs && (tiles >= 4096 || h->opt_part_subs == 2)) {

@@ -98,14 +98,11 @@ std::string jit_source(const SpecSig& g) {
     if (g.mode == 1) {
         if (const char* a = getenv("N1K_JIT_PART_ATTR")) o << "#define N1K_PART_ATTR " << a << "\n";  // (tuning experiments)
         else o << "#define N1K_PART_ATTR\n";
-        std::string pre = getenv("N1K_JIT_PART_NOPIPE") ? "#define N1K_PART_NOPIPE 1\n" : "";
-        std::string body = o.str();
-        o.str("");
-        o << pre << body;
+
         o << "extern \"C\" __global__ __launch_bounds__(512) N1K_PART_ATTR void n1k_jit_part_wide(const n1k::Program P, const n1k::FastArgs F,\n"
           << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 2, 512, true>(P, F, A);\n}\n"
           << "extern \"C\" __global__ __launch_bounds__(256) N1K_PART_ATTR void n1k_jit_part_wide256(const n1k::Program P, const n1k::FastArgs F,\n"
-          << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 2, 256, true>(P, F, A);\n}\n"
+          << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 2, 256, true, false>(P, F, A);\n}\n"
           << "extern \"C\" __global__ __launch_bounds__(512) N1K_PART_ATTR void n1k_jit_part_narrow(const n1k::Program P, const n1k::FastArgs F,\n"
           << "        const n1k::PartArgs A) {\n    n1k::scan_spec_partition_body<n1k::SpecJ, 4, 512, false>(P, F, A);\n}\n";
         return o.str();

@@ -518,7 +518,10 @@ struct PartLds {
     uint32_t total;
 };
 
-template <class Spec, int R, int BLOCK, bool WIDE>
+// PIPE: two tiles in flight (the next tile's columns requested before this one goes through LDS) — or one, with fewer
+// registers and more workgroups per CU (measured, 100 M rows of config 2: 512 threads x 2 per CU piped 0.58 ms, 256 x 5
+// piped 0.49 ms, 256 x 6 unpiped 0.43 ms).
+template <class Spec, int R, int BLOCK, bool WIDE, bool PIPE = true>
 N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const PartArgs& A) {
     constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
     constexpr int kNW = R * (int)kRowsPerItem;
@@ -645,17 +648,17 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
         // (the next tile writes pre / gbase / total / the staging arrays only behind its first barrier, which every wave
         //  reaches after it has left this loop)
     };
-#ifdef N1K_PART_NOPIPE  // (tuning experiments: one tile in flight, fewer registers, more workgroups per CU)
-    for (uint32_t base = blockIdx.x * tile; base < nitems; base += gridDim.x * tile) {
-        uint32_t tg[R][kRowsPerItem][kSpecCols];
-        uint64_t pv[R][kRowsPerItem][kSpecCols];
-        bool valid[R];
-        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
-        process(tg, pv, valid, base);
+    if constexpr (!PIPE) {
+        for (uint32_t base = blockIdx.x * tile; base < nitems; base += gridDim.x * tile) {
+            uint32_t tg[R][kRowsPerItem][kSpecCols];
+            uint64_t pv[R][kRowsPerItem][kSpecCols];
+            bool valid[R];
+            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
+            process(tg, pv, valid, base);
+        }
+        if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
+        return;
     }
-    if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
-    return;
-#endif
     uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
     uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
     bool vA[R], vB[R];
