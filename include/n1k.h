@@ -410,6 +410,11 @@ n1k_status n1k_merge_groups(n1k_handle *h, const void *blob, size_t len);
 typedef struct n1k_comm n1k_comm;
 n1k_status n1k_comm_unique_id(void *id);
 n1k_status n1k_comm_create(const void *id, int rank, int world, int device, n1k_comm **out);
+/* Loopback transport: `world` communicators (out[0 .. world)) whose ranks are THREADS of this process sharing one device;
+ * every collective is a rendezvous plus device-to-device copies.  For tests of the world_size > 1 paths on a single GPU
+ * (RCCL refuses two ranks on one device) and for hosts that run several operator copies per GPU.  Each rank must be driven
+ * from its own thread (a collective blocks until every rank has entered it). */
+n1k_status n1k_comm_create_loopback(int world, int device, n1k_comm **out);
 void n1k_comm_destroy(n1k_comm *c);
 const char *n1k_comm_last_error(const n1k_comm *c);
 int n1k_comm_rank(const n1k_comm *c);

@@ -74,7 +74,7 @@ SYMBOLS = [
     "n1k_create", "n1k_destroy", "n1k_reset", "n1k_stop", "n1k_last_error", "n1k_create_error", "n1k_num_columns",
     "n1k_column_path", "n1k_num_keys", "n1k_num_aggregates", "n1k_aggregate_name", "n1k_num_projection_terms",
     "n1k_projection_expr", "n1k_projection_alias", "n1k_dict_intern", "n1k_dict_size",
-    "n1k_dict_get", "n1k_set_option", "n1k_push_batch", "n1k_extract_json", "n1k_push_json", "n1k_push_device_batch", "n1k_run_device_batch", "n1k_sync", "n1k_finish",
+    "n1k_dict_get", "n1k_set_option", "n1k_push_batch", "n1k_extract_json", "n1k_push_json", "n1k_push_device_batch", "n1k_run_device_batch", "n1k_comm_create_loopback", "n1k_sync", "n1k_finish",
     "n1k_get_stats", "n1k_partition_device_batch", "n1k_export_groups", "n1k_order_rows", "n1k_merge_groups", "n1k_synth_columns",
     "n1k_jit_check", "n1k_partial_words", "n1k_partial_region_bytes", "n1k_export_partials_device", "n1k_export_partials_async",
     "n1k_merge_partials_device",
@@ -139,6 +139,9 @@ def lib():
     if hasattr(L, "n1k_run_device_batch"):  # (absent from older builds loaded through N1K_LIB for A/B measurements)
         L.n1k_run_device_batch.restype = C.c_int
         L.n1k_run_device_batch.argtypes = [H, C.POINTER(Batch), C.POINTER(Result)]
+    if hasattr(L, "n1k_comm_create_loopback"):
+        L.n1k_comm_create_loopback.restype = C.c_int
+        L.n1k_comm_create_loopback.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.n1k_extract_json.restype = C.c_int
     L.n1k_extract_json.argtypes = [H, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(Batch)]
     L.n1k_push_json.restype = C.c_int

@@ -18,6 +18,8 @@
 #include <functional>
 #include <numeric>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -3554,8 +3556,35 @@ n1k_status n1k_merge_groups(n1k_handle* h, const void* blob, size_t len) {
 
 }  // extern "C" (the communicator struct is C++)
 
+// Loopback transport (n1k_comm_create_loopback): the ranks are threads of ONE process sharing one device — every
+// collective is a rendezvous (barrier), device-to-device copies out of the peers' buffers, and a second rendezvous before
+// anybody reuses its send buffer.  It exists so that the world_size > 1 code paths of the exchange (region offsets, header
+// lists, verdicts, segmented receives, agreed capacities) can be run and checked on a single GPU; RCCL refuses two ranks on
+// one device.
+struct LoopHub {
+    int world = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void*> ptr;
+    std::vector<unsigned long long> val;
+    int refs = 0;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+        } else
+            cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
 struct n1k_comm {
     ncclComm_t comm = nullptr;
+    LoopHub* hub = nullptr;  // non-null: loopback transport
     int rank = 0, world = 1, device = 0;
     DevBuf<char> send, recv, gsend, grecv;
     DevBuf<unsigned long long> scalar;
@@ -3593,7 +3622,43 @@ n1k_status cfail(n1k_comm* c, n1k_status st, const char* fmt, ...) {
 
 // all-to-all of equal regions: region p of `send` goes to rank p, region s of `recv` comes from rank s.  This rank's own
 // region is not copied: the caller reads it where it lies (`self` returns its address).
+// loopback: what every peer published, copied (or read) by everybody between two rendezvous
+template <class Copy>
+n1k_status loop_collective(n1k_comm* c, const void* send, hipStream_t st, Copy copy) {
+    if (hipStreamSynchronize(st) != hipSuccess) return cfail(c, N1K_DEVICE_ERROR, "loopback: stream synchronisation failed");
+    c->hub->ptr[c->rank] = send;
+    c->hub->barrier();  // every rank's send buffer is complete and published
+    hipError_t e = copy();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    c->hub->barrier();  // everybody has read everybody: the send buffers may be overwritten
+    return e == hipSuccess ? N1K_OK : cfail(c, N1K_DEVICE_ERROR, "loopback: copy failed: %s", hipGetErrorString(e));
+}
+
+n1k_status all_gather_bytes(n1k_comm* c, const char* send, char* recv, size_t bytes, hipStream_t st) {
+    if (c->hub)
+        return loop_collective(c, send, st, [&]() -> hipError_t {
+            for (int p = 0; p < c->world; p++) {
+                hipError_t e = hipMemcpyAsync(recv + (size_t)p * bytes, c->hub->ptr[p], bytes, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        });
+    NCCL_TRY(c, ncclAllGather(send, recv, bytes, ncclChar, c->comm, st));
+    return N1K_OK;
+}
+
 n1k_status all_to_all_regions(n1k_comm* c, const char* send, char* recv, size_t region, hipStream_t st, const char** self) {
+    *self = send + (size_t)c->rank * region;
+    if (c->hub)
+        return loop_collective(c, send, st, [&]() -> hipError_t {
+            for (int p = 0; p < c->world; p++) {
+                if (p == c->rank) continue;
+                hipError_t e = hipMemcpyAsync(recv + (size_t)p * region, (const char*)c->hub->ptr[p] + (size_t)c->rank * region, region,
+                                              hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        });
     NCCL_TRY(c, ncclGroupStart());
     for (int p = 0; p < c->world; p++) {
         if (p == c->rank) continue;
@@ -3601,7 +3666,6 @@ n1k_status all_to_all_regions(n1k_comm* c, const char* send, char* recv, size_t 
         NCCL_TRY(c, ncclRecv(recv + (size_t)p * region, region, ncclChar, p, c->comm, st));
     }
     NCCL_TRY(c, ncclGroupEnd());
-    *self = send + (size_t)c->rank * region;
     return N1K_OK;
 }
 
@@ -3703,10 +3767,40 @@ n1k_status n1k_comm_create(const void* id, int rank, int world, int device, n1k_
     });
 }
 
+n1k_status n1k_comm_create_loopback(int world, int device, n1k_comm** out) {
+    return guarded(nullptr, [&]() -> n1k_status {
+        if (!out || world < 1 || world > (int)kMaxParts) return cfail(nullptr, N1K_INVALID, "bad communicator arguments");
+        if (hipSetDevice(device) != hipSuccess) return cfail(nullptr, N1K_DEVICE_ERROR, "no HIP device %d", device);
+        auto* hub = new LoopHub();
+        hub->world = world;
+        hub->ptr.assign(world, nullptr);
+        hub->val.assign(world, 0);
+        hub->refs = world;
+        for (int r = 0; r < world; r++) {
+            auto* c = new n1k_comm();
+            c->rank = r;
+            c->world = world;
+            c->device = device;
+            c->hub = hub;
+            (void)hipEventCreateWithFlags(&c->ev, hipEventDisableTiming);
+            out[r] = c;
+        }
+        return N1K_OK;
+    });
+}
+
 void n1k_comm_destroy(n1k_comm* c) {
     if (!c) return;
     try {
         (void)hipSetDevice(c->device);
+        if (c->hub) {
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(c->hub->mu);
+                last = --c->hub->refs == 0;
+            }
+            if (last) delete c->hub;
+        }
         if (c->comm) (void)ncclCommDestroy(c->comm);
         if (c->ev) (void)hipEventDestroy(c->ev);
         c->send.release();
@@ -3728,6 +3822,15 @@ n1k_status n1k_comm_max_u64(n1k_comm* c, n1k_handle* h, uint64_t value, uint64_t
         if (!c || !h || !out) return N1K_INVALID;
         n1k_status st = ensure_device(h);
         if (st != N1K_OK) return st;
+        if (c->hub) {  // loopback: values through the hub
+            c->hub->val[c->rank] = value;
+            c->hub->barrier();
+            unsigned long long mx = 0;
+            for (int p = 0; p < c->world; p++) mx = std::max(mx, c->hub->val[p]);
+            c->hub->barrier();
+            *out = mx;
+            return N1K_OK;
+        }
         HIP_TRY(h, c->scalar.ensure(4));
         unsigned long long v = value, m = 0;
         HIP_TRY(h, hipMemcpyAsync(c->scalar.p, &v, 8, hipMemcpyHostToDevice, h->stream));
@@ -3752,7 +3855,8 @@ n1k_status n1k_exchange_partials(n1k_comm* c, n1k_handle* sender, n1k_handle* re
         if (st != N1K_OK) return st;
         if (gathered) {
             // every rank ends with every rank's partial groups: no second collective for the result
-            NCCL_TRY(c, ncclAllGather(c->send.p, c->recv.p, region, ncclChar, c->comm, sender->stream));
+            st = all_gather_bytes(c, c->send.p, c->recv.p, region, sender->stream);
+            if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
         } else {
             const char* self = nullptr;
             st = all_to_all_regions(c, c->send.p, c->recv.p, region, sender->stream, &self);
@@ -3887,7 +3991,8 @@ n1k_status n1k_gather_groups(n1k_comm* c, n1k_handle* h, const n1k_result* local
             HIP_TRY(h, c->gsend.ensure(slot));
             HIP_TRY(h, c->grecv.ensure(slot * (size_t)c->world));
             HIP_TRY(h, hipMemcpyAsync(c->gsend.p, stage.data(), slot, hipMemcpyHostToDevice, h->stream));
-            NCCL_TRY(c, ncclAllGather(c->gsend.p, c->grecv.p, slot, ncclChar, c->comm, h->stream));
+            st = all_gather_bytes(c, c->gsend.p, c->grecv.p, slot, h->stream);
+            if (st != N1K_OK) return fail(h, st, "%s", c->last_error.c_str());
             c->ghost.resize(slot * (size_t)c->world);
             HIP_TRY(h, hipMemcpyAsync(c->ghost.data(), c->grecv.p, c->ghost.size(), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -145,6 +145,23 @@ class Comm:
             raise RuntimeError("n1k_comm_create failed: %s" % (self._lib.n1k_comm_last_error(None) or b"").decode())
         self.rank, self.world = rank, world
 
+    @classmethod
+    def loopback(cls, world: int, device: int) -> "List[Comm]":
+        """n1k_comm_create_loopback: `world` communicators whose ranks are threads of this process on one device (tests of
+        the world_size > 1 paths on a single GPU: drive every rank from its own thread)."""
+        from query_amd import _ffi
+        lib = _ffi.lib()
+        arr = (C.c_void_p * world)()
+        st = lib.n1k_comm_create_loopback(world, device, arr)
+        if st != 0:
+            raise RuntimeError("n1k_comm_create_loopback failed: %s" % (lib.n1k_comm_last_error(None) or b"").decode())
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c._lib, c._h, c.rank, c.world = lib, C.c_void_p(arr[r]), r, world
+            out.append(c)
+        return out
+
     def done(self):
         if self._h:
             self._lib.n1k_comm_destroy(self._h)

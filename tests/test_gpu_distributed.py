@@ -319,3 +319,82 @@ def test_row_exchange_20m_rows_subregions_world1(workload):
         pu.assert_same_groups(GroupRows(1, len(aggs), gk, ga, []), ora, aggs=aggs)
     finally:
         dist.destroy_process_group()
+
+
+def _run_ranks(world, fn):
+    """Drive `world` ranks from their own threads (the loopback transport blocks in every collective until all ranks are in)."""
+    import threading
+    errs, outs = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            outs[r] = fn(r)
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errs[r] = e
+
+    ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in ts), "a rank is stuck in a collective"
+    for e in errs:
+        if e is not None:
+            raise e
+    return outs
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,jit,subs", [(2, 0, 1), (2, 2, 2), (4, 2, 2), (3, 2, 1)],
+                         ids=["w2-interpreter", "w2-runtime-built-subregions", "w4-runtime-built-subregions", "w3-runtime-built-dense"])
+def test_world_size_n_exchanges_over_the_loopback_transport(world, jit, subs):
+    """The world_size > 1 paths of n1k_exchange_rows / n1k_exchange_partials / n1k_gather_groups on ONE GPU: the ranks are
+    threads over the loopback transport (n1k_comm_create_loopback: rendezvous + device copies instead of RCCL, which
+    refuses two ranks on one device).  Every rank shards one table, and every rank must end with the oracle's groups of the
+    whole table — through the row exchange (region offsets per destination, header lists, sub-regions, segmented receive,
+    capacities agreed through n1k_comm_max_u64), the hash-partitioned partial groups and the gathered partial groups."""
+    from query_amd import distributed as qd
+    from query_amd.gpu_operator import GroupRows
+    n = 240_007
+    t = n1o.synth_table(n, k_cat=61, zipf=True)
+    aggs = sorted(["count(*)", "sum(%s)" % D("price"), "max(%s)" % D("price")])
+    ora = n1o.run(t, COND, KEYS, aggs)
+    comms = qd.Comm.loopback(world, 0)
+    by = {c.name: c for c in t.columns}
+    shards, keep = [], []
+    probe = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, KEYS, aggs))
+    paths = probe.column_paths
+    probe.done()
+    for r in range(world):
+        lo, hi = n * r // world, n * (r + 1) // world
+        sub = n1o.Table([n1o.Column(c.name, c.kind, tags=None if c.tags is None else c.tags[lo:hi],
+                                    payload=None if c.payload is None else c.payload[lo:hi],
+                                    codes=None if c.codes is None else c.codes[lo:hi]) for c in t.columns], t.dictionary)
+        dev, k = _device_cols(sub, paths)
+        keep.append(k)
+        shards.append((hi - lo, dev))
+
+    def rank_body(r):
+        op = qd.ShardedFilterGroup(COND, KEYS, aggs, t.dictionary, r, world, 0, comm=comms[r])
+        for h in (op.sender, op.receiver):
+            h.set_option("jit", jit)
+        op.sender.set_option("part_subs", subs)
+        if subs == 2:
+            op.row_capacity = 2 * n  # (few tiles dealt unevenly over the sub-regions: generous regions)
+        rows_n, dev = shards[r]
+        got = {}
+        for mode, fn in (("rows", op.run_rows), ("partials", op.run_partials), ("gathered", op.run_gathered)):
+            for _ in range(2):
+                raw, info = fn(rows_n, dev)
+            cache = {}
+            got[mode] = (GroupRows(1, len(aggs), op.merger._py_values(raw["keys"], cache), op.merger._py_values(raw["aggs"], cache), []), info)
+        return got
+
+    outs = _run_ranks(world, rank_body)
+    for r in range(world):
+        for mode in ("rows", "partials", "gathered"):
+            rows, info = outs[r][mode]
+            pu.assert_same_groups(rows, ora, aggs=aggs)
+        assert outs[r]["rows"][1]["mode"] == "rows"
+    # every survivor arrived at exactly one owner
+    assert sum(outs[r]["rows"][1]["recv_rows"] for r in range(world)) == ora.rows_passed
