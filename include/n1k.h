@@ -424,6 +424,11 @@ n1k_status n1k_comm_max_u64(n1k_comm *c, n1k_handle *h, uint64_t value, uint64_t
 n1k_status n1k_exchange_partials(n1k_comm *c, n1k_handle *sender, n1k_handle *receiver, uint64_t capacity_groups, int gathered);
 n1k_status n1k_exchange_rows(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver, uint64_t capacity_rows);
 n1k_status n1k_gather_groups(n1k_comm *c, n1k_handle *h, const n1k_result *local, n1k_result *out);
+/* The same, carrying every rank's verdict on its own step: a rank whose n1k_finish failed (data its shard alone holds, say)
+ * still enters the collective with local_status != N1K_OK (local may be NULL) instead of leaving its peers waiting in it;
+ * every rank gets the first failing rank's status in *worst_status (N1K_OK: `out` holds the gathered groups). */
+n1k_status n1k_gather_groups_status(n1k_comm *c, n1k_handle *h, const n1k_result *local, int local_status, n1k_result *out,
+                                    int *worst_status);
 
 /* ------------------------------------------------------------- utilities -- */
 

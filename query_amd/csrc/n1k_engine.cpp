@@ -3965,8 +3965,18 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
 }
 
 n1k_status n1k_gather_groups(n1k_comm* c, n1k_handle* h, const n1k_result* local, n1k_result* out) {
+    int worst = 0;
+    n1k_status st = n1k_gather_groups_status(c, h, local, N1K_OK, out, &worst);
+    if (st == N1K_OK && worst != N1K_OK) return fail(h, (n1k_status)worst, "a peer rank's step failed with status %d", worst);
+    return st;
+}
+
+n1k_status n1k_gather_groups_status(n1k_comm* c, n1k_handle* h, const n1k_result* local, int local_status, n1k_result* out, int* worst_status) {
     return guarded(h, [&]() -> n1k_status {
-        if (!c || !h || !local || !out) return N1K_INVALID;
+        if (!c || !h || !out || !worst_status || (!local && local_status == N1K_OK)) return N1K_INVALID;
+        *worst_status = local_status;
+        static const n1k_result kNone{};
+        if (!local || local_status != N1K_OK) local = &kNone;  // a rank whose step failed contributes no groups, only its status
         if (h->has_array_agg) return fail(h, N1K_UNSUPPORTED, "array_agg values are interned per rank: gather the rows on the host");
         n1k_status st = ensure_device(h);
         if (st != N1K_OK) return st;
@@ -3983,6 +3993,8 @@ n1k_status n1k_gather_groups(n1k_comm* c, n1k_handle* h, const n1k_result* local
             slot = 16 + (size_t)capg * rec;
             stage.assign(slot, 0);
             memcpy(stage.data(), &mine, 8);
+            const unsigned long long my_status = (unsigned long long)(unsigned)local_status;
+            memcpy(stage.data() + 8, &my_status, 8);
             for (uint64_t g = 0; g < std::min<uint64_t>(local->ngroups, capg); g++) {
                 char* p = stage.data() + 16 + (size_t)g * rec;
                 if (nk) memcpy(p, local->keys + g * nk, nk * sizeof(n1k_value));
@@ -3996,11 +4008,18 @@ n1k_status n1k_gather_groups(n1k_comm* c, n1k_handle* h, const n1k_result* local
             c->ghost.resize(slot * (size_t)c->world);
             HIP_TRY(h, hipMemcpyAsync(c->ghost.data(), c->grecv.p, c->ghost.size(), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
-            unsigned long long most = 0;
+            unsigned long long most = 0, bad = 0;
             for (int r = 0; r < c->world; r++) {
-                unsigned long long n = 0;
+                unsigned long long n = 0, s = 0;
                 memcpy(&n, c->ghost.data() + (size_t)r * slot, 8);
+                memcpy(&s, c->ghost.data() + (size_t)r * slot + 8, 8);
                 most = std::max(most, n);
+                if (s && !bad) bad = s;  // (the lowest rank's failure: the same on every rank)
+            }
+            if (bad) {  // some rank's step failed: every rank learns it here, in the collective it would otherwise hang in
+                *worst_status = (int)bad;
+                memset(out, 0, sizeof *out);
+                return N1K_OK;
             }
             if (most <= capg) break;
             while (c->gather_cap < most) c->gather_cap *= 2;

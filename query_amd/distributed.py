@@ -223,6 +223,7 @@ class ShardedFilterGroup:
         from query_amd import _ffi
         from query_amd.gpu_operator import N1kError
         snd, lib = self.sender, self.sender._lib
+        failed = None
         while True:
             snd.reopen()
             snd.process_device_batch(self._batch(nrows, cols_by_path))
@@ -250,12 +251,15 @@ class ShardedFilterGroup:
                     raw, info = self.run_rows(nrows, cols_by_path)
                     info["mode"] = "rows (wide key values)"
                     return raw, info
-                raise
+                if gathered:
+                    raise  # (every rank merged the same regions: the same error everywhere)
+                failed = e  # this owner's share alone failed: the peers learn it in the gather instead of waiting there
+                raw = None
             break
         stats = snd.stats()
         info = {"mode": "gathered partials" if gathered else "partials", "region_bytes": region,
                 "scan_ms": float(stats["device_ms"]), "spec_kernel": int(stats["spec_kernel"])}
-        return (raw, info) if gathered else (self._gather(rcv, raw), info)
+        return (raw, info) if gathered else (self._gather(rcv, raw, failed), info)
 
     def run_gathered(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
         return self.run_partials(nrows, cols_by_path, replicate=True)
@@ -268,6 +272,7 @@ class ShardedFilterGroup:
         from query_amd.gpu_operator import N1kError
         snd, rcv, lib = self.sender, self.receiver, self.sender._lib
         batch = self._batch(nrows, cols_by_path)
+        failed = None
         while True:
             cap = self.row_capacity if self.row_capacity is not None else max(4096, int(nrows * 1.1 / self.world) + 4096)
             rcv.reopen()
@@ -279,7 +284,8 @@ class ShardedFilterGroup:
                 if e.status == _ffi.OOM and "region" in e.message:
                     self.row_capacity = cap * 2
                     continue
-                raise
+                failed = e  # this owner's rows alone failed (a value only its share holds): agreed on in the gather
+                raw = None
             break
         if self.row_capacity is None:
             got = self._max(rcv, int(rcv.stats()["rows_selected"]))
@@ -287,24 +293,34 @@ class ShardedFilterGroup:
             # region for that owner holds about got / world rows (+ 10 %: shards are not identical; an overflow doubles it)
             self.row_capacity = min(cap, max(4096, int(got / self.world * 1.1) + 4096)) if self.world > 1 else max(4096, int(got * 1.02) + 4096)
         stats = snd.stats()
-        return self._gather(rcv, raw), {"mode": "rows", "region_rows": cap, "scan_ms": float(stats["device_ms"]),
+        return self._gather(rcv, raw, failed), {"mode": "rows", "region_rows": cap, "scan_ms": float(stats["device_ms"]),
                                         "recv_rows": int(rcv.stats()["rows_selected"])}
 
-    def _gather(self, rcv, raw: dict) -> dict:
-        """n1k_gather_groups: the owners' finished groups on every rank, the grouped tail applied over the union."""
+    def _gather(self, rcv, raw: Optional[dict], failed=None) -> dict:
+        """n1k_gather_groups_status: the owners' finished groups on every rank, the grouped tail applied over the union.  A
+        rank whose own step failed (`failed`: its N1kError) still enters the collective, with its status instead of groups:
+        every rank then raises (the failing rank its own error, the others the status they were told)."""
         from query_amd import _ffi
-        from query_amd.gpu_operator import GpuFilterGroup
+        from query_amd.gpu_operator import GpuFilterGroup, N1kError
         dt = GpuFilterGroup._VALUE_DT
-        ng, nk, na = raw["ngroups"], raw["nkeys"], raw["naggs"]
-        keys = np.ascontiguousarray(raw["keys"]) if nk else np.zeros((ng, 0), dt)
-        aggs = np.ascontiguousarray(raw["aggs"]) if na else np.zeros((ng, 0), dt)
-        local = _ffi.Result()
-        local.ngroups, local.nkeys, local.naggs = ng, nk, na
-        local.keys = C.cast(keys.ctypes.data, C.POINTER(_ffi.Value)) if keys.size else None
-        local.aggs = C.cast(aggs.ctypes.data, C.POINTER(_ffi.Value)) if aggs.size else None
-        out = _ffi.Result()
         m = self.merger
-        m._check(m._lib.n1k_gather_groups(self.comm._h, m._h, C.byref(local), C.byref(out)))
+        nk = na = 0
+        local = _ffi.Result()
+        if failed is None:
+            ng, nk, na = raw["ngroups"], raw["nkeys"], raw["naggs"]
+            keys = np.ascontiguousarray(raw["keys"]) if nk else np.zeros((ng, 0), dt)
+            aggs = np.ascontiguousarray(raw["aggs"]) if na else np.zeros((ng, 0), dt)
+            local.ngroups, local.nkeys, local.naggs = ng, nk, na
+            local.keys = C.cast(keys.ctypes.data, C.POINTER(_ffi.Value)) if keys.size else None
+            local.aggs = C.cast(aggs.ctypes.data, C.POINTER(_ffi.Value)) if aggs.size else None
+        out = _ffi.Result()
+        worst = C.c_int(0)
+        m._check(m._lib.n1k_gather_groups_status(self.comm._h, m._h, C.byref(local), 0 if failed is None else int(failed.status),
+                                                 C.byref(out), C.byref(worst)))
+        if failed is not None:
+            raise failed
+        if worst.value != 0:
+            raise N1kError(int(worst.value), "a peer rank's step failed with status %d" % worst.value)
         n = int(out.ngroups)
 
         def arr(ptr, count):

@@ -398,3 +398,81 @@ def test_world_size_n_exchanges_over_the_loopback_transport(world, jit, subs):
         assert outs[r]["rows"][1]["mode"] == "rows"
     # every survivor arrived at exactly one owner
     assert sum(outs[r]["rows"][1]["recv_rows"] for r in range(world)) == ora.rows_passed
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("N1K_RANDOM_DIST_SEEDS", "24"))))
+def test_random_plans_sharded_over_two_ranks(seed):
+    """Differential test of the sharded operator: seeded random plans (conditions, arithmetic, 0-2 keys of every kind, 1-4
+    aggregates incl. DISTINCT) over random mixed-type tables cut in two shards, through the partial-group exchange (which
+    falls back to rows for DISTINCT and wide key values) and through the row exchange, world_size 2 over the loopback
+    transport: every rank must end with the oracle's groups of the whole table."""
+    import test_gpu_random_plans as rp
+    from query_amd import distributed as qd
+    from query_amd.gpu_operator import GroupRows
+    rng = np.random.default_rng(424200 + seed)
+    n = int(rng.integers(2, 5000))
+    t = rp.make_table(rng, n)
+    cond, keys, aggs = rp.rand_plan(rng)
+    if not keys:
+        keys = [rp.D("s")]  # (the exchanges partition on group keys)
+    try:
+        probe = query_amd.GpuFilterGroup(plan.filter_group_plan(cond, keys, aggs))
+    except query_amd.N1kError as e:
+        if e.status == _ffi.UNSUPPORTED:
+            pytest.skip("outside the device subset: " + e.message)
+        raise
+    paths = probe.column_paths
+    probe.done()
+    try:
+        ora = n1o.run(t, cond, keys, aggs, threads=2)
+    except n1o.OracleError as e:
+        pytest.skip("outside the oracle's restated subset: %s" % e)
+    world = 2
+    comms = qd.Comm.loopback(world, 0)
+    shards, keep = [], []
+    for r in range(world):
+        lo, hi = n * r // world, n * (r + 1) // world
+        sub = n1o.Table([n1o.Column(c.name, c.kind, tags=None if c.tags is None else c.tags[lo:hi],
+                                    payload=None if c.payload is None else c.payload[lo:hi],
+                                    codes=None if c.codes is None else c.codes[lo:hi]) for c in t.columns], t.dictionary)
+        dev, k = _device_cols(sub, paths)
+        keep.append(k)
+        shards.append((hi - lo, dev))
+    jit = 2 if seed % 3 == 0 else 0  # (a third of the seeds through the run-time-built kernels: ~ 3 s of compilation each)
+
+    def rank_body(r):
+        op = qd.ShardedFilterGroup(cond, keys, aggs, t.dictionary, r, world, 0, comm=comms[r])
+        for h in (op.sender, op.receiver):
+            h.set_option("jit", jit)
+        rows_n, dev = shards[r]
+        got = {}
+        for mode, fn in (("partials", op.run_partials), ("rows", op.run_rows)):
+            try:
+                raw, info = fn(rows_n, dev)
+            except query_amd.N1kError as e:
+                got[mode] = e
+                continue
+            cache = {}
+            got[mode] = GroupRows(len(keys), len(aggs), op.merger._py_values(raw["keys"], cache), op.merger._py_values(raw["aggs"], cache), [])
+        return got
+
+    old, pu.ABS_TOL = pu.ABS_TOL, 1e-9
+    try:
+        outs = _run_ranks(world, rank_body)
+        for mode in ("partials", "rows"):
+            res = [outs[r][mode] for r in range(world)]
+            errs = [x for x in res if isinstance(x, Exception)]
+            if errs:
+                # a data error (arrays as MIN / MAX operands ...) must reach EVERY rank — nobody is left waiting
+                assert len(errs) == world, "only %d of %d ranks failed: %r" % (len(errs), world, errs)
+                if all(e.status in (_ffi.UNSUPPORTED, _ffi.UNSUPPORTED_DATA) for e in errs):
+                    continue
+                raise errs[0]
+            for x in res:
+                try:
+                    pu.assert_same_groups(x, ora, aggs=aggs)
+                except AssertionError as e:
+                    raise AssertionError("%s | %s plan: %r %r %r jit %d" % (e, mode, cond, keys, aggs, jit))
+    finally:
+        pu.ABS_TOL = old
