@@ -1201,8 +1201,7 @@ interpreter:
         for (uint32_t sg = 0; sg < h->push_nseg; sg++) {
             const uint64_t off = (uint64_t)sg * h->push_seg_rows;
             for (uint32_t c = 0; c < P.ncols; c++) {
-                Ps.cols[c] = P.cols[c];
-                if (c >= (uint32_t)h->plan.paths.size()) continue;  // (derived columns: not with received regions)
+                Ps.cols[c] = P.cols[c];  // (derived columns too: they were evaluated over the whole capacity, row for row)
                 if (Ps.cols[c].tags) Ps.cols[c].tags += off;
                 if (Ps.cols[c].payload) Ps.cols[c].payload += off;
                 if (Ps.cols[c].codes) Ps.cols[c].codes += off;
