@@ -401,7 +401,10 @@ n1k_status n1k_merge_groups(n1k_handle *h, const void *blob, size_t len);
  *   by a hash of the group key VALUES into one packed region per destination rank ([count][verdict] header + every
  *   column's rows); ONE all-to-all moves counts and rows together; the receiver — a handle of the same plan without the
  *   Filter — runs InitialGroup over each received region, whose row count stays on the device.  Each group then
- *   lives on exactly one rank: COUNT(DISTINCT) needs no set merge.  capacity_rows: rows a region takes.
+ *   lives on exactly one rank: COUNT(DISTINCT) needs no set merge.  capacity_rows: rows a region takes — like
+ *   capacity_groups of n1k_exchange_partials it is part of the collective's shape and MUST be the same on every rank
+ *   (agree on it with n1k_comm_max_u64, e.g. from the largest shard's row count; the regions are split into 8
+ *   sub-regions with their own counts, which a receiver aggregates as one segmented batch).
  * n1k_gather_groups: every rank's finished groups (`local`, its n1k_finish result) to every rank with one all-gather of
  *   fixed-size slots (the slot size only changes on counts every rank reads in the gathered headers), then the handle's Order / Offset / Limit / projection over the union
  *   (≙ n1k_order_rows).  `out` belongs to the handle like n1k_finish's.

@@ -201,6 +201,7 @@ class ShardedFilterGroup:
         self.has_distinct = any("(distinct " in a.lower() for a in aggs)
         self.partial_capacity = None  # groups per region: agreed on in the first step
         self.row_capacity = None      # rows per region
+        self._first_row_capacity = None
         self._sbatch = None
 
     GATHER_LIMIT = 32 << 20  # partial groups of ALL ranks within this many bytes per rank: all-gather them
@@ -273,8 +274,12 @@ class ShardedFilterGroup:
         snd, rcv, lib = self.sender, self.receiver, self.sender._lib
         batch = self._batch(nrows, cols_by_path)
         failed = None
+        if self.row_capacity is None and self._first_row_capacity is None:
+            # the regions of one all-to-all have ONE size on every rank: the first step sizes them from the LARGEST shard
+            # (shards differ by a row under strong scaling; found by the loopback test — RCCL would have hung on it)
+            self._first_row_capacity = max(4096, int(self._max(snd, nrows) * 1.1 / self.world) + 4096)
         while True:
-            cap = self.row_capacity if self.row_capacity is not None else max(4096, int(nrows * 1.1 / self.world) + 4096)
+            cap = self.row_capacity if self.row_capacity is not None else self._first_row_capacity
             rcv.reopen()
             snd.reopen()  # (the sender holds no groups in this mode; its counters and timers start over)
             snd._check(lib.n1k_exchange_rows(self.comm._h, snd._h, C.byref(batch[0]), rcv._h, cap))

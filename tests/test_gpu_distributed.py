@@ -336,11 +336,15 @@ def _run_ranks(world, fn):
     for t in ts:
         t.start()
     for t in ts:
-        t.join(timeout=240)
-    assert not any(t.is_alive() for t in ts), "a rank is stuck in a collective"
-    for e in errs:
+        t.join(timeout=90)
+    for e in errs:  # (a rank that died outside a collective leaves its peers waiting in the next one: its error first)
         if e is not None:
             raise e
+    if any(t.is_alive() for t in ts):
+        import faulthandler
+        import sys
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)  # which call every rank sits in
+    assert not any(t.is_alive() for t in ts), "a rank is stuck in a collective; the others returned %r" % ([o for o in outs if o is not None],)
     return outs
 
 
