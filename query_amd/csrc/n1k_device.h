@@ -239,8 +239,17 @@ N1K_DEV void arith_apply(uint32_t op, uint32_t nops, const uint32_t (&tg)[4], co
         bool null = false, missing = false;
         Num acc = num_int(op == AR_ADD ? 0 : 1);
         for (uint32_t k = 0; k < nops; k++) {
-            if (!null && is_num(tg[k])) acc = op == AR_ADD ? num_add(acc, Num{tg[k], pv[k]}) : num_mult(acc, Num{tg[k], pv[k]});
-            else if (tg[k] == T_MISSING) missing = true;
+            if (!null && is_num(tg[k])) {
+                if (k == 0) {
+                    // the fold's first step, from the identity (Add.Apply starts at int 0, Mult.Apply at int 1), spelled out:
+                    // 1 * x is x (an int stays the same int, 1.0 * f is f bit for bit); 0 + x is x for a non-negative int,
+                    // float64(x) for a negative one (the same-sign rule of intValue.Add) and 0.0 + f for a float
+                    if (op == AR_MULT) acc = Num{tg[0], pv[0]};
+                    else if (tg[0] == T_INT) acc = (int64_t)pv[0] >= 0 ? num_int((int64_t)pv[0]) : num_flt((double)(int64_t)pv[0]);
+                    else acc = num_flt(0.0 + as_f64(pv[0]));
+                } else
+                    acc = op == AR_ADD ? num_add(acc, Num{tg[k], pv[k]}) : num_mult(acc, Num{tg[k], pv[k]});
+            } else if (tg[k] == T_MISSING) missing = true;
             else null = true;
         }
         if (missing) rt = T_MISSING;
