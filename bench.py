@@ -378,13 +378,18 @@ def main():
     # read at half its bytes), WRITE_SIZE is exact; both are KB per dispatch.  The figure belongs to the build the
     # profile was taken from (tools/profile_round.sh; `traffic_source` names the file): re-profile after kernel changes.
     pmc = os.path.join(ROOT, "profiles", "r02_bench_%s_100M_pmc_fetch_write.json" % args.workload)
-    if args.rows == 100_000_000 and args.kcat == (100_000 if args.workload.startswith("config5") else 1000) and os.path.exists(pmc):
+    if args.rows == 100_000_000 and args.kcat == (100_000 if args.workload.startswith("config5") else 1000) and os.path.exists(pmc) \
+            and not args.opt:
         try:
             with open(pmc) as fh:
                 c = json.load(fh)
-            k = [n for n in c["FETCH_SIZE"] if "scan_spec_" in n][0]
-            out["roofline"]["traffic"] = 1024.0 * (2.0 * c["FETCH_SIZE"][k]["avg_KB"] + c["WRITE_SIZE"][k]["avg_KB"])
-            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc) + " (%s, 2*FETCH_SIZE + WRITE_SIZE)" % k.split("<")[0].split("::")[-1]
+            k = [n for n in c["FETCH_SIZE"] if "scan_spec_" in n or "n1k_jit_wide" in n][0]
+            from query_amd import build as qbuild
+            if c.get("source_hash") in (None, qbuild.source_hash()):  # (None: profiles taken before the stamp existed)
+                out["roofline"]["traffic"] = 1024.0 * (2.0 * c["FETCH_SIZE"][k]["avg_KB"] + c["WRITE_SIZE"][k]["avg_KB"])
+                out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc) + " (%s, 2*FETCH_SIZE + WRITE_SIZE)" % k.split("<")[0].split("::")[-1]
+            else:
+                out["roofline"]["traffic_source"] = "none: profiles/%s belongs to other kernel sources (%s)" % (os.path.basename(pmc), c.get("source_hash"))
         except Exception:
             pass
     if not args.no_cpu:

@@ -35,6 +35,16 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > mt for d in deps)
 
 
+def source_hash() -> str:
+    """sha1 over the kernel / engine sources: stamps measurements (profiles/*_pmc_*.json) with the code they belong to."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     return _stale(LIB, [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)])
 

@@ -7,7 +7,7 @@ TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 DST=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $DST
-for WL in config2 config3 config5; do
+for WL in config2 config3 config5 arith; do
   python3 $ROOT/bench.py --workload $WL --steps 20 --warmup 3 2>/dev/null | tail -1 > $DST/${TAG}_bench_${WL}_100M.json.log
   bash $ROOT/tools/prof.sh ${TAG}_$WL all -- --workload $WL > /dev/null
   cp $ROOT/gpurun_out/prof_${TAG}_$WL/stats/bench_kernel_stats.csv $DST/${TAG}_bench_${WL}_100M_kernel_stats.csv

@@ -17,4 +17,10 @@ for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             a[0] += 1
             a[1] += float(r["Counter_Value"])
     out[name] = {k: {"dispatches": n, "avg_KB": s / n} for k, (n, s) in sorted(acc.items())}
+try:  # the sources the profiled library was built from (bench.py drops `traffic` when they have changed since)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from query_amd import build as _b
+    out["source_hash"] = _b.source_hash()
+except Exception:
+    pass
 json.dump(out, sys.stdout, indent=1)
