@@ -10,7 +10,10 @@ shard and the ranks meet in ONE exchange step, behind the C ABI (include/n1k.h, 
                            needs no set merge;
   * n1k_exchange_partials  every rank aggregates its shard first and only the partial groups travel — all-gathered
                            (every rank merges all of them and holds the result) or hash-partitioned to owners;
-  * n1k_gather_groups      the owners' finished groups to every rank, then the plan's ORDER BY / LIMIT over the union.
+  * n1k_gather_groups(_status)  the owners' finished groups to every rank, then the plan's ORDER BY / LIMIT over the
+                           union; a rank whose own step failed enters it with its status, so that every rank raises.
+  * n1k_comm_create_loopback   the same exchange with the ranks as THREADS of one process (Comm.loopback): world sizes
+                           > 1 on a single GPU (tests/test_gpu_distributed.py).
 
 This module is the thin Python caller (bench.py, tests): torch.distributed only carries the communicator id at start-up
 and the bench's barriers — no row and no group crosses it.  The functions at the top (exchange_counts, exchange_rows,
