@@ -36,10 +36,11 @@ def _stale(target: str, deps) -> bool:
 
 
 def source_hash() -> str:
-    """sha1 over the kernel / engine sources: stamps measurements (profiles/*_pmc_*.json) with the code they belong to."""
+    """sha1 over the DEVICE code (the two kernel translation units and every header they include): stamps measurements
+    (profiles/*_pmc_*.json) with the kernels they belong to."""
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+    for f in sorted([x for x in SOURCES if x.endswith(".hip")] + [x for x in HEADERS if not x.startswith("..")]):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

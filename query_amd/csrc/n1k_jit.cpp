@@ -4,6 +4,10 @@
 
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
 
 #include <cstdlib>
 #include <cstring>
@@ -31,8 +35,95 @@ std::string csrc_dir() {
 
 std::string sig_key(const SpecSig& s) { return std::string((const char*)&s, sizeof s); }
 
-bool compile(const SpecSig& sig, std::vector<char>& code, std::string& log) {
+// ---- code objects on disk: a shape is compiled once per installation, not once per process -----------------------
+//
+// <directory of libn1k.so>/jit_cache/<hash>.co (N1K_JIT_CACHE names another directory; "0" or "off" disables it).  The
+// hash covers the generated source text (the shape), every header under csrc/ the translation unit can include, the
+// compiler options and the hiprtc version: a changed kernel source can never meet a stale object.  Files appear by rename.
+uint64_t fnv1a(const void* p, size_t n, uint64_t h) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001B3ull;
+    return h;
+}
+
+std::string cache_dir() {
+    const char* e = getenv("N1K_JIT_CACHE");
+    if (e && (!strcmp(e, "0") || !strcmp(e, "off"))) return "";
+    if (e && *e) return e;
+    std::string c = csrc_dir();  // .../query_amd/csrc -> .../query_amd/jit_cache
+    size_t slash = c.rfind('/');
+    return (slash == std::string::npos ? std::string(".") : c.substr(0, slash)) + "/jit_cache";
+}
+
+uint64_t headers_hash() {
+    static uint64_t cached = 0;
+    if (cached) return cached;
+    uint64_t h = 0xCBF29CE484222325ull;
+    static const char* names[] = {"n1k_types.h", "n1k_device.h", "n1k_tables.h", "n1k_scatter.h", "n1k_spec.h"};
+    for (const char* n : names) {
+        std::string path = csrc_dir() + "/" + n;
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) continue;
+        char buf[65536];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) h = fnv1a(buf, got, h);
+        fclose(f);
+        h = fnv1a(n, strlen(n), h);
+    }
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    h = fnv1a(&major, sizeof major, h);
+    h = fnv1a(&minor, sizeof minor, h);
+    cached = h ? h : 1;
+    return cached;
+}
+
+std::string cache_path(const std::string& src) {
+    const std::string dir = cache_dir();
+    if (dir.empty()) return "";
+    uint64_t h = fnv1a(src.data(), src.size(), headers_hash());
+    static const char kOpts[] = "--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics";
+    h = fnv1a(kOpts, sizeof kOpts, h);
+    char name[40];
+    snprintf(name, sizeof name, "/%016llx.co", (unsigned long long)h);
+    return dir + name;
+}
+
+bool cache_read(const std::string& path, std::vector<char>& code) {
+    if (path.empty()) return false;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    bool ok = n > 64;
+    if (ok) {
+        code.resize((size_t)n);
+        ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n && !memcmp(code.data(), "\177ELF", 4);
+    }
+    fclose(f);
+    if (!ok) code.clear();
+    return ok;
+}
+
+void cache_write(const std::string& path, const std::vector<char>& code) {
+    if (path.empty() || code.empty()) return;
+    const std::string dir = path.substr(0, path.rfind('/'));
+    (void)mkdir(dir.c_str(), 0777);
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, ".tmp.%d.%p", (int)getpid(), (void*)&code);
+    const std::string t = dir + "/" + tmp;
+    FILE* f = fopen(t.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    fclose(f);
+    if (!ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
+}
+
+bool compile(const SpecSig& sig, std::vector<char>& code, std::string& log, bool use_cache = true) {
     std::string src = jit_source(sig);
+    const std::string cpath = use_cache ? cache_path(src) : std::string();
+    if (cache_read(cpath, code)) return true;
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "n1k_jit_shape.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         log = "hiprtcCreateProgram failed";
@@ -55,6 +146,7 @@ bool compile(const SpecSig& sig, std::vector<char>& code, std::string& log) {
         ok = cs > 0 && hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
     }
     hiprtcDestroyProgram(&prog);
+    if (ok) cache_write(cpath, code);
     return ok;
 }
 
@@ -123,9 +215,21 @@ std::string jit_source(const SpecSig& g) {
 bool jit_compile_check(const SpecSig& sig, std::string* log) {
     std::vector<char> code;
     std::string l;
-    bool ok = compile(sig, code, l);
+    bool ok = compile(sig, code, l, false);  // (a check compiles: it neither reads nor fills the cache)
     if (log) *log = l;
     return ok;
+}
+
+static bool load_module(const SpecSig& sig, JitKernel* k, const std::vector<char>& code) {
+    if (hipModuleLoadData(&k->module, code.data()) != hipSuccess) return false;
+    if (sig.mode == 1)
+        return hipModuleGetFunction(&k->part_wide, k->module, "n1k_jit_part_wide") == hipSuccess &&
+               hipModuleGetFunction(&k->part_wide256, k->module, "n1k_jit_part_wide256") == hipSuccess &&
+               hipModuleGetFunction(&k->part_narrow, k->module, "n1k_jit_part_narrow") == hipSuccess;
+    return hipModuleGetFunction(&k->wide, k->module, "n1k_jit_wide") == hipSuccess &&
+           hipModuleGetFunction(&k->narrow, k->module, "n1k_jit_narrow") == hipSuccess &&
+           hipModuleGetFunction(&k->rec_wide, k->module, "n1k_jit_rec_wide") == hipSuccess &&
+           hipModuleGetFunction(&k->rec_narrow, k->module, "n1k_jit_rec_narrow") == hipSuccess;
 }
 
 const JitKernel* jit_get(const SpecSig& sig) {
@@ -140,23 +244,18 @@ const JitKernel* jit_get(const SpecSig& sig) {
         k->failed = true;
         return k;
     }
-    if (sig.mode == 1) {
-        if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
-            hipModuleGetFunction(&k->part_wide, k->module, "n1k_jit_part_wide") != hipSuccess ||
-            hipModuleGetFunction(&k->part_wide256, k->module, "n1k_jit_part_wide256") != hipSuccess ||
-            hipModuleGetFunction(&k->part_narrow, k->module, "n1k_jit_part_narrow") != hipSuccess) {
+    if (!load_module(sig, k, code)) {
+        // (an object from the disk cache that does not load — truncated, another driver: compile afresh, once)
+        if (k->module) (void)hipModuleUnload(k->module);
+        *k = JitKernel();
+        const std::string cpath = cache_path(jit_source(sig));
+        if (!cpath.empty()) (void)remove(cpath.c_str());
+        code.clear();
+        if (!compile(sig, code, k->log, false) || !load_module(sig, k, code)) {
             k->failed = true;
             k->log += "\nhipModuleLoadData / hipModuleGetFunction failed";
-        }
-        return k;
-    }
-    if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
-        hipModuleGetFunction(&k->wide, k->module, "n1k_jit_wide") != hipSuccess ||
-        hipModuleGetFunction(&k->narrow, k->module, "n1k_jit_narrow") != hipSuccess ||
-        hipModuleGetFunction(&k->rec_wide, k->module, "n1k_jit_rec_wide") != hipSuccess ||
-        hipModuleGetFunction(&k->rec_narrow, k->module, "n1k_jit_rec_narrow") != hipSuccess) {
-        k->failed = true;
-        k->log += "\nhipModuleLoadData / hipModuleGetFunction failed";
+        } else
+            cache_write(cpath, code);
     }
     return k;
 }
