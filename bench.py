@@ -265,6 +265,41 @@ def kernel_label(st: dict, wl: dict) -> str:
     return "scan_spec_kernel(+merge_slabs_kernel)" if st.get("spec_kernel") else "scan_fast/scan_group_kernel"
 
 
+def by_rows(args, wl, local_rank: int) -> dict:
+    """north_star: rows/sec at 10 M / 100 M / 1 B rows.  The same query at the two other sizes on this GPU (columns resident
+    in HBM, 1 B rows = 13 GB of config 2's columns): 10 untimed + 10 timed executions each.  Never the headline `value`."""
+    import torch
+    import query_amd
+    out = {}
+    for label, n in (("10M", 10_000_000), ("1B", 1_000_000_000)):
+        if n == args.rows:
+            continue
+        free, _total = torch.cuda.mem_get_info(local_rank)
+        if n * 31 * 1.2 > free:  # (the generator fills all seven arrays: 31 B per row)
+            out[label] = {"skipped": "not enough free HBM"}
+            continue
+        cols = DeviceColumns(n, args.kcat, False, 0, n, local_rank)
+        pj = query_amd.plan.filter_group_plan(wl["cond"], wl["keys"], wl["aggs"], order=wl.get("order"), limit=wl.get("limit"))
+        op = query_amd.GpuFilterGroup(pj, device=local_rank)
+        op.intern(synth_dictionary(args.kcat))
+        batch = op.make_device_batch(n, [cols.by_path[p] for p in op.column_paths])
+        for _ in range(10):
+            op.run_device_batch_raw(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            op.run_device_batch_raw(batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        st = op.stats()
+        out[label] = {"rows": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "rows/s",
+                      "kernel_ms": st["device_ms"], "achieved_GB/s": wl["bytes_per_row"] * n / (st["device_ms"] * 1e-3) / 1e9 if st["device_ms"] else None}
+        op.done()
+        del cols, batch
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +314,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--three-calls", action="store_true", help="n1k_reset / n1k_push_device_batch / n1k_finish as three calls from Python")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the by_rows sub-record (the same query at 10 M and 1 B rows)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the h2d_inclusive / json_end_to_end sub-records")
     ap.add_argument("--ingest-rows", type=int, default=40_000_000, help="rows pushed from host buffers for h2d_inclusive")
     ap.add_argument("--json-docs", type=int, default=1_000_000, help="documents pushed as raw JSON for json_end_to_end")
@@ -401,6 +437,11 @@ def main():
             out.update(ingest_rates(args, wl, cols))
         except Exception as e:  # the sub-records never cost the headline line
             out["ingest_error"] = repr(e)[:300]
+    if not args.no_sizes and args.workload == "config2" and not args.zipf and not args.opt:
+        try:
+            out["by_rows"] = by_rows(args, wl, local_rank)
+        except Exception as e:  # the sub-records never cost the headline line
+            out["by_rows"] = {"error": repr(e)[:300]}
     print(json.dumps(out))
 
 
