@@ -480,3 +480,61 @@ def test_random_plans_sharded_over_two_ranks(seed):
                     raise AssertionError("%s | %s plan: %r %r %r jit %d" % (e, mode, cond, keys, aggs, jit))
     finally:
         pu.ABS_TOL = old
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_grouped_tail_and_distinct_across_ranks_over_the_loopback_transport(world):
+    """Config 5's shape (GROUP BY cat, region_id HAVING ... ORDER BY SUM(price) DESC, cat LIMIT k OFFSET o) and config 3's
+    (COUNT(DISTINCT user_id) + AVG(price)) at world sizes 2 and 4 on one GPU: every owner applies HAVING and keeps its first
+    offset + limit rows, n1k_gather_groups orders and cuts their union; DISTINCT plans always exchange rows."""
+    from query_amd import distributed as qd
+    from query_amd.gpu_operator import GroupRows
+    n = 150_001
+    t = n1o.synth_table(n, k_cat=300)
+    keys5 = [D("cat"), D("region_id")]
+    aggs5 = sorted(["sum(%s)" % D("price"), "count(*)"])
+    order, limit, offset = [("sum(%s)" % D("price"), True), (D("cat"), False)], 25, 3
+    having = "(5 < count(*))"
+    keys3 = [D("cat")]
+    aggs3 = sorted(["count(distinct %s)" % D("user_id"), "avg(%s)" % D("price")])
+    comms5, comms3 = qd.Comm.loopback(world, 0), qd.Comm.loopback(world, 0)
+    probe = query_amd.GpuFilterGroup(plan.filter_group_plan(None, keys5, sorted(aggs5 + aggs3)))
+    paths = probe.column_paths  # (every column either plan reads)
+    probe.done()
+    shards, keep = [], []
+    for r in range(world):
+        lo, hi = n * r // world, n * (r + 1) // world
+        sub = n1o.Table([n1o.Column(c.name, c.kind, tags=None if c.tags is None else c.tags[lo:hi],
+                                    payload=None if c.payload is None else c.payload[lo:hi],
+                                    codes=None if c.codes is None else c.codes[lo:hi]) for c in t.columns], t.dictionary)
+        dev, k = _device_cols(sub, paths)
+        keep.append(k)
+        shards.append((hi - lo, dev))
+
+    def rank_body(r):
+        rows_n, dev = shards[r]
+        got = {}
+        op5 = qd.ShardedFilterGroup(None, keys5, aggs5, t.dictionary, r, world, 0, order=order, limit=limit, offset=offset,
+                                    having=having, comm=comms5[r])
+        for mode, fn in (("gathered", op5.run_gathered), ("partials", op5.run_partials), ("rows", op5.run_rows)):
+            raw, _info = fn(rows_n, dev)
+            cache = {}
+            got[mode] = GroupRows(len(keys5), len(aggs5), op5.merger._py_values(raw["keys"], cache), op5.merger._py_values(raw["aggs"], cache), [])
+        op3 = qd.ShardedFilterGroup(None, keys3, aggs3, t.dictionary, r, world, 0, comm=comms3[r])
+        assert op3.has_distinct  # (sets do not travel as partial groups: such plans exchange rows, as bench.py does)
+        raw, info = op3.run_rows(rows_n, dev)
+        cache = {}
+        got["distinct"] = GroupRows(1, len(aggs3), op3.merger._py_values(raw["keys"], cache), op3.merger._py_values(raw["aggs"], cache), [])
+        return got
+
+    outs = _run_ranks(world, rank_body)
+    ora5 = n1o.run(t, None, keys5, aggs5)
+    ci = aggs5.index("count(*)")
+    kept = [(kk, aa) for kk, aa in zip(ora5.keys, ora5.aggs) if aa[ci][1] > 5]
+    ora5.keys, ora5.aggs = [x for x, _ in kept], [y for _, y in kept]
+    ora3 = n1o.run(t, None, keys3, aggs3)
+    for r in range(world):
+        for mode in ("gathered", "partials", "rows"):
+            pu.assert_ordered_groups(outs[r][mode], ora5, keys5, aggs5, order, limit, offset)
+        pu.assert_same_groups(outs[r]["distinct"], ora3, aggs=aggs3)
