@@ -3624,13 +3624,18 @@ n1k_status cfail(n1k_comm* c, n1k_status st, const char* fmt, ...) {
 // loopback: what every peer published, copied (or read) by everybody between two rendezvous
 template <class Copy>
 n1k_status loop_collective(n1k_comm* c, const void* send, hipStream_t st, Copy copy) {
-    if (hipStreamSynchronize(st) != hipSuccess) return cfail(c, N1K_DEVICE_ERROR, "loopback: stream synchronisation failed");
-    c->hub->ptr[c->rank] = send;
+    // (a rank whose own part fails still keeps both rendezvous: its peers must not be left waiting for it)
+    hipError_t e = hipStreamSynchronize(st);
+    c->hub->ptr[c->rank] = e == hipSuccess ? send : nullptr;
     c->hub->barrier();  // every rank's send buffer is complete and published
-    hipError_t e = copy();
+    if (e == hipSuccess) {
+        for (int p = 0; p < c->world; p++)
+            if (!c->hub->ptr[p]) e = hipErrorUnknown;  // (a peer failed before publishing)
+    }
+    if (e == hipSuccess) e = copy();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     c->hub->barrier();  // everybody has read everybody: the send buffers may be overwritten
-    return e == hipSuccess ? N1K_OK : cfail(c, N1K_DEVICE_ERROR, "loopback: copy failed: %s", hipGetErrorString(e));
+    return e == hipSuccess ? N1K_OK : cfail(c, N1K_DEVICE_ERROR, "loopback: collective failed: %s", hipGetErrorString(e));
 }
 
 n1k_status all_gather_bytes(n1k_comm* c, const char* send, char* recv, size_t bytes, hipStream_t st) {
