@@ -432,6 +432,12 @@ n1k_status n1k_gather_groups(n1k_comm *c, n1k_handle *h, const n1k_result *local
  * every rank gets the first failing rank's status in *worst_status (N1K_OK: `out` holds the gathered groups). */
 n1k_status n1k_gather_groups_status(n1k_comm *c, n1k_handle *h, const n1k_result *local, int local_status, n1k_result *out,
                                     int *worst_status);
+/* One whole step of the row exchange in one call: n1k_reset(receiver), n1k_reset(sender), n1k_exchange_rows,
+ * n1k_finish(receiver), n1k_gather_groups_status(merger) — what a host runs per query.  N1K_OOM with "region" in the
+ * receiver's n1k_last_error: a region overflowed, on every rank alike, and no gather took place (enlarge capacity_rows on
+ * every rank and repeat); otherwise the receiver's own status, with *worst_status as n1k_gather_groups_status reports it. */
+n1k_status n1k_rows_step(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver, n1k_handle *merger,
+                         uint64_t capacity_rows, n1k_result *out, int *worst_status);
 
 /* ------------------------------------------------------------- utilities -- */
 

@@ -79,7 +79,7 @@ SYMBOLS = [
     "n1k_jit_check", "n1k_partial_words", "n1k_partial_region_bytes", "n1k_export_partials_device", "n1k_export_partials_async",
     "n1k_merge_partials_device",
     "n1k_comm_unique_id", "n1k_comm_create", "n1k_comm_destroy", "n1k_comm_last_error", "n1k_comm_rank", "n1k_comm_world",
-    "n1k_comm_max_u64", "n1k_exchange_partials", "n1k_exchange_rows", "n1k_gather_groups", "n1k_gather_groups_status",
+    "n1k_comm_max_u64", "n1k_exchange_partials", "n1k_exchange_rows", "n1k_gather_groups", "n1k_gather_groups_status", "n1k_rows_step",
     "n1k_abi_version", "n1k_device_count",
 ]
 
@@ -190,6 +190,8 @@ def lib():
     L.n1k_exchange_partials.argtypes = [H, H, H, C.c_uint64, C.c_int]
     L.n1k_exchange_rows.restype = C.c_int
     L.n1k_exchange_rows.argtypes = [H, H, C.POINTER(Batch), H, C.c_uint64]
+    L.n1k_rows_step.restype = C.c_int
+    L.n1k_rows_step.argtypes = [H, H, C.POINTER(Batch), H, H, C.c_uint64, C.POINTER(Result), C.POINTER(C.c_int)]
     L.n1k_gather_groups_status.restype = C.c_int
     L.n1k_gather_groups_status.argtypes = [H, H, C.POINTER(Result), C.c_int, C.POINTER(Result), C.POINTER(C.c_int)]
     L.n1k_gather_groups.restype = C.c_int

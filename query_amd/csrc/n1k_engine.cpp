@@ -3968,6 +3968,23 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
     });
 }
 
+n1k_status n1k_rows_step(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, n1k_handle* merger,
+                         uint64_t capacity_rows, n1k_result* out, int* worst_status) {
+    if (!c || !sender || !batch || !receiver || !merger || !out || !worst_status) return N1K_INVALID;
+    *worst_status = N1K_OK;
+    n1k_status st = n1k_reset(receiver);
+    if (st == N1K_OK) st = n1k_reset(sender);  // (the sender holds no groups in this mode; its counters and timers start over)
+    if (st == N1K_OK) st = n1k_exchange_rows(c, sender, batch, receiver, capacity_rows);
+    if (st != N1K_OK) return st;
+    n1k_result local;
+    st = n1k_finish(receiver, &local);
+    // a region that overflowed fails the step on EVERY rank alike (the verdict travelled in the headers): no gather, the
+    // caller enlarges the regions and repeats; any other failure is this owner's alone and travels in the gather
+    if (st == N1K_OOM && receiver->last_error.find("region") != std::string::npos) return st;
+    n1k_status gs = n1k_gather_groups_status(c, merger, st == N1K_OK ? &local : nullptr, (int)st, out, worst_status);
+    return gs != N1K_OK ? gs : st;
+}
+
 n1k_status n1k_gather_groups(n1k_comm* c, n1k_handle* h, const n1k_result* local, n1k_result* out) {
     int worst = 0;
     n1k_status st = n1k_gather_groups_status(c, h, local, N1K_OK, out, &worst);

@@ -276,33 +276,49 @@ class ShardedFilterGroup:
         from query_amd.gpu_operator import N1kError
         snd, rcv, lib = self.sender, self.receiver, self.sender._lib
         batch = self._batch(nrows, cols_by_path)
-        failed = None
         if self.row_capacity is None and self._first_row_capacity is None:
             # the regions of one all-to-all have ONE size on every rank: the first step sizes them from the LARGEST shard
             # (shards differ by a row under strong scaling; found by the loopback test — RCCL would have hung on it)
             self._first_row_capacity = max(4096, int(self._max(snd, nrows) * 1.1 / self.world) + 4096)
+        out, worst = _ffi.Result(), C.c_int(0)
         while True:
             cap = self.row_capacity if self.row_capacity is not None else self._first_row_capacity
-            rcv.reopen()
-            snd.reopen()  # (the sender holds no groups in this mode; its counters and timers start over)
-            snd._check(lib.n1k_exchange_rows(self.comm._h, snd._h, C.byref(batch[0]), rcv._h, cap))
-            try:
-                raw = rcv.after_items_raw()
-            except N1kError as e:
-                if e.status == _ffi.OOM and "region" in e.message:
-                    self.row_capacity = cap * 2
-                    continue
-                failed = e  # this owner's rows alone failed (a value only its share holds): agreed on in the gather
-                raw = None
+            # n1k_rows_step: both resets, the exchange, the owner's n1k_finish and the gather in ONE call through the ABI
+            st = int(lib.n1k_rows_step(self.comm._h, snd._h, C.byref(batch[0]), rcv._h, self.merger._h, cap, C.byref(out), C.byref(worst)))
+            if st == _ffi.OOM and b"region" in (lib.n1k_last_error(rcv._h) or b""):
+                self.row_capacity = cap * 2  # (a region overflowed: on every rank alike, no gather took place)
+                continue
             break
         if self.row_capacity is None:
             got = self._max(rcv, int(rcv.stats()["rows_selected"]))
             # `got` is the LARGEST owner's total, and every source sees the same split of the keys over the owners: a source's
             # region for that owner holds about got / world rows (+ 10 %: shards are not identical; an overflow doubles it)
             self.row_capacity = min(cap, max(4096, int(got / self.world * 1.1) + 4096)) if self.world > 1 else max(4096, int(got * 1.02) + 4096)
+        if st != _ffi.OK:  # this rank's own failure (its peers learnt it in the gather)
+            msg = b""
+            for hnd in (rcv, snd, self.merger):
+                msg = msg or (lib.n1k_last_error(hnd._h) or b"")
+            raise N1kError(st, msg.decode(errors="replace"))
+        if worst.value != 0:
+            raise N1kError(int(worst.value), "a peer rank's step failed with status %d" % worst.value)
         stats = snd.stats()
-        return self._gather(rcv, raw, failed), {"mode": "rows", "region_rows": cap, "scan_ms": float(stats["device_ms"]),
+        return self._result_dict(out), {"mode": "rows", "region_rows": cap, "scan_ms": float(stats["device_ms"]),
                                         "recv_rows": int(rcv.stats()["rows_selected"])}
+
+    @staticmethod
+    def _result_dict(out) -> dict:
+        from query_amd.gpu_operator import GpuFilterGroup
+        dt = GpuFilterGroup._VALUE_DT
+        n, nk, na = int(out.ngroups), int(out.nkeys), int(out.naggs)
+
+        def arr(ptr, count):
+            if not count or not ptr:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer(bytearray(C.string_at(ptr, count * dt.itemsize)), dtype=dt)
+
+        return {"ngroups": n, "nkeys": nk, "naggs": na,
+                "keys": arr(out.keys, n * nk).reshape(n, nk) if nk else np.zeros((n, 0), dt),
+                "aggs": arr(out.aggs, n * na).reshape(n, na) if na else np.zeros((n, 0), dt)}
 
     def _gather(self, rcv, raw: Optional[dict], failed=None) -> dict:
         """n1k_gather_groups_status: the owners' finished groups on every rank, the grouped tail applied over the union.  A
