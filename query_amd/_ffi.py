@@ -190,10 +190,11 @@ def lib():
     L.n1k_exchange_partials.argtypes = [H, H, H, C.c_uint64, C.c_int]
     L.n1k_exchange_rows.restype = C.c_int
     L.n1k_exchange_rows.argtypes = [H, H, C.POINTER(Batch), H, C.c_uint64]
-    L.n1k_rows_step.restype = C.c_int
-    L.n1k_rows_step.argtypes = [H, H, C.POINTER(Batch), H, H, C.c_uint64, C.POINTER(Result), C.POINTER(C.c_int)]
-    L.n1k_gather_groups_status.restype = C.c_int
-    L.n1k_gather_groups_status.argtypes = [H, H, C.POINTER(Result), C.c_int, C.POINTER(Result), C.POINTER(C.c_int)]
+    if hasattr(L, "n1k_rows_step"):  # (absent from older builds loaded through N1K_LIB for A/B measurements)
+        L.n1k_rows_step.restype = C.c_int
+        L.n1k_rows_step.argtypes = [H, H, C.POINTER(Batch), H, H, C.c_uint64, C.POINTER(Result), C.POINTER(C.c_int)]
+        L.n1k_gather_groups_status.restype = C.c_int
+        L.n1k_gather_groups_status.argtypes = [H, H, C.POINTER(Result), C.c_int, C.POINTER(Result), C.POINTER(C.c_int)]
     L.n1k_gather_groups.restype = C.c_int
     L.n1k_gather_groups.argtypes = [H, H, C.POINTER(Result), C.POINTER(Result)]
     L.n1k_synth_columns.restype = C.c_int
