@@ -538,3 +538,49 @@ def test_grouped_tail_and_distinct_across_ranks_over_the_loopback_transport(worl
         for mode in ("gathered", "partials", "rows"):
             pu.assert_ordered_groups(outs[r][mode], ora5, keys5, aggs5, order, limit, offset)
         pu.assert_same_groups(outs[r]["distinct"], ora3, aggs=aggs3)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["rows", "partials"])
+def test_one_owners_failure_reaches_every_rank(mode):
+    """A value only ONE owner's share holds makes that owner's n1k_finish fail (MAX over an array: its collation is outside
+    the device subset).  Its peers would wait for it in the gather: instead the failing rank enters the collective with its
+    status (n1k_gather_groups_status) and EVERY rank raises — nobody hangs, nobody returns a partial answer."""
+    from query_amd import distributed as qd
+    world, n = 2, 4000
+    dictionary = [b"k%d" % i for i in range(8)] + [b"[1]"]
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, 8, n).astype(np.uint32)
+    tags = np.full(n, n1o.T_INT, np.uint8)
+    pay = rng.integers(0, 1000, n).astype(np.uint64)
+    tags[n - 7], pay[n - 7] = n1o.T_ARRAY, 8  # one array value, in the second shard, in ONE group
+    t = n1o.Table([n1o.Column(D("s"), n1o.COL_DICT32, codes=codes), n1o.Column(D("v"), n1o.COL_TAGGED64, tags=tags, payload=pay)],
+                  dictionary)
+    keys, aggs = [D("s")], sorted(["count(*)", "max(%s)" % D("v")])
+    comms = qd.Comm.loopback(world, 0)
+    probe = query_amd.GpuFilterGroup(plan.filter_group_plan(None, keys, aggs))
+    paths = probe.column_paths
+    probe.done()
+    shards, keep = [], []
+    for r in range(world):
+        lo, hi = n * r // world, n * (r + 1) // world
+        sub = n1o.Table([n1o.Column(c.name, c.kind, tags=None if c.tags is None else c.tags[lo:hi],
+                                    payload=None if c.payload is None else c.payload[lo:hi],
+                                    codes=None if c.codes is None else c.codes[lo:hi]) for c in t.columns], t.dictionary)
+        dev, k = _device_cols(sub, paths)
+        keep.append(k)
+        shards.append((hi - lo, dev))
+
+    def rank_body(r):
+        op = qd.ShardedFilterGroup(None, keys, aggs, t.dictionary, r, world, 0, comm=comms[r])
+        rows_n, dev = shards[r]
+        try:
+            (op.run_rows if mode == "rows" else op.run_partials)(rows_n, dev)
+        except query_amd.N1kError as e:
+            return e
+        return None
+
+    outs = _run_ranks(world, rank_body)
+    assert all(isinstance(o, query_amd.N1kError) for o in outs), outs
+    assert all(o.status == _ffi.UNSUPPORTED_DATA for o in outs), [(o.status, o.message) for o in outs]
+    assert sum("peer rank" in o.message for o in outs) == world - 1  # (one owner's own error, the others were told)
