@@ -12,8 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libn1k.so")
-SOURCES = ["n1k_kernels.hip", "n1k_bins.hip", "n1k_plan.cpp", "n1k_engine.cpp", "n1k_jit.cpp", "n1k_json.cpp"]
+SOURCES = ["n1k_kernels.hip", "n1k_bins.hip", "n1k_plan.cpp", "n1k_engine.cpp", "n1k_scan.cpp", "n1k_partitioned.cpp", "n1k_distinct.cpp",
+           "n1k_finish.cpp", "n1k_tail.cpp", "n1k_exchange.cpp", "n1k_jit.cpp", "n1k_json.cpp"]
 HEADERS = ["n1k_types.h", "n1k_device.h", "n1k_tables.h", "n1k_scatter.h", "n1k_spec.h", "n1k_jit.h", "n1k_kernels.h", "n1k_plan.h", os.path.join("..", "..", "include", "n1k.h")]
+HOST_HEADERS = ["n1k_engine.h"]  # host-only: not part of source_hash()
 ARCH = "gfx950"
 
 
@@ -47,7 +49,7 @@ def source_hash() -> str:
 
 
 def needs_build() -> bool:
-    return _stale(LIB, [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)])
+    return _stale(LIB, [os.path.join(CSRC, f) for f in SOURCES + HEADERS + HOST_HEADERS] + [os.path.abspath(__file__)])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -57,12 +59,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, f) for f in HEADERS + HOST_HEADERS] + [os.path.abspath(__file__)]
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
         path = os.path.join(CSRC, src)
-        if force or _stale(obj, [path] + headers):
+        deps = headers if not src.endswith(".hip") else [os.path.join(CSRC, f) for f in HEADERS]  # (kernels see no host header)
+        if force or _stale(obj, [path] + deps):
             cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)

@@ -1,0 +1,775 @@
+// n1k_exchange.cpp — partial groups in and out of a handle, the hash partition of the row exchange, and the collectives
+// (RCCL, or the loopback transport) behind n1k_comm_* / n1k_exchange_* / n1k_gather_groups.
+#include "n1k_engine.h"
+
+using namespace n1k;
+using namespace n1k_eng;
+
+#include <rccl/rccl.h>
+
+// Filter + hash partition of a bound batch (bind_columns(h, b, defer = true) came first): the run-time-built kernel of the
+// plan's shape when there is one (large batches, or jit = 2: n1k_spec.h scan_spec_partition_body — wide loads, arithmetic
+// in registers, survivors written in runs), else the interpreting partition_kernel over materialised derived columns.
+static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) {
+    // packed regions (the row exchange): A.sub_rows = rows per sub-region; whoever writes dense runs converts the counts
+    const uint64_t seg_rows = A.region_bytes ? A.sub_rows : 0;
+    A.nsub = 1;
+    if (b->nrows == 0) {
+        if (seg_rows) HIP_TRY(h, launch_dense_to_segments(A.counts, A.nparts, A.count_stride, seg_rows, h->stream));
+        return materialize_derived(h, b);
+    }
+    const uint64_t n = b->nrows;
+    FastArgs F;
+    const JitKernel* jit = nullptr;
+    const bool fuse = !h->derived.empty() && !h->derived_ready;
+    if (h->opt_spec && h->opt_jit && (h->opt_jit == 2 || n >= h->opt_jit_min_rows) && n < (1ull << 31) && (!fuse || h->opt_fuse_arith) &&
+        sizeof(Program) + sizeof(FastArgs) + sizeof(PartArgs) + 64 <= 4096 && build_fast_args(h, 1u << 15, F, fuse, true)) {
+        // what the staging needs in LDS (n1k_spec.h PartLds: 2048 rows x (9 B per TAGGED64 column, 4 B per DICT32 column, 1))
+        size_t lds = 2048 + 2048;
+        for (uint32_t c = 0; c < F.ncols; c++) lds += 2048u * (F.cols[c].kind == COLK_DICT32 ? 4u : 9u);
+        if (lds <= 60 * 1024) {
+            SpecSig sig = make_plan_sig(h, F);
+            sig.mode = 1;
+            sig.hashed = 0;  // (no table in this mode)
+            jit = jit_get(sig);
+            if (jit->failed || !jit->part_wide) {
+                h->jit_log = jit->log;
+                jit = nullptr;
+            }
+        }
+    }
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    if (jit) {
+        bool aligned = true;
+        for (uint32_t c = 0; c < F.ncols; c++) {
+            F.cols[c] = h->prog.cols[c];
+            aligned &= ((uintptr_t)F.cols[c].tags % 2 == 0) && ((uintptr_t)F.cols[c].payload % 16 == 0) && ((uintptr_t)F.cols[c].codes % 8 == 0);
+        }
+        const bool wide = aligned && h->opt_wide && n >= 2;
+        F.nrows = (uint32_t)n;
+        F.row_base = h->row_base;
+        F.err_flags = h->d_errp;
+        // 256-thread workgroups (tiles of 1024 rows, one in flight, six per CU: many independent workgroups overlap the wait
+        // for each tile's reservation) or 512-thread ones (2048 rows, two tiles in flight, two per CU)
+        const uint32_t pblock = wide && h->opt_part_block == 256 ? 256u : 512u;
+        const uint64_t tiles = (n + pblock * 4 - 1) / (pblock * 4);
+        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * (h->opt_part_per_cu ? h->opt_part_per_cu : (pblock == 256 ? 6u : 2u)), tiles));
+        // many tiles: every destination's region in kRowSubs sub-regions with their own counters, workgroups dealt round-robin
+        // (tile t goes to sub-region t % kRowSubs: an even share of the rows whatever their order)
+        if (seg_rows && h->opt_part_subs && (tiles >= 4096 || h->opt_part_subs == 2)) {
+            A.nsub = kRowSubs;
+            grid = (grid + kRowSubs - 1) / kRowSubs * kRowSubs;
+        }
+        if (e0) (void)hipEventRecord(e0, h->stream);
+        HIP_TRY(h, jit_launch_partition(jit, h->prog, F, A, grid, wide, pblock, h->stream));
+        h->stats.spec_kernel = F.nderived ? 3u : 2u;
+    } else {
+        n1k_status st = materialize_derived(h, b);
+        if (st != N1K_OK) return st;
+        const uint64_t ntiles = (n + 2047) / 2048;  // partition_kernel<4, 512>
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->num_cus * 4, ntiles));
+        if (e0) (void)hipEventRecord(e0, h->stream);
+        HIP_TRY(h, launch_partition(h->prog, A, grid, h->stream));
+        h->stats.spec_kernel = 0;
+    }
+    if (seg_rows && A.nsub == 1) HIP_TRY(h, launch_dense_to_segments(A.counts, A.nparts, A.count_stride, seg_rows, h->stream));
+    if (e1) (void)hipEventRecord(e1, h->stream);
+    h->events.emplace_back(e0, e1);
+    return N1K_OK;
+}
+
+extern "C" {
+
+n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uint32_t nparts, uint64_t capacity_rows,
+                                      const n1k_col* out_cols, uint64_t* out_counts) {
+    return guarded(h, [&]() -> n1k_status {
+    if (!h || !batch || !out_cols || !out_counts || nparts == 0) return N1K_INVALID;
+    if (nparts > kMaxParts) return fail(h, N1K_INVALID, "at most %u destinations per partition call", kMaxParts);
+    if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
+    if (!h->plan.has_group) return fail(h, N1K_INVALID, "partitioning needs group keys");
+    if (sizeof(Program) + sizeof(PartArgs) + 64 > 4096) return fail(h, N1K_UNSUPPORTED, "kernel arguments exceed 4 KiB");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    st = validate_batch(h, batch);
+    if (st != N1K_OK) return st;
+    if (!h->layout_fixed) {
+        st = fix_layout(h, batch);
+        if (st != N1K_OK) return st;
+    }
+    PartArgs A{};
+    st = bind_columns(h, batch, true);
+    if (st != N1K_OK) return st;
+    A.ncopy = (uint32_t)h->plan.paths.size();  // derived columns are recomputed by the receiver
+    for (uint32_t c = 0; c < A.ncopy; c++) {
+        if (out_cols[c].kind != batch->cols[c].kind) return fail(h, N1K_INVALID, "output column %u has another kind", c);
+        A.out_tags[c] = (uint8_t*)out_cols[c].tags;
+        A.out_payload[c] = (uint64_t*)out_cols[c].payload;
+        A.out_codes[c] = (uint32_t*)out_cols[c].codes;
+    }
+    st = ensure_rank(h);
+    if (st != N1K_OK) return st;
+    A.nrows = batch->nrows;
+    A.capacity = capacity_rows;
+    A.nparts = nparts;
+    A.counts = (unsigned long long*)out_counts;
+    A.err_flags = h->d_errp;
+    HIP_TRY(h, hipMemsetAsync(out_counts, 0, nparts * sizeof(uint64_t), h->stream));
+    st = run_partition(h, batch, A);
+    if (st != N1K_OK) return st;
+    uint32_t err_flags = 0;
+    HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (err_flags & ERR_TABLE_FULL) return fail(h, N1K_OOM, "partition region capacity (%llu rows) exceeded", (unsigned long long)capacity_rows);
+    if (err_flags & ERR_UNPACKABLE_KEY) return fail(h, N1K_UNSUPPORTED_DATA, "a group key value does not fit the packed key");
+    if (err_flags & ERR_UNSUPPORTED_VALUE) return fail(h, N1K_UNSUPPORTED_DATA, "a value outside the device subset was met");
+    h->stats.rows_in += batch->nrows;
+    h->stats.batches += 1;
+    return N1K_OK;
+    });
+}
+
+uint32_t n1k_partial_words(const n1k_handle* h) { return h ? h->prog.glob_words : 0; }
+
+uint64_t n1k_partial_region_bytes(const n1k_handle* h, uint64_t capacity_groups) {
+    if (!h) return 0;
+    return 8ull * (2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words));
+}
+
+n1k_status n1k_export_partials_async(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
+    return guarded(h, [&]() -> n1k_status {
+    if (!h || !out || nparts == 0 || capacity_groups == 0) return N1K_INVALID;
+    if (h->pending.count) {
+        n1k_status pst = flush_pending(h);
+        if (pst != N1K_OK) return pst;
+    }
+    if (!h->plan.has_group) return fail(h, N1K_INVALID, "no groups in a Filter-only plan");
+    if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    uint64_t region_words = 2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words);
+    HIP_TRY(h, hipMemsetAsync(out, 0, (size_t)nparts * region_words * 8, h->stream));  // headers (and padding) to zero
+    if (h->table.capacity)
+        HIP_TRY(h, launch_export_partials(h->prog, h->table, nparts, capacity_groups, (uint64_t*)out, region_words,
+                                          h->d_errp, h->stream));
+    return N1K_OK;
+    });
+}
+
+n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t capacity_groups, void* out) {
+    return guarded(h, [&]() -> n1k_status {
+    n1k_status st = n1k_export_partials_async(h, nparts, capacity_groups, out);
+    if (st != N1K_OK) return st;
+    uint32_t err_flags = 0;
+    unsigned long long sel = 0, wide = 0;
+    HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&sel, h->d_counters.p, sizeof sel, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&wide, h->d_counters.p + 13, sizeof wide, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stats.rows_selected = sel;
+    h->stats.wide_key_values = wide;
+    // codes of the wide-value tables mean nothing on another device: such groups travel as rows instead
+    if (wide) {
+        HIP_TRY(h, hipMemsetAsync(h->d_errp, 0, 4, h->stream));  // a region overflow of the abandoned export is moot
+        return fail(h, N1K_UNSUPPORTED, "group keys hold %llu float / wide integer values: use the row exchange", wide);
+    }
+    if (err_flags & ERR_TABLE_FULL) {
+        HIP_TRY(h, hipMemsetAsync(h->d_errp, 0, 4, h->stream));
+        return fail(h, N1K_OOM, "more than %llu groups for one destination: raise the region capacity",
+                    (unsigned long long)capacity_groups);
+    }
+    return N1K_OK;
+    });
+}
+
+n1k_status n1k_merge_partials_device(n1k_handle* h, uint32_t nregions, uint64_t capacity_groups, const void* in) {
+    return guarded(h, [&]() -> n1k_status {
+    if (!h || !in || nregions == 0 || capacity_groups == 0) return N1K_INVALID;
+    if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
+    if (!h->layout_fixed) return fail(h, N1K_INVALID, "merge needs the key layout: push a batch (even an empty one) first");
+    if (h->pending.count) {
+        n1k_status pst = flush_pending(h);
+        if (pst != N1K_OK) return pst;
+    }
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    // the incoming groups bound the growth of the table
+    uint64_t saved = h->row_base;
+    h->row_base += (uint64_t)nregions * capacity_groups;
+    st = ensure_table(h, 0);
+    h->row_base = saved;
+    if (st != N1K_OK) return st;
+    uint64_t region_words = 2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words);
+    HIP_TRY(h, launch_merge_partials(h->prog, h->table, nregions, capacity_groups, (const uint64_t*)in, region_words,
+                                     h->d_errp, h->d_counters.p + 1, h->stream));
+    h->merged_groups_bound += (uint64_t)nregions * capacity_groups;
+    return N1K_OK;
+    });
+}
+
+n1k_status n1k_export_groups(n1k_handle* h, const void** blob, size_t* len) {
+    return guarded(h, [&]() -> n1k_status {
+    if (!h || !blob || !len) return N1K_INVALID;
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    st = flush_pending(h);
+    if (st != N1K_OK) return st;
+    unsigned long long ng = 0;
+    HIP_TRY(h, hipMemcpyAsync(&ng, h->d_counters.p + 1, sizeof ng, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    uint64_t cap = std::max<uint64_t>(ng, 1);
+    uint64_t bytes = n1k_partial_region_bytes(h, cap);
+    DevBuf<uint64_t> tmp;
+    HIP_TRY(h, tmp.ensure(bytes / 8));
+    st = n1k_export_partials_device(h, 1, cap, tmp.p);
+    if (st == N1K_OK) {
+        h->export_blob.resize(bytes + 16);
+        uint64_t hdr[2] = {0x4e314b5041525431ull /* "N1KPART1" */, cap};
+        memcpy(h->export_blob.data(), hdr, 16);
+        hipError_t e = hipMemcpy(h->export_blob.data() + 16, tmp.p, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(h, N1K_DEVICE_ERROR, "copy of exported groups failed: %s", hipGetErrorString(e));
+    }
+    tmp.release();
+    if (st != N1K_OK) return st;
+    *blob = h->export_blob.data();
+    *len = h->export_blob.size();
+    return N1K_OK;
+    });
+}
+
+n1k_status n1k_merge_groups(n1k_handle* h, const void* blob, size_t len) {
+    return guarded(h, [&]() -> n1k_status {
+    if (!h || !blob || len < 32) return N1K_INVALID;
+    uint64_t hdr[2];
+    memcpy(hdr, blob, 16);
+    if (hdr[0] != 0x4e314b5041525431ull) return fail(h, N1K_INVALID, "not an exported group blob");
+    uint64_t cap = hdr[1];
+    if (n1k_partial_region_bytes(h, cap) + 16 != len) return fail(h, N1K_INVALID, "blob does not match this plan");
+    n1k_status st = ensure_device(h);
+    if (st != N1K_OK) return st;
+    DevBuf<uint64_t> tmp;
+    HIP_TRY(h, tmp.ensure((len - 16) / 8));
+    HIP_TRY(h, hipMemcpy(tmp.p, (const char*)blob + 16, len - 16, hipMemcpyHostToDevice));
+    st = n1k_merge_partials_device(h, 1, cap, tmp.p);
+    if (st == N1K_OK) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    tmp.release();
+    return st;
+    });
+}
+
+// ---------------------------------------------------------------- multi-GPU: RCCL behind the C ABI
+//
+// One communicator per rank (one rank per GPU; on one node every GPU pair has its own xGMI link, so the grouped
+// send / recv of an all-to-all keeps all of a GPU's links busy at once).  Everything below is ordered on the sending
+// handle's stream; the receiving handle's stream waits on an event; nothing waits on the host before n1k_finish.
+
+}  // extern "C" (the communicator struct is C++)
+
+// Loopback transport (n1k_comm_create_loopback): the ranks are threads of ONE process sharing one device — every
+// collective is a rendezvous (barrier), device-to-device copies out of the peers' buffers, and a second rendezvous before
+// anybody reuses its send buffer.  It exists so that the world_size > 1 code paths of the exchange (region offsets, header
+// lists, verdicts, segmented receives, agreed capacities) can be run and checked on a single GPU; RCCL refuses two ranks on
+// one device.
+struct LoopHub {
+    int world = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void*> ptr;
+    std::vector<unsigned long long> val;
+    int refs = 0;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+        } else
+            cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
+struct n1k_comm {
+    ncclComm_t comm = nullptr;
+    LoopHub* hub = nullptr;  // non-null: loopback transport
+    int rank = 0, world = 1, device = 0;
+    DevBuf<char> send, recv, gsend, grecv;
+    DevBuf<unsigned long long> scalar;
+    hipEvent_t ev = nullptr;
+    std::string last_error;
+    uint64_t gather_cap = 1024;    // records per slot of n1k_gather_groups (the same on every rank, see there)
+    std::vector<char> ghost;       // gathered records on the host
+    std::vector<n1k_value> gkeys, gaggs;
+};
+
+namespace {
+
+n1k_status cfail(n1k_comm* c, n1k_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->last_error = buf;
+    g_create_error = buf;
+    return st;
+}
+
+#define NCCL_TRY(c, expr)                                                                                   \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess) return cfail(c, N1K_DEVICE_ERROR, "%s failed: %s", #expr, ncclGetErrorString(_r)); \
+    } while (0)
+#define CHIP_TRY(c, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return cfail(c, _e == hipErrorOutOfMemory ? N1K_OOM : N1K_DEVICE_ERROR, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// all-to-all of equal regions: region p of `send` goes to rank p, region s of `recv` comes from rank s.  This rank's own
+// region is not copied: the caller reads it where it lies (`self` returns its address).
+// loopback: what every peer published, copied (or read) by everybody between two rendezvous
+template <class Copy>
+n1k_status loop_collective(n1k_comm* c, const void* send, hipStream_t st, Copy copy) {
+    // (a rank whose own part fails still keeps both rendezvous: its peers must not be left waiting for it)
+    hipError_t e = hipStreamSynchronize(st);
+    c->hub->ptr[c->rank] = e == hipSuccess ? send : nullptr;
+    c->hub->barrier();  // every rank's send buffer is complete and published
+    if (e == hipSuccess) {
+        for (int p = 0; p < c->world; p++)
+            if (!c->hub->ptr[p]) e = hipErrorUnknown;  // (a peer failed before publishing)
+    }
+    if (e == hipSuccess) e = copy();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    c->hub->barrier();  // everybody has read everybody: the send buffers may be overwritten
+    return e == hipSuccess ? N1K_OK : cfail(c, N1K_DEVICE_ERROR, "loopback: collective failed: %s", hipGetErrorString(e));
+}
+
+n1k_status all_gather_bytes(n1k_comm* c, const char* send, char* recv, size_t bytes, hipStream_t st) {
+    if (c->hub)
+        return loop_collective(c, send, st, [&]() -> hipError_t {
+            for (int p = 0; p < c->world; p++) {
+                hipError_t e = hipMemcpyAsync(recv + (size_t)p * bytes, c->hub->ptr[p], bytes, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        });
+    NCCL_TRY(c, ncclAllGather(send, recv, bytes, ncclChar, c->comm, st));
+    return N1K_OK;
+}
+
+n1k_status all_to_all_regions(n1k_comm* c, const char* send, char* recv, size_t region, hipStream_t st, const char** self) {
+    *self = send + (size_t)c->rank * region;
+    if (c->hub)
+        return loop_collective(c, send, st, [&]() -> hipError_t {
+            for (int p = 0; p < c->world; p++) {
+                if (p == c->rank) continue;
+                hipError_t e = hipMemcpyAsync(recv + (size_t)p * region, (const char*)c->hub->ptr[p] + (size_t)c->rank * region, region,
+                                              hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        });
+    NCCL_TRY(c, ncclGroupStart());
+    for (int p = 0; p < c->world; p++) {
+        if (p == c->rank) continue;
+        NCCL_TRY(c, ncclSend(send + (size_t)p * region, region, ncclChar, p, c->comm, st));
+        NCCL_TRY(c, ncclRecv(recv + (size_t)p * region, region, ncclChar, p, c->comm, st));
+    }
+    NCCL_TRY(c, ncclGroupEnd());
+    return N1K_OK;
+}
+
+int sender_column(const n1k_handle* snd, const std::string& path) {
+    for (size_t j = 0; j < snd->plan.paths.size(); j++)
+        if (snd->plan.paths[j] == path) return (int)j;
+    return -1;
+}
+
+// the receiving handle learns the key layout (column kinds) and the dictionary from the sending one: both were built
+// from the same plan, in one process
+n1k_status prepare_receiver(n1k_handle* snd, n1k_handle* rcv) {
+    if (!snd->layout_fixed) return fail(snd, N1K_INVALID, "the sender has seen no batch yet");
+    for (size_t i = rcv->dict.size(); i < snd->dict.size(); i++)
+        if (intern(rcv, snd->dict[i]) != (uint32_t)i) return fail(rcv, N1K_INVALID, "sender and receiver dictionaries differ");
+    n1k_status st = ensure_device(rcv);
+    if (st != N1K_OK) return st;
+    if (!rcv->layout_fixed) {
+        // (the receiver has no Filter: its columns are the sender's in another order — matched by their path text)
+        std::vector<n1k_col> cols(std::max<size_t>(1, rcv->plan.paths.size()));
+        for (size_t i = 0; i < rcv->plan.paths.size(); i++) {
+            const int j = sender_column(snd, rcv->plan.paths[i]);
+            if (j < 0) return fail(rcv, N1K_INVALID, "the receiver's column %s is not a column of the sender", rcv->plan.paths[i].c_str());
+            cols[i].kind = snd->col_kinds[j];
+        }
+        n1k_batch b{};
+        b.ncols = (uint32_t)rcv->plan.paths.size();
+        b.cols = cols.data();
+        st = push_device(rcv, &b);  // an empty batch: fixes the layout, runs nothing
+    }
+    return st;
+}
+
+n1k_status order_streams(n1k_comm* c, n1k_handle* snd, n1k_handle* rcv) {
+    if (snd->stream == rcv->stream) return N1K_OK;
+    CHIP_TRY(c, hipEventRecord(c->ev, snd->stream));
+    CHIP_TRY(c, hipStreamWaitEvent(rcv->stream, c->ev, 0));
+    return N1K_OK;
+}
+
+// layout of one packed row region for `cap` rows (kRowSubs sub-regions of cap / kRowSubs rows) of the plan's input columns:
+// the header (sub-region x's row count at word x * kCursorStride, the verdict in word 1), then per column its arrays, each
+// starting on a 16-byte boundary
+size_t row_region_layout(const n1k_handle* h, uint64_t cap, std::vector<size_t>& off_a, std::vector<size_t>& off_b) {
+    size_t at = (size_t)kRowSubs * kCursorStride * 8;  // header: the sub-regions' counts, 128 bytes apart; verdict in word 1
+    const size_t nc = h->plan.paths.size();
+    off_a.assign(nc, 0);
+    off_b.assign(nc, 0);
+    auto pad = [](size_t x) { return (x + 15) / 16 * 16; };
+    for (size_t i = 0; i < nc; i++) {
+        if (h->col_kinds[i] == N1K_COL_DICT32) {
+            off_a[i] = at;
+            at = pad(at + cap * 4);
+        } else {
+            off_a[i] = at;  // payload
+            at = pad(at + cap * 8);
+            off_b[i] = at;  // tags
+            at = pad(at + cap);
+        }
+    }
+    return (at + 127) / 128 * 128;
+}
+
+}  // namespace
+
+extern "C" {
+
+n1k_status n1k_comm_unique_id(void* id) {
+    return guarded(nullptr, [&]() -> n1k_status {
+        if (!id) return N1K_INVALID;
+        static_assert(sizeof(ncclUniqueId) == N1K_COMM_ID_BYTES, "N1K_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+        ncclUniqueId u;
+        NCCL_TRY(nullptr, ncclGetUniqueId(&u));
+        memcpy(id, &u, sizeof u);
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_comm_create(const void* id, int rank, int world, int device, n1k_comm** out) {
+    return guarded(nullptr, [&]() -> n1k_status {
+        if (out) *out = nullptr;
+        if (!id || !out || world < 1 || rank < 0 || rank >= world || world > (int)kMaxParts) return cfail(nullptr, N1K_INVALID, "bad communicator arguments");
+        auto* c = new n1k_comm();
+        c->rank = rank;
+        c->world = world;
+        c->device = device;
+        auto bail = [&](n1k_status st) {
+            delete c;
+            return st;
+        };
+        if (hipSetDevice(device) != hipSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "no HIP device %d", device));
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof u);
+        ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+        if (r != ncclSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "ncclCommInitRank failed: %s", ncclGetErrorString(r)));
+        if (hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "hipEventCreate failed"));
+        *out = c;
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_comm_create_loopback(int world, int device, n1k_comm** out) {
+    return guarded(nullptr, [&]() -> n1k_status {
+        if (!out || world < 1 || world > (int)kMaxParts) return cfail(nullptr, N1K_INVALID, "bad communicator arguments");
+        if (hipSetDevice(device) != hipSuccess) return cfail(nullptr, N1K_DEVICE_ERROR, "no HIP device %d", device);
+        auto* hub = new LoopHub();
+        hub->world = world;
+        hub->ptr.assign(world, nullptr);
+        hub->val.assign(world, 0);
+        hub->refs = world;
+        for (int r = 0; r < world; r++) {
+            auto* c = new n1k_comm();
+            c->rank = r;
+            c->world = world;
+            c->device = device;
+            c->hub = hub;
+            (void)hipEventCreateWithFlags(&c->ev, hipEventDisableTiming);
+            out[r] = c;
+        }
+        return N1K_OK;
+    });
+}
+
+void n1k_comm_destroy(n1k_comm* c) {
+    if (!c) return;
+    try {
+        (void)hipSetDevice(c->device);
+        if (c->hub) {
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(c->hub->mu);
+                last = --c->hub->refs == 0;
+            }
+            if (last) delete c->hub;
+        }
+        if (c->comm) (void)ncclCommDestroy(c->comm);
+        if (c->ev) (void)hipEventDestroy(c->ev);
+        c->send.release();
+        c->recv.release();
+        c->gsend.release();
+        c->grecv.release();
+        c->scalar.release();
+        delete c;
+    } catch (...) {
+    }
+}
+
+const char* n1k_comm_last_error(const n1k_comm* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
+int n1k_comm_rank(const n1k_comm* c) { return c ? c->rank : -1; }
+int n1k_comm_world(const n1k_comm* c) { return c ? c->world : 0; }
+
+n1k_status n1k_comm_max_u64(n1k_comm* c, n1k_handle* h, uint64_t value, uint64_t* out) {
+    return guarded(h, [&]() -> n1k_status {
+        if (!c || !h || !out) return N1K_INVALID;
+        n1k_status st = ensure_device(h);
+        if (st != N1K_OK) return st;
+        if (c->hub) {  // loopback: values through the hub
+            c->hub->val[c->rank] = value;
+            c->hub->barrier();
+            unsigned long long mx = 0;
+            for (int p = 0; p < c->world; p++) mx = std::max(mx, c->hub->val[p]);
+            c->hub->barrier();
+            *out = mx;
+            return N1K_OK;
+        }
+        HIP_TRY(h, c->scalar.ensure(4));
+        unsigned long long v = value, m = 0;
+        HIP_TRY(h, hipMemcpyAsync(c->scalar.p, &v, 8, hipMemcpyHostToDevice, h->stream));
+        NCCL_TRY(c, ncclAllReduce(c->scalar.p, c->scalar.p + 1, 1, ncclUint64, ncclMax, c->comm, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(&m, c->scalar.p + 1, 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        *out = m;
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_exchange_partials(n1k_comm* c, n1k_handle* sender, n1k_handle* receiver, uint64_t capacity_groups, int gathered) {
+    return guarded(sender, [&]() -> n1k_status {
+        if (!c || !sender || !receiver || capacity_groups == 0) return N1K_INVALID;
+        n1k_status st = prepare_receiver(sender, receiver);
+        if (st != N1K_OK) return st == N1K_INVALID && sender->last_error.empty() ? fail(sender, st, "%s", receiver->last_error.c_str()) : st;
+        const size_t region = (size_t)n1k_partial_region_bytes(sender, capacity_groups);
+        const uint32_t nsend = gathered ? 1u : (uint32_t)c->world;
+        HIP_TRY(sender, c->send.ensure(region * nsend));
+        HIP_TRY(sender, c->recv.ensure(region * (size_t)c->world));
+        st = n1k_export_partials_async(sender, nsend, capacity_groups, c->send.p);
+        if (st != N1K_OK) return st;
+        if (gathered) {
+            // every rank ends with every rank's partial groups: no second collective for the result
+            st = all_gather_bytes(c, c->send.p, c->recv.p, region, sender->stream);
+            if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+        } else {
+            const char* self = nullptr;
+            st = all_to_all_regions(c, c->send.p, c->recv.p, region, sender->stream, &self);
+            if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+            // (this rank's own region joins the received ones by a device copy of G groups, not through the fabric)
+            HIP_TRY(sender, hipMemcpyAsync(c->recv.p + (size_t)c->rank * region, self, region, hipMemcpyDeviceToDevice, sender->stream));
+        }
+        st = order_streams(c, sender, receiver);
+        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+        st = n1k_merge_partials_device(receiver, (uint32_t)c->world, capacity_groups, c->recv.p);
+        if (st != N1K_OK) return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, uint64_t capacity_rows) {
+    return guarded(sender, [&]() -> n1k_status {
+        if (!c || !sender || !receiver || !batch || capacity_rows == 0) return N1K_INVALID;
+        if (!sender->plan.has_group) return fail(sender, N1K_INVALID, "the row exchange partitions on group keys");
+        if (sender->stop_flag.load()) return fail(sender, N1K_STOPPED, "operator was stopped");
+        n1k_status st = ensure_device(sender);
+        if (st != N1K_OK) return st;
+        st = validate_batch(sender, batch);
+        if (st != N1K_OK) return st;
+        if (!sender->layout_fixed) {
+            st = fix_layout(sender, batch);
+            if (st != N1K_OK) return st;
+        }
+        st = prepare_receiver(sender, receiver);
+        if (st != N1K_OK) return st;
+        const uint64_t cap = (capacity_rows + 16 * kRowSubs - 1) / (16 * kRowSubs) * (16 * kRowSubs);  // kRowSubs sub-regions of whole 16-row groups
+        if (cap >= (1ull << 31)) return fail(sender, N1K_INVALID, "row regions hold fewer than 2^31 rows");
+        std::vector<size_t> off_a, off_b;
+        const size_t region = row_region_layout(sender, cap, off_a, off_b);
+        const uint32_t P = (uint32_t)c->world;
+        HIP_TRY(sender, c->send.ensure(region * P));
+        HIP_TRY(sender, c->recv.ensure(region * P));
+        // 1. Filter + hash partition on the group key values into the packed regions (headers zeroed first)
+        for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * region, 0, (size_t)kRowSubs * kCursorStride * 8, sender->stream));
+        st = bind_columns(sender, batch, true);
+        if (st != N1K_OK) return st;
+        st = ensure_rank(sender);
+        if (st != N1K_OK) return st;
+        PartArgs A{};
+        A.nrows = batch->nrows;
+        A.capacity = cap;
+        A.nparts = P;
+        A.ncopy = (uint32_t)sender->plan.paths.size();
+        A.counts = (unsigned long long*)c->send.p;
+        A.count_stride = (uint32_t)(region / 8);
+        A.region_bytes = region;
+        A.sub_rows = cap / kRowSubs;
+        A.err_flags = sender->d_errp;
+        for (uint32_t i = 0; i < A.ncopy; i++) {
+            if (sender->col_kinds[i] == N1K_COL_DICT32) A.out_codes[i] = (uint32_t*)(c->send.p + off_a[i]);
+            else {
+                A.out_payload[i] = (uint64_t*)(c->send.p + off_a[i]);
+                A.out_tags[i] = (uint8_t*)(c->send.p + off_b[i]);
+            }
+        }
+        st = run_partition(sender, batch, A);
+        if (st != N1K_OK) return st;
+        sender->stats.rows_in += batch->nrows;
+        sender->stats.batches += 1;
+        // 2. ONE all-to-all: counts, verdicts and rows of every column travel in the same region
+        const char* self = nullptr;
+        st = all_to_all_regions(c, c->send.p, c->recv.p, region, sender->stream, &self);
+        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+        st = order_streams(c, sender, receiver);
+        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+        // 3. the owner's InitialGroup over what it received: one batch per source, each with its row count on the device.
+        //    (Headers are checked first: a sender that overflowed voids the step on every rank.)
+        std::vector<const char*> src(P);
+        for (uint32_t sidx = 0; sidx < P; sidx++) src[sidx] = (int)sidx == c->rank ? self : c->recv.p + (size_t)sidx * region;
+        {
+            HeaderList H{};
+            for (uint32_t sidx = 0; sidx < P; sidx++) H.h[sidx] = (unsigned long long*)src[sidx];
+            HIP_TRY(receiver, launch_exchange_verdict(H, P, receiver->d_errp, receiver->stream));
+        }
+        for (uint32_t sidx = 0; sidx < P; sidx++) {
+            const uint32_t rnc = (uint32_t)receiver->plan.paths.size();
+            std::vector<n1k_col> cols(std::max<size_t>(1, rnc));
+            for (uint32_t i = 0; i < rnc; i++) {
+                const int j = sender_column(sender, receiver->plan.paths[i]);  // (prepare_receiver checked that it exists)
+                cols[i].kind = sender->col_kinds[j];
+                if (cols[i].kind == N1K_COL_DICT32) cols[i].codes = (const uint32_t*)(src[sidx] + off_a[j]);
+                else {
+                    cols[i].payload = (const uint64_t*)(src[sidx] + off_a[j]);
+                    cols[i].tags = (const uint8_t*)(src[sidx] + off_b[j]);
+                }
+            }
+            n1k_batch rb{};
+            rb.nrows = cap;
+            rb.ncols = rnc;
+            rb.cols = cols.data();
+            receiver->push_seg_counts = (const unsigned long long*)src[sidx];  // (the region's header)
+            receiver->push_nseg = kRowSubs;
+            receiver->push_seg_rows = cap / kRowSubs;
+            st = push_device(receiver, &rb);
+            receiver->push_seg_counts = nullptr;
+            receiver->push_nseg = 0;
+            if (st != N1K_OK) return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
+        }
+        return N1K_OK;
+    });
+}
+
+n1k_status n1k_rows_step(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, n1k_handle* merger,
+                         uint64_t capacity_rows, n1k_result* out, int* worst_status) {
+    if (!c || !sender || !batch || !receiver || !merger || !out || !worst_status) return N1K_INVALID;
+    *worst_status = N1K_OK;
+    n1k_status st = n1k_reset(receiver);
+    if (st == N1K_OK) st = n1k_reset(sender);  // (the sender holds no groups in this mode; its counters and timers start over)
+    if (st == N1K_OK) st = n1k_exchange_rows(c, sender, batch, receiver, capacity_rows);
+    if (st != N1K_OK) return st;
+    n1k_result local;
+    st = n1k_finish(receiver, &local);
+    // a region that overflowed fails the step on EVERY rank alike (the verdict travelled in the headers): no gather, the
+    // caller enlarges the regions and repeats; any other failure is this owner's alone and travels in the gather
+    if (st == N1K_OOM && receiver->last_error.find("region") != std::string::npos) return st;
+    n1k_status gs = n1k_gather_groups_status(c, merger, st == N1K_OK ? &local : nullptr, (int)st, out, worst_status);
+    return gs != N1K_OK ? gs : st;
+}
+
+n1k_status n1k_gather_groups(n1k_comm* c, n1k_handle* h, const n1k_result* local, n1k_result* out) {
+    int worst = 0;
+    n1k_status st = n1k_gather_groups_status(c, h, local, N1K_OK, out, &worst);
+    if (st == N1K_OK && worst != N1K_OK) return fail(h, (n1k_status)worst, "a peer rank's step failed with status %d", worst);
+    return st;
+}
+
+n1k_status n1k_gather_groups_status(n1k_comm* c, n1k_handle* h, const n1k_result* local, int local_status, n1k_result* out, int* worst_status) {
+    return guarded(h, [&]() -> n1k_status {
+        if (!c || !h || !out || !worst_status || (!local && local_status == N1K_OK)) return N1K_INVALID;
+        *worst_status = local_status;
+        static const n1k_result kNone{};
+        if (!local || local_status != N1K_OK) local = &kNone;  // a rank whose step failed contributes no groups, only its status
+        if (h->has_array_agg) return fail(h, N1K_UNSUPPORTED, "array_agg values are interned per rank: gather the rows on the host");
+        n1k_status st = ensure_device(h);
+        if (st != N1K_OK) return st;
+        const size_t nk = h->plan.keys.size(), na = h->plan.aggs.size();
+        const size_t rec = (nk + na) * sizeof(n1k_value);
+        // ONE all-gather of fixed-size slots [count][records]: the slot size is part of the collective's shape, so it is the
+        // same on every rank by construction — it starts at 1024 records and only ever changes on what ALL ranks read in
+        // the gathered headers (a count beyond the slot: everybody doubles to fit the largest and gathers again)
+        unsigned long long mine = local->ngroups;
+        std::vector<char> stage;
+        size_t slot = 0;
+        for (;;) {
+            const uint64_t capg = c->gather_cap;
+            slot = 16 + (size_t)capg * rec;
+            stage.assign(slot, 0);
+            memcpy(stage.data(), &mine, 8);
+            const unsigned long long my_status = (unsigned long long)(unsigned)local_status;
+            memcpy(stage.data() + 8, &my_status, 8);
+            for (uint64_t g = 0; g < std::min<uint64_t>(local->ngroups, capg); g++) {
+                char* p = stage.data() + 16 + (size_t)g * rec;
+                if (nk) memcpy(p, local->keys + g * nk, nk * sizeof(n1k_value));
+                if (na) memcpy(p + nk * sizeof(n1k_value), local->aggs + g * na, na * sizeof(n1k_value));
+            }
+            HIP_TRY(h, c->gsend.ensure(slot));
+            HIP_TRY(h, c->grecv.ensure(slot * (size_t)c->world));
+            HIP_TRY(h, hipMemcpyAsync(c->gsend.p, stage.data(), slot, hipMemcpyHostToDevice, h->stream));
+            st = all_gather_bytes(c, c->gsend.p, c->grecv.p, slot, h->stream);
+            if (st != N1K_OK) return fail(h, st, "%s", c->last_error.c_str());
+            c->ghost.resize(slot * (size_t)c->world);
+            HIP_TRY(h, hipMemcpyAsync(c->ghost.data(), c->grecv.p, c->ghost.size(), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            unsigned long long most = 0, bad = 0;
+            for (int r = 0; r < c->world; r++) {
+                unsigned long long n = 0, s = 0;
+                memcpy(&n, c->ghost.data() + (size_t)r * slot, 8);
+                memcpy(&s, c->ghost.data() + (size_t)r * slot + 8, 8);
+                most = std::max(most, n);
+                if (s && !bad) bad = s;  // (the lowest rank's failure: the same on every rank)
+            }
+            if (bad) {  // some rank's step failed: every rank learns it here, in the collective it would otherwise hang in
+                *worst_status = (int)bad;
+                memset(out, 0, sizeof *out);
+                return N1K_OK;
+            }
+            if (most <= capg) break;
+            while (c->gather_cap < most) c->gather_cap *= 2;
+        }
+        // 3. the union, in rank order; the plan's grouped tail (ORDER BY / OFFSET / LIMIT, projection) over it
+        c->gkeys.clear();
+        c->gaggs.clear();
+        for (int r = 0; r < c->world; r++) {
+            const char* base = c->ghost.data() + (size_t)r * slot;
+            unsigned long long n = 0;
+            memcpy(&n, base, 8);
+            for (unsigned long long g = 0; g < n; g++) {
+                const n1k_value* v = (const n1k_value*)(base + 16 + (size_t)g * rec);
+                c->gkeys.insert(c->gkeys.end(), v, v + nk);
+                c->gaggs.insert(c->gaggs.end(), v + nk, v + nk + na);
+            }
+        }
+        const uint64_t total = nk ? c->gkeys.size() / nk : (na ? c->gaggs.size() / na : 0);
+        return n1k_order_rows(h, total, c->gkeys.data(), c->gaggs.data(), out);
+    });
+}
+
+}  // extern "C"
