@@ -300,6 +300,77 @@ def by_rows(args, wl, local_rank: int) -> dict:
     return out
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks as child processes (one per GPU, the
+    same command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relay rank 0's JSON line, fail if any rank fails.
+    Runs BEFORE this process has imported torch or touched HIP: a process that has initialised the GPU must not start others."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    deadline = None
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                try:
+                    if i == 0:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    else:
+                        p.wait(timeout=0.2)
+                    rcs[i] = p.returncode
+                except subprocess.TimeoutExpired:
+                    pass
+        if deadline is None and any(rc not in (None, 0) for rc in rcs):
+            deadline = time.time() + 30  # a rank died: its peers get half a minute to notice, then they are stopped (by PID)
+        if deadline is not None and time.time() > deadline:
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %r\n" % bad)
+        return 1
+    return 0
+
+
+def dry_run(args, rank: int, world: int):
+    """--dry-run: the N > 1 start-up without a GPU — rendezvous over gloo, the communicator id from rank 0 to every rank, the
+    shard bounds of the synthetic data set, one all-reduce; rank 0 prints a JSON line.  (tests/test_distributed_cpu.py)"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from query_amd import distributed as qd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ident = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        ident = torch.from_numpy(np.frombuffer(os.urandom(128), dtype=np.uint8).copy())
+    dist.broadcast(ident, src=0)
+    total_rows, first, rows = qd.shard_bounds(args, rank, world)
+    check = torch.tensor([rows, int(ident.to(torch.int64).sum())], dtype=torch.int64)
+    gathered = [torch.zeros_like(check) for _ in range(world)]
+    dist.all_gather(gathered, check)
+    ok = sum(int(g[0]) for g in gathered) == total_rows and len({int(g[1]) for g in gathered}) == 1
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "total_rows": total_rows, "rows_per_rank": [int(g[0]) for g in gathered],
+                          "scaling": "strong" if args.total_rows else "weak", "ranks_agree": ok}))
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,20 +397,29 @@ def main():
                          "ablation: G groups travel instead of the rows); plans with DISTINCT always exchange rows")
     ap.add_argument("--no-ablation", action="store_true", help="multi-GPU: skip the partial-group ablation measured next to the row exchange")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank")
+    ap.add_argument("--dry-run", action="store_true", help="N > 1 start-up only, over gloo, no GPU (launcher, rendezvous, shard bounds)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: be one (before anything touches torch / HIP)
+        raise SystemExit(launch_ranks(args))
     if args.kcat is None:
         args.kcat = 100_000 if args.workload.startswith("config5") else 1000
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import torch
     import query_amd
     if query_amd.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the device path has no CPU fallback")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if query_amd.device_count() < local_world:  # (every rank of the node sees the same count: all of them stop here, none waits)
+        raise SystemExit("bench.py --gpus %d: %d ranks on this node but %d visible GPU(s); one rank per GPU" %
+                         (args.gpus, local_world, query_amd.device_count()))
     torch.cuda.set_device(local_rank)
 
     if world > 1 or args.force_dist:

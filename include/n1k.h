@@ -44,7 +44,9 @@ typedef enum n1k_status {
     N1K_OOM = 4,              /* host/device allocation failed or group-table capacity exceeded */
     N1K_STOPPED = 5,          /* n1k_stop() was observed (≙ processItem returning false after SendStop) */
     N1K_INVALID = 6,          /* bad argument / batch shape */
-    N1K_UNSUPPORTED_DATA = 7  /* a value met at run time is outside the device subset (see n1k_tag) */
+    N1K_UNSUPPORTED_DATA = 7, /* a value met at run time is outside the device subset (see n1k_tag) */
+    N1K_REGION_FULL = 8       /* multi-GPU: a fixed-capacity region of an exchange overflowed; the step is void on EVERY rank alike —
+                                 repeat it with a larger capacity on every rank (never an allocation failure: that is N1K_OOM) */
 } n1k_status;
 
 /* ------------------------------------------------------------ value tags -- */
@@ -259,7 +261,9 @@ n1k_status n1k_dict_get(const n1k_handle *h, uint32_t code, const char **ptr, si
  *         bring at least min_groups (4096) new groups; forced number of passes), "topk_min_groups" (ORDER BY ... LIMIT: the device top-k filter runs from this many groups on, default 65536),
  *         "distinct_set_slots" / "distinct_levels" (LDS set size, forced number of partition passes: tests),
  *         "distinct_region_cap" (forced capacity of the specialised scan's hash regions: tests), "dedupe_block" (256 / 512 / 1024: tuning), "wide_values" (before the first push: how many distinct float / wide-integer group key
- *         values the handle can code, default 1<<20; 0 = such keys are N1K_UNSUPPORTED_DATA)} */
+ *         values the handle can code, default 1<<20; 0 = such keys are N1K_UNSUPPORTED_DATA),
+ *         "inject_failure" (tests of the multi-GPU failure rules, one shot, on the SENDING handle: the next exchange call
+ *         pretends that 1 = its buffers, 2 = its partition / export, 3 = its receiving part failed)} */
 n1k_status n1k_set_option(n1k_handle *h, const char *name, int64_t value);
 
 /* ----------------------------------------------------------------- data ---- */
@@ -347,13 +351,13 @@ n1k_status n1k_partition_device_batch(n1k_handle *h, const n1k_batch *batch, uin
  * n1k_export_partials_device: write every group of the handle (packed key + raw accumulators) into `nparts`
  * regions of `out` (device memory) by a hash of the packed group key.  Region d (region_bytes = n1k_partial_region_bytes(h, capacity_groups)) is
  *     [count u64][verdict u64][keys: capacity x u64][accumulators: capacity x n1k_partial_words(h) x u64]
- * so that ONE all-to-all with equal splits moves all regions.  N1K_OOM when a region overflows; N1K_UNSUPPORTED
+ * so that ONE all-to-all with equal splits moves all regions.  N1K_REGION_FULL when a region overflows; N1K_UNSUPPORTED
  * when the keys hold float / wide-integer values (their codes are local to the handle).
  *
  * n1k_export_partials_async: the same, ordered on the handle's stream with no host synchronisation.  The two
  * failures above are written into the `verdict` word of EVERY region instead (bit 0 overflow, bit 1 wide values),
  * so that each receiver learns them from the exchange itself: n1k_merge_partials_device then merges nothing and
- * the receiver's n1k_finish returns N1K_OOM / N1K_UNSUPPORTED — on all ranks alike, which lets them retry in step.
+ * the receiver's n1k_finish returns N1K_REGION_FULL / N1K_UNSUPPORTED — on all ranks alike, which lets them retry in step.
  *
  * n1k_merge_partials_device: ≙ CumulateIntermediate (execution/group_intermediate.go:91-101) over `nregions`
  * regions of that layout (device memory), e.g. what the all-to-all delivered.  The handle must have the same
@@ -388,9 +392,25 @@ n1k_status n1k_merge_groups(n1k_handle *h, const void *blob, size_t len);
  * host has, and every rank calls n1k_comm_create — a collective, like ncclCommInitRank.
  *
  * The exchange calls are collectives too: every rank makes the same call.  They are enqueued on the sending handle's
- * stream with no host synchronisation; the receiving handle's n1k_finish is the step's one wait.  A sender whose
- * fixed-capacity region overflows says so inside the region headers, so every receiver's n1k_finish fails the same
- * way (N1K_OOM) and all ranks can retry in step with a larger capacity.
+ * stream with no host synchronisation; the receiving handle's n1k_finish is the step's one wait.  Several exchanges may
+ * be issued on one communicator per step (one per batch): each waits, on the device, for the owner's kernels that still
+ * read the previous one's regions.
+ *
+ * Failures.  A rank never leaves its peers waiting in a collective:
+ *   - whatever fails on a rank BEFORE the collective (a stopped operator, a batch that does not validate, buffers that
+ *     cannot be allocated, the partition or the export itself) does not keep it from entering: it ships regions that
+ *     hold only its n1k_status in their verdict word, returns that status from the exchange call, and every receiver's
+ *     n1k_finish then fails with the same status;
+ *   - what a sender's kernels find (a region that overflows: N1K_REGION_FULL; rows whose group key does not pack, values its
+ *     Filter cannot order: N1K_UNSUPPORTED_DATA) travels in the same verdict word;
+ *   in both cases the step is void on EVERY rank alike — n1k_failure_is_global(handle) says so after the failing call —
+ *   and no rank goes on to n1k_gather_groups: all of them retry (N1K_REGION_FULL: with a larger capacity) or give up in step;
+ *   - what fails on a rank AFTER the collective (the owner's InitialGroup / merge / n1k_finish over what it received) is
+ *     that rank's alone: it enters n1k_gather_groups_status with its status, and every rank learns it there.
+ * n1k_rows_step / n1k_partials_step run one whole step by these rules.  Not carried (the peers are left waiting; bound
+ * such a wait with the host's own watchdog): a rank without a usable device, a rank that cannot allocate even one
+ * region, and the first n1k_exchange_rows of a handle whose batch does not have the plan's column count / kinds (the
+ * region size is a function of the column kinds; N1K_INVALID).
  *
  * n1k_exchange_partials: per-GPU partial groups (≙ the Initial -> Intermediate hand-over, algebra/aggregate.go:25-40):
  *   the sender's groups are exported (n1k_export_partials_async), moved by ONE collective — all-gather when `gathered`
@@ -432,12 +452,21 @@ n1k_status n1k_gather_groups(n1k_comm *c, n1k_handle *h, const n1k_result *local
  * every rank gets the first failing rank's status in *worst_status (N1K_OK: `out` holds the gathered groups). */
 n1k_status n1k_gather_groups_status(n1k_comm *c, n1k_handle *h, const n1k_result *local, int local_status, n1k_result *out,
                                     int *worst_status);
+/* 1 when the last failure reported on this handle (by an exchange call on a sender, by n1k_finish on a receiver) was told
+ * to / learnt from the verdict words of an exchange: every rank's step failed alike and no rank enters the gather. */
+int n1k_failure_is_global(const n1k_handle *h);
 /* One whole step of the row exchange in one call: n1k_reset(receiver), n1k_reset(sender), n1k_exchange_rows,
- * n1k_finish(receiver), n1k_gather_groups_status(merger) — what a host runs per query.  N1K_OOM with "region" in the
- * receiver's n1k_last_error: a region overflowed, on every rank alike, and no gather took place (enlarge capacity_rows on
- * every rank and repeat); otherwise the receiver's own status, with *worst_status as n1k_gather_groups_status reports it. */
+ * n1k_finish(receiver), n1k_gather_groups_status(merger) — what a host runs per query.  A failure with
+ * n1k_failure_is_global(receiver) or n1k_failure_is_global(sender): the step is void on every rank alike and no gather took
+ * place (N1K_REGION_FULL: a region overflowed — enlarge capacity_rows on every rank and repeat); otherwise the rank's own status,
+ * with *worst_status as n1k_gather_groups_status reports it. */
 n1k_status n1k_rows_step(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver, n1k_handle *merger,
                          uint64_t capacity_rows, n1k_result *out, int *worst_status);
+/* The same for partial groups: n1k_reset(receiver), n1k_reset(sender), n1k_push_device_batch(sender, batch) (InitialGroup
+ * over the shard), n1k_exchange_partials, n1k_finish(receiver) and — unless `gathered`, where every rank merged every rank's
+ * groups and `receiver` (a handle that carries the plan's grouped tail) holds the result — the gather through `merger`. */
+n1k_status n1k_partials_step(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver, n1k_handle *merger,
+                             uint64_t capacity_groups, int gathered, n1k_result *out, int *worst_status);
 
 /* ------------------------------------------------------------- utilities -- */
 

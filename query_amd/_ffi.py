@@ -14,9 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("N1K_LIB") or os.path.join(_HERE, "libn1k.so")  # N1K_LIB: ablation builds only
 
 # n1k_status
-OK, UNSUPPORTED, EVAL_ERROR, DEVICE_ERROR, OOM, STOPPED, INVALID, UNSUPPORTED_DATA = range(8)
+OK, UNSUPPORTED, EVAL_ERROR, DEVICE_ERROR, OOM, STOPPED, INVALID, UNSUPPORTED_DATA, REGION_FULL = range(9)
 STATUS_NAMES = ["N1K_OK", "N1K_UNSUPPORTED", "N1K_EVAL_ERROR", "N1K_DEVICE_ERROR", "N1K_OOM", "N1K_STOPPED",
-                "N1K_INVALID", "N1K_UNSUPPORTED_DATA"]
+                "N1K_INVALID", "N1K_UNSUPPORTED_DATA", "N1K_REGION_FULL"]
 
 # n1k_tag
 T_MISSING, T_NULL, T_FALSE, T_TRUE, T_INT, T_FLOAT, T_STRING, T_ARRAY, T_OBJECT = range(9)
@@ -79,7 +79,7 @@ SYMBOLS = [
     "n1k_jit_check", "n1k_partial_words", "n1k_partial_region_bytes", "n1k_export_partials_device", "n1k_export_partials_async",
     "n1k_merge_partials_device",
     "n1k_comm_unique_id", "n1k_comm_create", "n1k_comm_destroy", "n1k_comm_last_error", "n1k_comm_rank", "n1k_comm_world",
-    "n1k_comm_max_u64", "n1k_exchange_partials", "n1k_exchange_rows", "n1k_gather_groups", "n1k_gather_groups_status", "n1k_rows_step",
+    "n1k_comm_max_u64", "n1k_exchange_partials", "n1k_exchange_rows", "n1k_gather_groups", "n1k_gather_groups_status", "n1k_rows_step", "n1k_partials_step", "n1k_failure_is_global",
     "n1k_abi_version", "n1k_device_count",
 ]
 
@@ -195,6 +195,11 @@ def lib():
         L.n1k_rows_step.argtypes = [H, H, C.POINTER(Batch), H, H, C.c_uint64, C.POINTER(Result), C.POINTER(C.c_int)]
         L.n1k_gather_groups_status.restype = C.c_int
         L.n1k_gather_groups_status.argtypes = [H, H, C.POINTER(Result), C.c_int, C.POINTER(Result), C.POINTER(C.c_int)]
+    if hasattr(L, "n1k_partials_step"):
+        L.n1k_partials_step.restype = C.c_int
+        L.n1k_partials_step.argtypes = [H, H, C.POINTER(Batch), H, H, C.c_uint64, C.c_int, C.POINTER(Result), C.POINTER(C.c_int)]
+        L.n1k_failure_is_global.restype = C.c_int
+        L.n1k_failure_is_global.argtypes = [H]
     L.n1k_gather_groups.restype = C.c_int
     L.n1k_gather_groups.argtypes = [H, H, C.POINTER(Result), C.POINTER(Result)]
     L.n1k_synth_columns.restype = C.c_int

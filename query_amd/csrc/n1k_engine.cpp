@@ -696,6 +696,7 @@ n1k_status n1k_reset(n1k_handle* h) {
     return guarded(h, [&]() -> n1k_status {
     if (!h) return N1K_INVALID;
     h->stop_flag.store(0);
+    h->failure_global = false;
     h->row_base = 0;
     h->merged_groups_bound = 0;
     h->selected.clear();
@@ -790,6 +791,7 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
     else if (n == "pinned_out") h->opt_pinned_out = value ? 1 : 0;
     else if (n == "lean_topk") h->opt_lean_topk = value ? 1 : 0;
+    else if (n == "inject_failure") h->opt_inject_failure = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
     else if (n == "part_block") h->opt_part_block = value == 256 ? 256 : 512;
     else if (n == "part_subs") h->opt_part_subs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);  // 0 off, 1 large batches, 2 always (tests)
     else if (n == "part_per_cu") h->opt_part_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8);

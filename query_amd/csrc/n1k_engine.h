@@ -134,6 +134,9 @@ struct n1k_handle {
     std::vector<std::vector<uint64_t>> js_payload;
     std::vector<n1k_col> js_cols;
     uint32_t opt_json_threads = 0;  // 0 = hardware concurrency (at most 16)
+    bool failure_global = false;  // the last failure reported on this handle was learnt from (or told through) the verdict words of an
+                                  // exchange: every rank's step fails alike, nobody enters the gather (n1k_failure_is_global)
+    uint32_t opt_inject_failure = 0;  // tests: the exchange pretends that its site 1 (buffers) / 2 (partition, export) / 3 (receiving part) failed, once
     bool out_count_dirty = true;  // the finalize position counter holds a previous finish's count
     char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
     unsigned long long* pin_counters = nullptr;  // pinned host copy of the device counters (one D2H per decision point)

@@ -119,7 +119,7 @@ n1k_status n1k_partition_device_batch(n1k_handle* h, const n1k_batch* batch, uin
     uint32_t err_flags = 0;
     HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (err_flags & ERR_TABLE_FULL) return fail(h, N1K_OOM, "partition region capacity (%llu rows) exceeded", (unsigned long long)capacity_rows);
+    if (err_flags & ERR_TABLE_FULL) return fail(h, N1K_REGION_FULL, "partition region capacity (%llu rows) exceeded", (unsigned long long)capacity_rows);
     if (err_flags & ERR_UNPACKABLE_KEY) return fail(h, N1K_UNSUPPORTED_DATA, "a group key value does not fit the packed key");
     if (err_flags & ERR_UNSUPPORTED_VALUE) return fail(h, N1K_UNSUPPORTED_DATA, "a value outside the device subset was met");
     h->stats.rows_in += batch->nrows;
@@ -174,7 +174,7 @@ n1k_status n1k_export_partials_device(n1k_handle* h, uint32_t nparts, uint64_t c
     }
     if (err_flags & ERR_TABLE_FULL) {
         HIP_TRY(h, hipMemsetAsync(h->d_errp, 0, 4, h->stream));
-        return fail(h, N1K_OOM, "more than %llu groups for one destination: raise the region capacity",
+        return fail(h, N1K_REGION_FULL, "more than %llu groups for one destination: raise the region capacity",
                     (unsigned long long)capacity_groups);
     }
     return N1K_OK;
@@ -276,6 +276,7 @@ struct LoopHub {
     int arrived = 0;
     uint64_t generation = 0;
     std::vector<const void*> ptr;
+    std::vector<size_t> stride;  // all-to-all: distance between the regions a rank published (0: one region for every peer)
     std::vector<unsigned long long> val;
     int refs = 0;
     void barrier() {
@@ -295,8 +296,12 @@ struct n1k_comm {
     LoopHub* hub = nullptr;  // non-null: loopback transport
     int rank = 0, world = 1, device = 0;
     DevBuf<char> send, recv, gsend, grecv;
+    DevBuf<char> void_send, void_recv;  // one region each: what a rank whose own part of a step failed ships / lets land (void_regions)
     DevBuf<unsigned long long> scalar;
     hipEvent_t ev = nullptr;
+    hipEvent_t ev_consumed = nullptr;   // on the receiving stream, behind the last kernel that reads send / recv
+    bool consumed_pending = false;
+    bool failure_broadcast = false;     // the last exchange failed on this rank before the collective and its peers were told
     std::string last_error;
     uint64_t gather_cap = 1024;    // records per slot of n1k_gather_groups (the same on every rank, see there)
     std::vector<char> ghost;       // gathered records on the host
@@ -360,25 +365,37 @@ n1k_status all_gather_bytes(n1k_comm* c, const char* send, char* recv, size_t by
     return N1K_OK;
 }
 
-n1k_status all_to_all_regions(n1k_comm* c, const char* send, char* recv, size_t region, hipStream_t st, const char** self) {
-    *self = send + (size_t)c->rank * region;
-    if (c->hub)
+// All-to-all of equal regions: the region at send + p * send_stride goes to rank p, rank s's region lands at
+// recv + s * recv_stride.  This rank's own region is not copied: the caller reads it where it lies (`self`).  A stride of 0
+// is how a rank whose own part failed takes part (void_regions): one region for every peer, one sink for what arrives.
+// Once the group is open it is always closed: no early return between ncclGroupStart and ncclGroupEnd.
+n1k_status all_to_all_regions(n1k_comm* c, const char* send, size_t send_stride, char* recv, size_t recv_stride, size_t region, hipStream_t st,
+                              const char** self) {
+    *self = send + (size_t)c->rank * send_stride;
+    if (c->hub) {
+        c->hub->stride[c->rank] = send_stride;  // (published with the pointer: read by the peers behind the first rendezvous)
         return loop_collective(c, send, st, [&]() -> hipError_t {
             for (int p = 0; p < c->world; p++) {
                 if (p == c->rank) continue;
-                hipError_t e = hipMemcpyAsync(recv + (size_t)p * region, (const char*)c->hub->ptr[p] + (size_t)c->rank * region, region,
+                hipError_t e = hipMemcpyAsync(recv + (size_t)p * recv_stride, (const char*)c->hub->ptr[p] + (size_t)c->rank * c->hub->stride[p], region,
                                               hipMemcpyDeviceToDevice, st);
                 if (e != hipSuccess) return e;
             }
             return hipSuccess;
         });
+    }
     NCCL_TRY(c, ncclGroupStart());
+    ncclResult_t first = ncclSuccess;
     for (int p = 0; p < c->world; p++) {
         if (p == c->rank) continue;
-        NCCL_TRY(c, ncclSend(send + (size_t)p * region, region, ncclChar, p, c->comm, st));
-        NCCL_TRY(c, ncclRecv(recv + (size_t)p * region, region, ncclChar, p, c->comm, st));
+        ncclResult_t r = ncclSend(send + (size_t)p * send_stride, region, ncclChar, p, c->comm, st);
+        if (first == ncclSuccess) first = r;
+        r = ncclRecv(recv + (size_t)p * recv_stride, region, ncclChar, p, c->comm, st);
+        if (first == ncclSuccess) first = r;
     }
-    NCCL_TRY(c, ncclGroupEnd());
+    const ncclResult_t end = ncclGroupEnd();
+    if (first == ncclSuccess) first = end;
+    if (first != ncclSuccess) return cfail(c, N1K_DEVICE_ERROR, "all-to-all of the regions failed: %s", ncclGetErrorString(first));
     return N1K_OK;
 }
 
@@ -474,7 +491,9 @@ n1k_status n1k_comm_create(const void* id, int rank, int world, int device, n1k_
         memcpy(&u, id, sizeof u);
         ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
         if (r != ncclSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "ncclCommInitRank failed: %s", ncclGetErrorString(r)));
-        if (hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "hipEventCreate failed"));
+        if (hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_consumed, hipEventDisableTiming) != hipSuccess)
+            return bail(cfail(nullptr, N1K_DEVICE_ERROR, "hipEventCreate failed"));
+        if (c->scalar.ensure(4) != hipSuccess) return bail(cfail(nullptr, N1K_OOM, "no device memory for the communicator"));  // (nothing of n1k_comm_max_u64 can fail before its collective)
         *out = c;
         return N1K_OK;
     });
@@ -487,6 +506,7 @@ n1k_status n1k_comm_create_loopback(int world, int device, n1k_comm** out) {
         auto* hub = new LoopHub();
         hub->world = world;
         hub->ptr.assign(world, nullptr);
+        hub->stride.assign(world, 0);
         hub->val.assign(world, 0);
         hub->refs = world;
         for (int r = 0; r < world; r++) {
@@ -496,6 +516,7 @@ n1k_status n1k_comm_create_loopback(int world, int device, n1k_comm** out) {
             c->device = device;
             c->hub = hub;
             (void)hipEventCreateWithFlags(&c->ev, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&c->ev_consumed, hipEventDisableTiming);
             out[r] = c;
         }
         return N1K_OK;
@@ -516,6 +537,9 @@ void n1k_comm_destroy(n1k_comm* c) {
         }
         if (c->comm) (void)ncclCommDestroy(c->comm);
         if (c->ev) (void)hipEventDestroy(c->ev);
+        if (c->ev_consumed) (void)hipEventDestroy(c->ev_consumed);
+        c->void_send.release();
+        c->void_recv.release();
         c->send.release();
         c->recv.release();
         c->gsend.release();
@@ -544,7 +568,6 @@ n1k_status n1k_comm_max_u64(n1k_comm* c, n1k_handle* h, uint64_t value, uint64_t
             *out = mx;
             return N1K_OK;
         }
-        HIP_TRY(h, c->scalar.ensure(4));
         unsigned long long v = value, m = 0;
         HIP_TRY(h, hipMemcpyAsync(c->scalar.p, &v, 8, hipMemcpyHostToDevice, h->stream));
         NCCL_TRY(c, ncclAllReduce(c->scalar.p, c->scalar.p + 1, 1, ncclUint64, ncclMax, c->comm, h->stream));
@@ -555,64 +578,168 @@ n1k_status n1k_comm_max_u64(n1k_comm* c, n1k_handle* h, uint64_t value, uint64_t
     });
 }
 
-n1k_status n1k_exchange_partials(n1k_comm* c, n1k_handle* sender, n1k_handle* receiver, uint64_t capacity_groups, int gathered) {
-    return guarded(sender, [&]() -> n1k_status {
-        if (!c || !sender || !receiver || capacity_groups == 0) return N1K_INVALID;
-        n1k_status st = prepare_receiver(sender, receiver);
-        if (st != N1K_OK) return st == N1K_INVALID && sender->last_error.empty() ? fail(sender, st, "%s", receiver->last_error.c_str()) : st;
-        const size_t region = (size_t)n1k_partial_region_bytes(sender, capacity_groups);
-        const uint32_t nsend = gathered ? 1u : (uint32_t)c->world;
-        HIP_TRY(sender, c->send.ensure(region * nsend));
-        HIP_TRY(sender, c->recv.ensure(region * (size_t)c->world));
-        st = n1k_export_partials_async(sender, nsend, capacity_groups, c->send.p);
-        if (st != N1K_OK) return st;
-        if (gathered) {
-            // every rank ends with every rank's partial groups: no second collective for the result
-            st = all_gather_bytes(c, c->send.p, c->recv.p, region, sender->stream);
-            if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
-        } else {
-            const char* self = nullptr;
-            st = all_to_all_regions(c, c->send.p, c->recv.p, region, sender->stream, &self);
-            if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
-            // (this rank's own region joins the received ones by a device copy of G groups, not through the fabric)
-            HIP_TRY(sender, hipMemcpyAsync(c->recv.p + (size_t)c->rank * region, self, region, hipMemcpyDeviceToDevice, sender->stream));
-        }
-        st = order_streams(c, sender, receiver);
-        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
-        st = n1k_merge_partials_device(receiver, (uint32_t)c->world, capacity_groups, c->recv.p);
-        if (st != N1K_OK) return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
-        return N1K_OK;
-    });
+// ---- one exchange step, failure-safe -------------------------------------------------------------------------------------
+//
+// A collective has to be entered by every rank, whatever happened on that rank before it: a rank that returned early would
+// leave its peers waiting in ncclRecv for good.  So the exchange calls are built in three parts:
+//   1. the local part (validation, buffers, Filter + partition / export): anything may fail here;
+//   2. the collective, ALWAYS entered — a rank whose local part failed ships regions that hold nothing but its status in
+//      the verdict word (n1k_types.h VD_*), from its usual buffers or, when it has none, from one scratch region that every
+//      peer gets; its own return value is its local status, and c->failure_broadcast says that the peers know;
+//   3. the receiving part (verdict check, InitialGroup / merge on the owner): a failure here is this rank's alone and
+//      travels in the gather (n1k_gather_groups_status).
+// What cannot be carried: a rank with no device, a rank that cannot even allocate one region, and — for the row exchange
+// only — a first batch whose column kinds are not the plan's (the region size is a function of them): see n1k.h.
+
+namespace {
+
+// behind the last reader of c->send / c->recv (the owner's scans of the previous exchange on this communicator): the next
+// exchange overwrites both buffers on the sending stream
+n1k_status wait_consumed(n1k_comm* c, n1k_handle* snd) {
+    if (!c->consumed_pending) return N1K_OK;
+    CHIP_TRY(c, hipStreamWaitEvent(snd->stream, c->ev_consumed, 0));
+    return N1K_OK;
+}
+n1k_status mark_consumed(n1k_comm* c, n1k_handle* rcv) {
+    CHIP_TRY(c, hipEventRecord(c->ev_consumed, rcv->stream));
+    c->consumed_pending = true;
+    return N1K_OK;
 }
 
-n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, uint64_t capacity_rows) {
-    return guarded(sender, [&]() -> n1k_status {
-        if (!c || !sender || !receiver || !batch || capacity_rows == 0) return N1K_INVALID;
-        if (!sender->plan.has_group) return fail(sender, N1K_INVALID, "the row exchange partitions on group keys");
+// the regions of a rank whose local part failed: headers that hold nothing but the status.  Its usual buffers when they are
+// large enough (stride = region), else ONE scratch region that goes to every peer and one that every peer's region lands in.
+n1k_status void_regions(n1k_comm* c, n1k_handle* snd, size_t region, size_t header_bytes, uint32_t nsend, uint32_t nrecv, n1k_status status,
+                        const char** send, size_t* send_stride, char** recv, size_t* recv_stride, bool recv_contiguous) {
+    if (c->send.n >= region * nsend && c->recv.n >= region * nrecv) {
+        *send = c->send.p;
+        *send_stride = region;
+        *recv = c->recv.p;
+        *recv_stride = region;
+    } else {
+        CHIP_TRY(c, c->void_send.ensure(region));
+        CHIP_TRY(c, c->void_recv.ensure(recv_contiguous ? region * nrecv : region));
+        *send = c->void_send.p;
+        *send_stride = 0;
+        *recv = c->void_recv.p;
+        *recv_stride = recv_contiguous ? region : 0;
+        nsend = 1;
+    }
+    for (uint32_t d = 0; d < nsend; d++) CHIP_TRY(c, hipMemsetAsync((char*)*send + (size_t)d * *send_stride, 0, header_bytes, snd->stream));
+    CHIP_TRY(c, launch_stamp_verdict((unsigned long long*)*send, nsend, *send_stride / 8, nullptr, (uint32_t)status, snd->stream));
+    return N1K_OK;
+}
+
+// test hook (option inject_failure, one shot): pretend that `site` failed on this handle
+bool injected(n1k_handle* h, uint32_t site) {
+    if (h->opt_inject_failure != site) return false;
+    h->opt_inject_failure = 0;
+    return true;
+}
+
+// n1k_exchange_partials; `failed`: what the caller's own preparation of this step returned (n1k_partials_step)
+n1k_status exchange_partials_impl(n1k_comm* c, n1k_handle* sender, n1k_handle* receiver, uint64_t capacity_groups, int gathered, n1k_status failed) {
+    c->failure_broadcast = false;
+    sender->failure_global = false;
+    n1k_status st = ensure_device(sender);
+    if (st != N1K_OK) return st;  // (no device: this rank cannot take part in anything)
+    st = wait_consumed(c, sender);
+    if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+    const size_t region = (size_t)n1k_partial_region_bytes(sender, capacity_groups);  // (a function of the plan alone)
+    const uint32_t P = (uint32_t)c->world, nsend = gathered ? 1u : P;
+    // 1. local part
+    n1k_status local = failed;
+    if (local == N1K_OK && sender->stop_flag.load()) local = fail(sender, N1K_STOPPED, "operator was stopped");
+    if (local == N1K_OK) {
+        local = prepare_receiver(sender, receiver);
+        if (local == N1K_INVALID && sender->last_error.empty()) fail(sender, local, "%s", receiver->last_error.c_str());
+    }
+    if (local == N1K_OK && injected(sender, 1)) local = fail(sender, N1K_OOM, "injected failure: buffers of the exchange");
+    if (local == N1K_OK) {
+        hipError_t e = c->send.ensure(region * nsend);
+        if (e == hipSuccess) e = c->recv.ensure(region * (size_t)P);
+        if (e != hipSuccess) local = fail(sender, e == hipErrorOutOfMemory ? N1K_OOM : N1K_DEVICE_ERROR, "buffers of the exchange: %s", hipGetErrorString(e));
+    }
+    if (local == N1K_OK) local = n1k_export_partials_async(sender, nsend, capacity_groups, c->send.p);
+    if (local == N1K_OK && injected(sender, 2)) local = fail(sender, N1K_DEVICE_ERROR, "injected failure: export of the partial groups");
+    // 2. the collective, always
+    const char* send = c->send.p;
+    char* recv = c->recv.p;
+    size_t sstride = region, rstride = region;
+    if (local != N1K_OK) {
+        st = void_regions(c, sender, region, 16, nsend, P, local, &send, &sstride, &recv, &rstride, gathered != 0);
+        if (st != N1K_OK) return local;  // (not even one region: the peers are not told — see the comment above)
+    }
+    const char* self = nullptr;
+    if (gathered) st = all_gather_bytes(c, send, recv, region, sender->stream);
+    else st = all_to_all_regions(c, send, sstride, recv, rstride, region, sender->stream, &self);
+    if (local != N1K_OK) {
+        c->failure_broadcast = st == N1K_OK;
+        sender->failure_global = st == N1K_OK;
+        return local;
+    }
+    if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+    // 3. the receiving part
+    if (!gathered)  // (this rank's own region joins the received ones by a device copy of G groups, not through the fabric)
+        HIP_TRY(sender, hipMemcpyAsync(c->recv.p + (size_t)c->rank * region, self, region, hipMemcpyDeviceToDevice, sender->stream));
+    st = order_streams(c, sender, receiver);
+    if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+    if (injected(sender, 3)) return fail(sender, N1K_DEVICE_ERROR, "injected failure: the receiving part");
+    st = n1k_merge_partials_device(receiver, P, capacity_groups, c->recv.p);
+    (void)mark_consumed(c, receiver);
+    if (st != N1K_OK) return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
+    return N1K_OK;
+}
+
+// the column kinds of a batch are the plan's (and the ones seen before): what the size of a row region hangs on
+bool batch_kinds_ok(const n1k_handle* h, const n1k_batch* b) {
+    if (!b || b->ncols != (uint32_t)h->plan.paths.size() || (b->ncols && !b->cols)) return false;
+    for (uint32_t i = 0; i < b->ncols; i++) {
+        if (b->cols[i].kind != N1K_COL_DICT32 && b->cols[i].kind != N1K_COL_TAGGED64) return false;
+        if (h->layout_fixed && b->cols[i].kind != h->col_kinds[i]) return false;
+    }
+    return true;
+}
+
+n1k_status exchange_rows_impl(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, uint64_t capacity_rows, n1k_status failed) {
+    c->failure_broadcast = false;
+    sender->failure_global = false;
+    if (!sender->plan.has_group) return fail(sender, N1K_INVALID, "the row exchange partitions on group keys");
+    n1k_status st = ensure_device(sender);
+    if (st != N1K_OK) return st;  // (no device: this rank cannot take part in anything)
+    // 0. the size of a region: from the column kinds (of this batch, or as fixed by an earlier one)
+    n1k_status local = failed;
+    if (!batch_kinds_ok(sender, batch)) {
+        if (!sender->layout_fixed)
+            return fail(sender, N1K_INVALID, "the first batch of a row exchange does not have the plan's columns: the region size is unknown "
+                                             "and this rank cannot enter the collective");
+        if (local == N1K_OK) local = fail(sender, N1K_INVALID, "the batch does not have the columns of the earlier ones");
+    } else if (!sender->layout_fixed) {
+        st = fix_layout(sender, batch);  // (sets the column kinds first, then the key layout)
+        if (st != N1K_OK && local == N1K_OK) local = st;
+    }
+    const uint64_t cap = (capacity_rows + 16 * kRowSubs - 1) / (16 * kRowSubs) * (16 * kRowSubs);  // kRowSubs sub-regions of whole 16-row groups
+    if (cap >= (1ull << 31)) return fail(sender, N1K_INVALID, "row regions hold fewer than 2^31 rows");  // (the same on every rank)
+    std::vector<size_t> off_a, off_b;
+    const size_t region = row_region_layout(sender, cap, off_a, off_b);
+    const uint32_t P = (uint32_t)c->world;
+    const size_t header = (size_t)kRowSubs * kCursorStride * 8;
+    st = wait_consumed(c, sender);
+    if (st != N1K_OK && local == N1K_OK) local = fail(sender, st, "%s", c->last_error.c_str());
+    // 1. local part: Filter + hash partition on the group key values into the packed regions (headers zeroed first)
+    auto local_part = [&]() -> n1k_status {
         if (sender->stop_flag.load()) return fail(sender, N1K_STOPPED, "operator was stopped");
-        n1k_status st = ensure_device(sender);
-        if (st != N1K_OK) return st;
-        st = validate_batch(sender, batch);
-        if (st != N1K_OK) return st;
-        if (!sender->layout_fixed) {
-            st = fix_layout(sender, batch);
-            if (st != N1K_OK) return st;
-        }
-        st = prepare_receiver(sender, receiver);
-        if (st != N1K_OK) return st;
-        const uint64_t cap = (capacity_rows + 16 * kRowSubs - 1) / (16 * kRowSubs) * (16 * kRowSubs);  // kRowSubs sub-regions of whole 16-row groups
-        if (cap >= (1ull << 31)) return fail(sender, N1K_INVALID, "row regions hold fewer than 2^31 rows");
-        std::vector<size_t> off_a, off_b;
-        const size_t region = row_region_layout(sender, cap, off_a, off_b);
-        const uint32_t P = (uint32_t)c->world;
+        n1k_status s = validate_batch(sender, batch);
+        if (s != N1K_OK) return s;
+        s = prepare_receiver(sender, receiver);
+        if (s != N1K_OK) return s;
+        if (injected(sender, 1)) return fail(sender, N1K_OOM, "injected failure: buffers of the exchange");
         HIP_TRY(sender, c->send.ensure(region * P));
         HIP_TRY(sender, c->recv.ensure(region * P));
-        // 1. Filter + hash partition on the group key values into the packed regions (headers zeroed first)
-        for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * region, 0, (size_t)kRowSubs * kCursorStride * 8, sender->stream));
-        st = bind_columns(sender, batch, true);
-        if (st != N1K_OK) return st;
-        st = ensure_rank(sender);
-        if (st != N1K_OK) return st;
+        for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * region, 0, header, sender->stream));
+        s = bind_columns(sender, batch, true);
+        if (s != N1K_OK) return s;
+        s = ensure_rank(sender);
+        if (s != N1K_OK) return s;
         PartArgs A{};
         A.nrows = batch->nrows;
         A.capacity = cap;
@@ -630,69 +757,136 @@ n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* b
                 A.out_tags[i] = (uint8_t*)(c->send.p + off_b[i]);
             }
         }
-        st = run_partition(sender, batch, A);
-        if (st != N1K_OK) return st;
+        s = run_partition(sender, batch, A);
+        if (s != N1K_OK) return s;
+        if (injected(sender, 2)) return fail(sender, N1K_DEVICE_ERROR, "injected failure: the partition");
         sender->stats.rows_in += batch->nrows;
         sender->stats.batches += 1;
-        // 2. ONE all-to-all: counts, verdicts and rows of every column travel in the same region
-        const char* self = nullptr;
-        st = all_to_all_regions(c, c->send.p, c->recv.p, region, sender->stream, &self);
-        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
-        st = order_streams(c, sender, receiver);
-        if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
-        // 3. the owner's InitialGroup over what it received: one batch per source, each with its row count on the device.
-        //    (Headers are checked first: a sender that overflowed voids the step on every rank.)
-        std::vector<const char*> src(P);
-        for (uint32_t sidx = 0; sidx < P; sidx++) src[sidx] = (int)sidx == c->rank ? self : c->recv.p + (size_t)sidx * region;
-        {
-            HeaderList H{};
-            for (uint32_t sidx = 0; sidx < P; sidx++) H.h[sidx] = (unsigned long long*)src[sidx];
-            HIP_TRY(receiver, launch_exchange_verdict(H, P, receiver->d_errp, receiver->stream));
-        }
-        for (uint32_t sidx = 0; sidx < P; sidx++) {
-            const uint32_t rnc = (uint32_t)receiver->plan.paths.size();
-            std::vector<n1k_col> cols(std::max<size_t>(1, rnc));
-            for (uint32_t i = 0; i < rnc; i++) {
-                const int j = sender_column(sender, receiver->plan.paths[i]);  // (prepare_receiver checked that it exists)
-                cols[i].kind = sender->col_kinds[j];
-                if (cols[i].kind == N1K_COL_DICT32) cols[i].codes = (const uint32_t*)(src[sidx] + off_a[j]);
-                else {
-                    cols[i].payload = (const uint64_t*)(src[sidx] + off_a[j]);
-                    cols[i].tags = (const uint8_t*)(src[sidx] + off_b[j]);
-                }
-            }
-            n1k_batch rb{};
-            rb.nrows = cap;
-            rb.ncols = rnc;
-            rb.cols = cols.data();
-            receiver->push_seg_counts = (const unsigned long long*)src[sidx];  // (the region's header)
-            receiver->push_nseg = kRowSubs;
-            receiver->push_seg_rows = cap / kRowSubs;
-            st = push_device(receiver, &rb);
-            receiver->push_seg_counts = nullptr;
-            receiver->push_nseg = 0;
-            if (st != N1K_OK) return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
-        }
+        // what the partition itself found (rows whose key does not pack, values the Filter cannot order) joins the verdicts
+        HIP_TRY(sender, launch_stamp_verdict((unsigned long long*)c->send.p, P, region / 8, sender->d_errp, 0, sender->stream));
         return N1K_OK;
+    };
+    if (local == N1K_OK) local = local_part();
+    // 2. ONE all-to-all, always: counts, verdicts and rows of every column travel in the same region
+    const char* send = c->send.p;
+    char* recv = c->recv.p;
+    size_t sstride = region, rstride = region;
+    if (local != N1K_OK) {
+        st = void_regions(c, sender, region, header, P, P, local, &send, &sstride, &recv, &rstride, false);
+        if (st != N1K_OK) return local;  // (not even one region: the peers are not told — see the comment above)
+    }
+    const char* self = nullptr;
+    st = all_to_all_regions(c, send, sstride, recv, rstride, region, sender->stream, &self);
+    if (local != N1K_OK) {
+        c->failure_broadcast = st == N1K_OK;
+        sender->failure_global = st == N1K_OK;
+        return local;
+    }
+    if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+    st = order_streams(c, sender, receiver);
+    if (st != N1K_OK) return fail(sender, st, "%s", c->last_error.c_str());
+    // 3. the owner's InitialGroup over what it received: one batch per source, each with its row count on the device.
+    //    (Headers are checked first: a sender that overflowed, dropped rows or failed voids the step on every rank.)
+    std::vector<const char*> src(P);
+    for (uint32_t sidx = 0; sidx < P; sidx++) src[sidx] = (int)sidx == c->rank ? self : c->recv.p + (size_t)sidx * region;
+    {
+        HeaderList H{};
+        for (uint32_t sidx = 0; sidx < P; sidx++) H.h[sidx] = (unsigned long long*)src[sidx];
+        HIP_TRY(receiver, launch_exchange_verdict(H, P, receiver->d_errp, receiver->stream));
+    }
+    if (injected(sender, 3)) return fail(sender, N1K_DEVICE_ERROR, "injected failure: the receiving part");
+    for (uint32_t sidx = 0; sidx < P; sidx++) {
+        const uint32_t rnc = (uint32_t)receiver->plan.paths.size();
+        std::vector<n1k_col> cols(std::max<size_t>(1, rnc));
+        for (uint32_t i = 0; i < rnc; i++) {
+            const int j = sender_column(sender, receiver->plan.paths[i]);  // (prepare_receiver checked that it exists)
+            cols[i].kind = sender->col_kinds[j];
+            if (cols[i].kind == N1K_COL_DICT32) cols[i].codes = (const uint32_t*)(src[sidx] + off_a[j]);
+            else {
+                cols[i].payload = (const uint64_t*)(src[sidx] + off_a[j]);
+                cols[i].tags = (const uint8_t*)(src[sidx] + off_b[j]);
+            }
+        }
+        n1k_batch rb{};
+        rb.nrows = cap;
+        rb.ncols = rnc;
+        rb.cols = cols.data();
+        receiver->push_seg_counts = (const unsigned long long*)src[sidx];  // (the region's header)
+        receiver->push_nseg = kRowSubs;
+        receiver->push_seg_rows = cap / kRowSubs;
+        st = push_device(receiver, &rb);
+        receiver->push_seg_counts = nullptr;
+        receiver->push_nseg = 0;
+        if (st != N1K_OK) {
+            (void)mark_consumed(c, receiver);
+            return fail(sender, st, "receiver: %s", receiver->last_error.c_str());
+        }
+    }
+    (void)mark_consumed(c, receiver);
+    return N1K_OK;
+}
+
+}  // namespace
+
+n1k_status n1k_exchange_partials(n1k_comm* c, n1k_handle* sender, n1k_handle* receiver, uint64_t capacity_groups, int gathered) {
+    return guarded(sender, [&]() -> n1k_status {
+        if (!c || !sender || !receiver || capacity_groups == 0) return N1K_INVALID;
+        return exchange_partials_impl(c, sender, receiver, capacity_groups, gathered, N1K_OK);
     });
+}
+
+n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, uint64_t capacity_rows) {
+    return guarded(sender, [&]() -> n1k_status {
+        if (!c || !sender || !receiver || capacity_rows == 0) return N1K_INVALID;
+        return exchange_rows_impl(c, sender, batch, receiver, capacity_rows, N1K_OK);
+    });
+}
+
+
+int n1k_failure_is_global(const n1k_handle* h) { return h && h->failure_global ? 1 : 0; }
+
+// what follows the exchange in one step: the owner's n1k_finish, then — unless the step failed on every rank alike — the
+// gather, entered with this rank's own status
+static n1k_status finish_and_gather(n1k_comm* c, n1k_status st, n1k_handle* receiver, n1k_handle* merger, bool gather, n1k_result* out,
+                                    int* worst_status) {
+    if (st != N1K_OK && c->failure_broadcast) return st;  // this rank's own failure, told to every peer in the headers: no gather anywhere
+    n1k_result local;
+    const n1k_status fs = n1k_finish(receiver, &local);  // (also after a failure of the receiving part: the verdicts decide)
+    if (fs != N1K_OK && receiver->failure_global) return fs;  // learnt from the headers, by every rank alike: no gather anywhere
+    if (st == N1K_OK) st = fs;
+    if (!gather) {
+        if (st == N1K_OK) *out = local;
+        return st;
+    }
+    const n1k_status gs = n1k_gather_groups_status(c, merger, st == N1K_OK ? &local : nullptr, (int)st, out, worst_status);
+    return gs != N1K_OK ? gs : st;
 }
 
 n1k_status n1k_rows_step(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, n1k_handle* merger,
                          uint64_t capacity_rows, n1k_result* out, int* worst_status) {
-    if (!c || !sender || !batch || !receiver || !merger || !out || !worst_status) return N1K_INVALID;
+    if (!c || !sender || !batch || !receiver || !merger || !out || !worst_status || capacity_rows == 0) return N1K_INVALID;
     *worst_status = N1K_OK;
     n1k_status st = n1k_reset(receiver);
     if (st == N1K_OK) st = n1k_reset(sender);  // (the sender holds no groups in this mode; its counters and timers start over)
-    if (st == N1K_OK) st = n1k_exchange_rows(c, sender, batch, receiver, capacity_rows);
-    if (st != N1K_OK) return st;
-    n1k_result local;
-    st = n1k_finish(receiver, &local);
-    // a region that overflowed fails the step on EVERY rank alike (the verdict travelled in the headers): no gather, the
-    // caller enlarges the regions and repeats; any other failure is this owner's alone and travels in the gather
-    if (st == N1K_OOM && receiver->last_error.find("region") != std::string::npos) return st;
-    n1k_status gs = n1k_gather_groups_status(c, merger, st == N1K_OK ? &local : nullptr, (int)st, out, worst_status);
-    return gs != N1K_OK ? gs : st;
+    // (a reset that failed is this rank's own failure: it still enters the exchange, with that status)
+    const n1k_status prep = st;
+    st = guarded(sender, [&]() -> n1k_status { return exchange_rows_impl(c, sender, batch, receiver, capacity_rows, prep); });
+    return finish_and_gather(c, st, receiver, merger, true, out, worst_status);
 }
+
+n1k_status n1k_partials_step(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, n1k_handle* merger,
+                             uint64_t capacity_groups, int gathered, n1k_result* out, int* worst_status) {
+    if (!c || !sender || !batch || !receiver || !merger || !out || !worst_status || capacity_groups == 0) return N1K_INVALID;
+    *worst_status = N1K_OK;
+    n1k_status st = n1k_reset(receiver);
+    if (st == N1K_OK) st = n1k_reset(sender);
+    if (st == N1K_OK) st = n1k_push_device_batch(sender, batch);  // InitialGroup over the shard: the single-GPU kernels
+    const n1k_status prep = st;
+    st = guarded(sender, [&]() -> n1k_status { return exchange_partials_impl(c, sender, receiver, capacity_groups, gathered, prep); });
+    // gathered: every rank merged every rank's groups and `receiver` (the handle that carries the plan's tail) holds the result
+    return finish_and_gather(c, st, receiver, merger, !gathered, out, worst_status);
+}
+
 
 n1k_status n1k_gather_groups(n1k_comm* c, n1k_handle* h, const n1k_result* local, n1k_result* out) {
     int worst = 0;

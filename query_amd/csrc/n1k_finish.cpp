@@ -11,6 +11,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     return guarded(h, [&]() -> n1k_status {
     if (!h || !out) return N1K_INVALID;
     memset(out, 0, sizeof *out);
+    h->failure_global = false;
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
     const ParsedPlan& pl = h->plan;
     uint32_t nk = (uint32_t)pl.keys.size(), na = (uint32_t)pl.aggs.size();
@@ -231,13 +232,26 @@ redo_sets:
         n1k_status ast = array_agg_groups(h, ng, counters);
         if (ast != N1K_OK) return ast;
     }
+    // What the verdict words of a multi-GPU exchange said comes first: every rank read the same verdicts, so every rank
+    // returns from here with the same status (n1k_failure_is_global) and none of them goes on to the gather.
+    if (err_flags & kErrFromVerdict) {
+        h->failure_global = true;
+        if (err_flags & ERR_PEER_FAILED) {
+            const int ps = (int)(counters[27] & 0xFF);
+            return fail(h, ps > 0 && ps <= N1K_REGION_FULL ? (n1k_status)ps : N1K_DEVICE_ERROR,
+                        "a rank failed before the exchange (its status: %d); the step is void on every rank", ps);
+        }
+        if (err_flags & ERR_EXCHANGE_WIDE)
+            return fail(h, N1K_UNSUPPORTED, "a sender's group keys hold float / wide integer values: use the row exchange");
+        if (err_flags & ERR_EXCHANGE_OVERFLOW)
+            return fail(h, N1K_REGION_FULL, "a sender's region overflowed: raise the region capacity (on every rank)");
+        if (err_flags & ERR_PEER_UNPACKABLE)
+            return fail(h, N1K_UNSUPPORTED_DATA, "a sender met a group key value that does not fit the packed key (option wide_values, or a key layout too narrow)");
+        return fail(h, N1K_UNSUPPORTED_DATA, "a sender met a value outside the device subset (ordering of arrays/objects)");
+    }
     if (err_flags & ERR_TABLE_FULL)
         return fail(h, N1K_OOM, "group table capacity exceeded: raise the max_groups option (now %llu)",
                     (unsigned long long)h->opt_max_groups);
-    if (err_flags & ERR_EXCHANGE_WIDE)
-        return fail(h, N1K_UNSUPPORTED, "a sender's group keys hold float / wide integer values: use the row exchange");
-    if (err_flags & ERR_EXCHANGE_OVERFLOW)
-        return fail(h, N1K_OOM, "a sender's partial-group region overflowed: raise the region capacity");
     if (err_flags & ERR_UNPACKABLE_KEY)
         return fail(h, N1K_UNSUPPORTED_DATA,
                     "a group key value does not fit the packed key: more than %llu distinct float / wide integer key "

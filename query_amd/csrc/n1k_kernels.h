@@ -94,6 +94,8 @@ hipError_t launch_publish_counters(const unsigned long long* src, unsigned long 
 hipError_t launch_partition(const Program& P, const PartArgs& A, uint32_t grid, hipStream_t st);
 struct HeaderList { unsigned long long* h[kMaxParts]; };  // the headers of the row regions a rank received (one per source)
 hipError_t launch_exchange_verdict(const HeaderList& H, uint32_t nregions, uint32_t* err_flags, hipStream_t st);
+hipError_t launch_stamp_verdict(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, const uint32_t* err_flags,
+                                uint32_t host_status, hipStream_t st);
 hipError_t launch_dense_to_segments(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows, hipStream_t st);
 struct SpecEntry {
     const char* name;

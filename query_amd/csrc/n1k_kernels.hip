@@ -1575,6 +1575,18 @@ N1K_DEV void merge_partial_record(const Program& P, const GlobalTable& G, uint64
     }
 }
 
+// what a receiver makes of the verdict words it was sent (n1k_types.h VD_*): error flags that void the step on every rank
+// alike, and the largest host status any sender reported
+N1K_DEV void raise_verdict(uint64_t verdict, uint32_t* err_flags) {
+    uint32_t f = 0;
+    if (verdict & VD_OVERFLOW) f |= ERR_EXCHANGE_OVERFLOW;
+    if (verdict & VD_WIDE) f |= ERR_EXCHANGE_WIDE;
+    if (verdict & VD_UNPACKABLE) f |= ERR_PEER_UNPACKABLE;
+    if (verdict & VD_UNSUPPORTED) f |= ERR_PEER_UNSUPPORTED;
+    if (verdict >> VD_STATUS_SHIFT) f |= ERR_PEER_FAILED;
+    atomicOr(err_flags, f);
+}
+
 // merge received partial groups into this GPU's table (one thread per record)
 __global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint32_t nregions, uint64_t cap,
                                       const uint64_t* in, uint64_t region_words, uint32_t* err_flags,
@@ -1585,10 +1597,17 @@ __global__ void merge_partials_kernel(const Program P, const GlobalTable G, uint
     if (r >= nregions) return;
     // a sender that could not export (see export_partials_kernel) voids the whole exchange: nothing is merged and
     // n1k_finish reports it, on every rank alike
-    uint64_t verdict = 0;
-    for (uint32_t q = 0; q < nregions; q++) verdict |= in[(size_t)q * region_words + 1];
+    uint64_t verdict = 0, status = 0;
+    for (uint32_t q = 0; q < nregions; q++) {
+        const uint64_t v = in[(size_t)q * region_words + 1];
+        verdict |= v;
+        status = (v >> VD_STATUS_SHIFT) > status ? (v >> VD_STATUS_SHIFT) : status;
+    }
     if (verdict) {
-        if (i == 0) atomicOr(err_flags, (uint32_t)(((verdict & 1ull) ? ERR_EXCHANGE_OVERFLOW : 0u) | ((verdict & 2ull) ? ERR_EXCHANGE_WIDE : 0u)));
+        if (i == 0) {
+            raise_verdict(verdict, err_flags);
+            if (status) atomicMax((unsigned long long*)err_flags + kPeerStatusFromErr, (unsigned long long)(status & 0xFF));
+        }
         return;
     }
     const uint64_t* region = in + (size_t)r * region_words;
@@ -2683,15 +2702,40 @@ hipError_t launch_arith(const ArithArgs& A, hipStream_t st) {
 // whose region overflowed said so in every header — the receiver then aggregates nothing (all counts to zero) and its
 // n1k_finish reports it, on every rank alike.
 __global__ void exchange_verdict_kernel(const HeaderList H, uint32_t nregions, uint32_t* err_flags) {
-    unsigned long long v = 0;
-    for (uint32_t r = 0; r < nregions; r++) v |= H.h[r][1];
+    unsigned long long v = 0, status = 0;
+    for (uint32_t r = 0; r < nregions; r++) {
+        const unsigned long long x = H.h[r][1];
+        v |= x;
+        status = (x >> VD_STATUS_SHIFT) > status ? (x >> VD_STATUS_SHIFT) : status;
+    }
     if (!v) return;
-    atomicOr(err_flags, (uint32_t)ERR_EXCHANGE_OVERFLOW);
+    if (threadIdx.x == 0) {
+        raise_verdict(v, err_flags);
+        if (status) atomicMax((unsigned long long*)err_flags + kPeerStatusFromErr, status & 0xFFull);
+    }
     for (uint32_t i = threadIdx.x; i < nregions * kRowSubs; i += blockDim.x) H.h[i / kRowSubs][(size_t)(i % kRowSubs) * kCursorStride] = 0;
 }
 
 hipError_t launch_exchange_verdict(const HeaderList& H, uint32_t nregions, uint32_t* err_flags, hipStream_t st) {
     hipLaunchKernelGGL(exchange_verdict_kernel, dim3(1), dim3(64), 0, st, H, nregions, err_flags);
+    return hipGetLastError();
+}
+
+// The sending side: behind the partition (or the export) of a step, this sender's own error flags — rows it dropped because
+// their key does not pack, values its Filter cannot order — and, if its host part failed, that status join the verdict word of
+// EVERY region it ships (n1k_types.h VD_*): the step then fails on every rank alike instead of returning short groups.
+__global__ void stamp_verdict_kernel(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, const uint32_t* err_flags,
+                                     uint32_t host_status) {
+    const uint32_t f = err_flags ? *err_flags : 0u;
+    const unsigned long long v = ((f & ERR_UNPACKABLE_KEY) ? VD_UNPACKABLE : 0ull) | ((f & ERR_UNSUPPORTED_VALUE) ? VD_UNSUPPORTED : 0ull) |
+                                 ((unsigned long long)(host_status & 0xFFu) << VD_STATUS_SHIFT);
+    if (!v) return;
+    for (uint32_t r = threadIdx.x; r < nregions; r += blockDim.x) atomicOr(&headers[(size_t)r * stride_words + 1], v);
+}
+
+hipError_t launch_stamp_verdict(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, const uint32_t* err_flags,
+                                uint32_t host_status, hipStream_t st) {
+    hipLaunchKernelGGL(stamp_verdict_kernel, dim3(1), dim3(64), 0, st, headers, nregions, stride_words, err_flags, host_status);
     return hipGetLastError();
 }
 

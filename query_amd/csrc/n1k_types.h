@@ -35,7 +35,7 @@ constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 // [5] DISTINCT region words [8..11] pair-log cursors [12] error flags [13] wide key values [16..19] word-log cursors
 // [25] survivor count saved by the optimistic partitioned path [26] its region's group count (copied for the host)
 // [20] COUNT(DISTINCT) optimistic path: set / bin overflow flags [21] records of the partitioned path [22] its singleton
-// partial groups [24] COUNT(DISTINCT) exact path: LDS-set overflow flag
+// partial groups [24] COUNT(DISTINCT) exact path: LDS-set overflow flag [27] the n1k_status a peer's verdict carried (ERR_PEER_FAILED)
 constexpr uint32_t kCounters = 32;
 
 // value tags == n1k_tag (include/n1k.h)
@@ -147,8 +147,29 @@ enum : uint32_t {
     ERR_TABLE_FULL = 2,       // global group table capacity exceeded
     ERR_UNSUPPORTED_VALUE = 4, // e.g. ordering two arrays/objects
     ERR_EXCHANGE_OVERFLOW = 16, // a sender's partial-group region overflowed (seen by the merge on every rank)
-    ERR_EXCHANGE_WIDE = 32      // a sender's keys hold wide-value codes: partial groups cannot travel
+    ERR_EXCHANGE_WIDE = 32,     // a sender's keys hold wide-value codes: partial groups cannot travel
+    // learnt from the verdict word of a received region (multi-GPU exchange): some SENDER's step failed — seen by every
+    // receiver alike, so every rank's n1k_finish fails in the same step
+    ERR_PEER_UNPACKABLE = 64,   // a sender dropped rows whose group key does not pack (its ERR_UNPACKABLE_KEY)
+    ERR_PEER_UNSUPPORTED = 128, // a sender met a value outside the device subset (its ERR_UNSUPPORTED_VALUE)
+    ERR_PEER_FAILED = 256       // a sender failed on the host before the collective; its n1k_status is in counter [27]
 };
+constexpr uint32_t kErrFromVerdict = ERR_EXCHANGE_OVERFLOW | ERR_EXCHANGE_WIDE | ERR_PEER_UNPACKABLE | ERR_PEER_UNSUPPORTED | ERR_PEER_FAILED;
+
+// Verdict word of a region that travels between GPUs (word 1 of a packed row region's or a partial-group region's header).
+// A sender writes the same verdict into EVERY region it ships, so all receivers read the same set of verdicts.
+enum : uint64_t {
+    VD_OVERFLOW = 1,     // some region of this sender overflowed
+    VD_WIDE = 2,         // partial groups: the keys hold device-local wide-value codes
+    VD_UNPACKABLE = 4,   // rows: the sender's partition dropped rows whose key does not pack
+    VD_UNSUPPORTED = 8,  // rows: the sender's Filter met a value outside the device subset
+    VD_STATUS_SHIFT = 8  // bits 8..15: the n1k_status of a sender that failed on the host before the collective
+};
+// the error flags live in counter [12]; the largest status a peer's verdict carried goes to counter [27]
+constexpr uint32_t kPeerStatusFromErr = 15;
+#ifndef __HIPCC_RTC__
+static_assert(12 + kPeerStatusFromErr == 27, "peer status counter");
+#endif
 
 struct Program {
     uint32_t ncols, nterms, nlogic, nkeys, naggs;

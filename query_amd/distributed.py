@@ -16,9 +16,9 @@ shard and the ranks meet in ONE exchange step, behind the C ABI (include/n1k.h, 
                            > 1 on a single GPU (tests/test_gpu_distributed.py).
 
 This module is the thin Python caller (bench.py, tests): torch.distributed only carries the communicator id at start-up
-and the bench's barriers — no row and no group crosses it.  The functions at the top (exchange_counts, exchange_rows,
-gather_groups, FixedGather) are the same protocol spelt with torch collectives, so that it can be rehearsed under gloo
-on CPU tensors (tests/test_distributed_cpu.py, world_size 2); the GPU path does not use them.
+and the bench's barriers — no row and no group crosses it.  One step is ONE call through the ABI (n1k_rows_step /
+n1k_partials_step), which also owns the failure rules (include/n1k.h, "Failures"): a failure that every rank sees alike
+(n1k_failure_is_global) ends the step without a gather, a rank's own failure travels in the gather.
 """
 from __future__ import annotations
 
@@ -29,97 +29,6 @@ import time
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
-
-
-def exchange_counts(counts, group=None):
-    """counts[d] rows this rank sends to rank d  ->  tensor recv[s] rows it receives from rank s."""
-    import torch
-    import torch.distributed as dist
-    recv = torch.empty_like(counts)
-    dist.all_to_all_single(recv, counts, group=group)
-    return recv
-
-
-def exchange_rows(send_cols: Sequence, send_counts: Sequence[int], recv_counts: Sequence[int], group=None) -> List:
-    """One all_to_all_single per column buffer.  send_cols[c] is contiguous and ordered by destination rank
-    (send_counts rows each); returns the received column buffers ordered by source rank."""
-    import torch
-    import torch.distributed as dist
-    out = []
-    total = int(sum(recv_counts))
-    for col in send_cols:
-        recv = torch.empty((total,) + tuple(col.shape[1:]), dtype=col.dtype, device=col.device)
-        dist.all_to_all_single(recv, col, output_split_sizes=[int(x) for x in recv_counts],
-                               input_split_sizes=[int(x) for x in send_counts], group=group)
-        out.append(recv)
-    return out
-
-
-def gather_groups(local: np.ndarray, device=None, dst: int = 0, group=None) -> Optional[np.ndarray]:
-    """Gather variable-length arrays of fixed-size records (uint8 [n, record_bytes]) on rank dst."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    dev = device if device is not None else torch.device("cpu")
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    width = local.shape[1] if local.ndim == 2 else 1
-    mx = max(max(counts), 1)
-    pad = np.zeros((mx, width), dtype=np.uint8)
-    pad[:local.shape[0]] = local.reshape(local.shape[0], width)
-    mine = torch.from_numpy(pad).to(dev)
-    bufs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(bufs, mine, group=group)  # G rows: tiny next to the row exchange
-    if rank != dst:
-        return None
-    parts = [bufs[r][:counts[r]].cpu().numpy() for r in range(world)]
-    return np.concatenate(parts, axis=0) if parts else np.zeros((0, width), np.uint8)
-
-
-class FixedGather:
-    """Gather of the finished groups with ONE collective: every rank contributes a fixed-size slot
-    [count i64][records ...]; if some rank has more records than a slot holds, every rank sees it in the gathered
-    headers and all retry with larger slots."""
-
-    def __init__(self, record_bytes: int, capacity: Optional[int] = None):
-        """capacity: records per slot, THE SAME ON EVERY RANK (a slot's size is part of the collective's shape); None =
-        agreed on at the first call from the largest contribution (one small all-reduce)."""
-        self.record_bytes = max(int(record_bytes), 1)
-        self.capacity = capacity
-        self._bufs = None
-
-    def __call__(self, local: np.ndarray, device, group=None) -> np.ndarray:
-        import torch
-        import torch.distributed as dist
-        world = dist.get_world_size(group)
-        n = int(local.shape[0])
-        if self.capacity is None:
-            # ranks own different numbers of groups after a hash partition: the slot size must not depend on the local one
-            most = torch.tensor([n], dtype=torch.int64, device=device)
-            dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
-            self.capacity = max(1024, int(2 ** int(np.ceil(np.log2(max(2 * int(most.item()), 1))))))
-        while True:
-            slot = 8 + self.capacity * self.record_bytes
-            if self._bufs is None or self._bufs[0].numel() != slot:
-                self._bufs = (torch.zeros(slot, dtype=torch.uint8, device=device),
-                              torch.zeros(slot * world, dtype=torch.uint8, device=device))
-            mine, allb = self._bufs
-            host = np.zeros(slot, dtype=np.uint8)
-            host[:8] = np.array([n], dtype=np.int64).view(np.uint8)
-            k = min(n, self.capacity)
-            host[8:8 + k * self.record_bytes] = local[:k].reshape(-1)
-            mine.copy_(torch.from_numpy(host))
-            dist.all_gather_into_tensor(allb, mine, group=group)
-            got = allb.cpu().numpy().reshape(world, slot)
-            counts = got[:, :8].copy().view(np.int64).reshape(world)
-            if counts.max() <= self.capacity:
-                parts = [got[r, 8:8 + int(counts[r]) * self.record_bytes].reshape(int(counts[r]), self.record_bytes)
-                         for r in range(world)]
-                return np.concatenate(parts, axis=0)
-            self.capacity = int(2 ** int(np.ceil(np.log2(counts.max()))))
 
 
 class Comm:
@@ -221,49 +130,57 @@ class ShardedFilterGroup:
 
     # ------------------------------------------------------------------ exchange of partial groups
     def run_partials(self, nrows: int, cols_by_path: Dict[str, tuple], replicate: bool = False) -> Tuple[dict, dict]:
-        """Every rank aggregates its shard (the single-GPU kernels), then n1k_exchange_partials moves the partial groups:
-        one all-gather (replicate and few groups) or one all-to-all of hash-partitioned regions; the receiver merges and
-        n1k_finish is the step's one wait.  A region that overflows fails the step on every rank alike: retry x4."""
+        """n1k_partials_step: every rank aggregates its shard (the single-GPU kernels), ONE collective moves the partial groups —
+        an all-gather (replicate and few groups) or an all-to-all of hash-partitioned regions — the receiver merges, finishes,
+        and (hash-partitioned) the finished groups are gathered.  A region that overflows voids the step on every rank alike:
+        all of them retry with 4 x the capacity; wide key values (coded per handle) send all of them to the row exchange."""
         from query_amd import _ffi
         from query_amd.gpu_operator import N1kError
         snd, lib = self.sender, self.sender._lib
-        failed = None
-        while True:
+        batch = self._batch(nrows, cols_by_path)
+        if self.partial_capacity is None:
+            # first step only: size the regions from the groups the shards really hold
             snd.reopen()
-            snd.process_device_batch(self._batch(nrows, cols_by_path))
-            if self.partial_capacity is None:
-                snd.sync()  # first step only: size the regions from the groups the shards really hold
-                ng = self._max(snd, int(snd.stats()["groups_out"]))
-                full = 1 << max(10, int(np.ceil(np.log2(ng * 1.25 + 64))))
-                if replicate and int(lib.n1k_partial_region_bytes(snd._h, full)) * self.world <= self.GATHER_LIMIT:
-                    self.partial_capacity = full
-                else:
-                    self.partial_capacity = 1 << max(10, int(np.ceil(np.log2(ng / self.world * 1.5 + 64))))
+            snd.process_device_batch(batch)
+            snd.sync()
+            ng = self._max(snd, int(snd.stats()["groups_out"]))
+            full = 1 << max(10, int(np.ceil(np.log2(ng * 1.25 + 64))))
+            if replicate and int(lib.n1k_partial_region_bytes(snd._h, full)) * self.world <= self.GATHER_LIMIT:
+                self.partial_capacity = full
+            else:
+                self.partial_capacity = 1 << max(10, int(np.ceil(np.log2(ng / self.world * 1.5 + 64))))
+        out, worst = _ffi.Result(), C.c_int(0)
+        while True:
             cap = self.partial_capacity
             region = int(lib.n1k_partial_region_bytes(snd._h, cap))
             gathered = replicate and region * self.world <= self.GATHER_LIMIT
             rcv = self.merger if gathered else self.receiver
-            rcv.reopen()
-            snd._check(lib.n1k_exchange_partials(self.comm._h, snd._h, rcv._h, cap, 1 if gathered else 0))
-            try:
-                raw = rcv.after_items_raw()
-            except N1kError as e:
-                if e.status == _ffi.OOM and "region" in e.message:
-                    self.partial_capacity *= 4
-                    continue
-                if e.status == _ffi.UNSUPPORTED:  # wide key values are coded per handle: such groups travel as rows
-                    raw, info = self.run_rows(nrows, cols_by_path)
-                    info["mode"] = "rows (wide key values)"
-                    return raw, info
-                if gathered:
-                    raise  # (every rank merged the same regions: the same error everywhere)
-                failed = e  # this owner's share alone failed: the peers learn it in the gather instead of waiting there
-                raw = None
+            st = int(lib.n1k_partials_step(self.comm._h, snd._h, C.byref(batch[0]), rcv._h, self.merger._h, cap, 1 if gathered else 0,
+                                           C.byref(out), C.byref(worst)))
+            everywhere = bool(lib.n1k_failure_is_global(rcv._h)) or bool(lib.n1k_failure_is_global(snd._h))
+            if st == _ffi.REGION_FULL:
+                self.partial_capacity *= 4  # (a region overflowed: on every rank alike, no gather took place)
+                continue
+            if st == _ffi.UNSUPPORTED and everywhere:  # wide key values are coded per handle: such groups travel as rows
+                raw, info = self.run_rows(nrows, cols_by_path)
+                info["mode"] = "rows (wide key values)"
+                return raw, info
             break
+        self._raise(st, worst.value, (rcv, snd, self.merger))
         stats = snd.stats()
         info = {"mode": "gathered partials" if gathered else "partials", "region_bytes": region,
                 "scan_ms": float(stats["device_ms"]), "spec_kernel": int(stats["spec_kernel"])}
-        return (raw, info) if gathered else (self._gather(rcv, raw, failed), info)
+        return self._result_dict(out), info
+
+    def _raise(self, st: int, worst: int, handles):
+        from query_amd.gpu_operator import N1kError
+        if st != 0:  # this rank's own failure (its peers learnt it in the headers or in the gather)
+            msg = b""
+            for hnd in handles:
+                msg = msg or (hnd._lib.n1k_last_error(hnd._h) or b"")
+            raise N1kError(st, msg.decode(errors="replace"))
+        if worst != 0:
+            raise N1kError(int(worst), "a peer rank's step failed with status %d" % worst)
 
     def run_gathered(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
         return self.run_partials(nrows, cols_by_path, replicate=True)
@@ -285,22 +202,16 @@ class ShardedFilterGroup:
             cap = self.row_capacity if self.row_capacity is not None else self._first_row_capacity
             # n1k_rows_step: both resets, the exchange, the owner's n1k_finish and the gather in ONE call through the ABI
             st = int(lib.n1k_rows_step(self.comm._h, snd._h, C.byref(batch[0]), rcv._h, self.merger._h, cap, C.byref(out), C.byref(worst)))
-            if st == _ffi.OOM and b"region" in (lib.n1k_last_error(rcv._h) or b""):
+            if st == _ffi.REGION_FULL:
                 self.row_capacity = cap * 2  # (a region overflowed: on every rank alike, no gather took place)
                 continue
             break
-        if self.row_capacity is None:
+        if self.row_capacity is None and st == _ffi.OK and worst.value == 0:  # (a failed step is known as such on every rank)
             got = self._max(rcv, int(rcv.stats()["rows_selected"]))
             # `got` is the LARGEST owner's total, and every source sees the same split of the keys over the owners: a source's
             # region for that owner holds about got / world rows (+ 10 %: shards are not identical; an overflow doubles it)
             self.row_capacity = min(cap, max(4096, int(got / self.world * 1.1) + 4096)) if self.world > 1 else max(4096, int(got * 1.02) + 4096)
-        if st != _ffi.OK:  # this rank's own failure (its peers learnt it in the gather)
-            msg = b""
-            for hnd in (rcv, snd, self.merger):
-                msg = msg or (lib.n1k_last_error(hnd._h) or b"")
-            raise N1kError(st, msg.decode(errors="replace"))
-        if worst.value != 0:
-            raise N1kError(int(worst.value), "a peer rank's step failed with status %d" % worst.value)
+        self._raise(st, worst.value, (rcv, snd, self.merger))
         stats = snd.stats()
         return self._result_dict(out), {"mode": "rows", "region_rows": cap, "scan_ms": float(stats["device_ms"]),
                                         "recv_rows": int(rcv.stats()["rows_selected"])}
@@ -320,46 +231,18 @@ class ShardedFilterGroup:
                 "keys": arr(out.keys, n * nk).reshape(n, nk) if nk else np.zeros((n, 0), dt),
                 "aggs": arr(out.aggs, n * na).reshape(n, na) if na else np.zeros((n, 0), dt)}
 
-    def _gather(self, rcv, raw: Optional[dict], failed=None) -> dict:
-        """n1k_gather_groups_status: the owners' finished groups on every rank, the grouped tail applied over the union.  A
-        rank whose own step failed (`failed`: its N1kError) still enters the collective, with its status instead of groups:
-        every rank then raises (the failing rank its own error, the others the status they were told)."""
-        from query_amd import _ffi
-        from query_amd.gpu_operator import GpuFilterGroup, N1kError
-        dt = GpuFilterGroup._VALUE_DT
-        m = self.merger
-        nk = na = 0
-        local = _ffi.Result()
-        if failed is None:
-            ng, nk, na = raw["ngroups"], raw["nkeys"], raw["naggs"]
-            keys = np.ascontiguousarray(raw["keys"]) if nk else np.zeros((ng, 0), dt)
-            aggs = np.ascontiguousarray(raw["aggs"]) if na else np.zeros((ng, 0), dt)
-            local.ngroups, local.nkeys, local.naggs = ng, nk, na
-            local.keys = C.cast(keys.ctypes.data, C.POINTER(_ffi.Value)) if keys.size else None
-            local.aggs = C.cast(aggs.ctypes.data, C.POINTER(_ffi.Value)) if aggs.size else None
-        out = _ffi.Result()
-        worst = C.c_int(0)
-        m._check(m._lib.n1k_gather_groups_status(self.comm._h, m._h, C.byref(local), 0 if failed is None else int(failed.status),
-                                                 C.byref(out), C.byref(worst)))
-        if failed is not None:
-            raise failed
-        if worst.value != 0:
-            raise N1kError(int(worst.value), "a peer rank's step failed with status %d" % worst.value)
-        n = int(out.ngroups)
-
-        def arr(ptr, count):
-            if not count or not ptr:
-                return np.zeros(0, dtype=dt)
-            return np.frombuffer(bytearray(C.string_at(ptr, count * dt.itemsize)), dtype=dt)
-
-        return {"ngroups": n, "nkeys": nk, "naggs": na,
-                "keys": arr(out.keys, n * nk).reshape(n, nk) if nk else np.zeros((n, 0), dt),
-                "aggs": arr(out.aggs, n * na).reshape(n, na) if na else np.zeros((n, 0), dt)}
-
     def done(self):
         for h in (self.sender, self.receiver, self.merger):
             h.done()
         self.comm.done()
+
+
+def shard_bounds(args, rank: int, world: int) -> Tuple[int, int, int]:
+    """(rows in all, this rank's first row, its row count): weak scaling by default (every rank owns --rows rows of one global
+    synthetic data set), --total-rows T = strong scaling (T rows in all, split evenly; shards differ by at most one row)."""
+    total_rows = args.total_rows if args.total_rows else args.rows * world
+    first = total_rows * rank // world
+    return total_rows, first, total_rows * (rank + 1) // world - first
 
 
 def bench_main(args, rank: int, world: int, local_rank: int):
@@ -377,9 +260,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # bootstrap + the bench's barriers only
     wl = bench.workloads()[args.workload]
     strong = bool(args.total_rows)
-    total_rows = args.total_rows if strong else args.rows * world
-    first = total_rows * rank // world
-    rows = total_rows * (rank + 1) // world - first
+    total_rows, first, rows = shard_bounds(args, rank, world)
     cols = bench.DeviceColumns(rows, args.kcat, bool(args.zipf), first, total_rows, local_rank)
     op = ShardedFilterGroup(wl["cond"], wl["keys"], wl["aggs"], bench.synth_dictionary(args.kcat), rank, world,
                             local_rank, order=wl.get("order"), limit=wl.get("limit"))

@@ -21,7 +21,7 @@ from ._ffi import COL_DICT32, COL_TAGGED64
 
 class N1kError(RuntimeError):
     def __init__(self, status: int, message: str):
-        super().__init__("%s: %s" % (_ffi.STATUS_NAMES[status] if 0 <= status < 8 else status, message))
+        super().__init__("%s: %s" % (_ffi.STATUS_NAMES[status] if 0 <= status < len(_ffi.STATUS_NAMES) else status, message))
         self.status = status
         self.message = message
 

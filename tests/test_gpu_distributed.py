@@ -584,3 +584,241 @@ def test_one_owners_failure_reaches_every_rank(mode):
     assert all(isinstance(o, query_amd.N1kError) for o in outs), outs
     assert all(o.status == _ffi.UNSUPPORTED_DATA for o in outs), [(o.status, o.message) for o in outs]
     assert sum("peer rank" in o.message for o in outs) == world - 1  # (one owner's own error, the others were told)
+
+
+def _shards(t, paths, world):
+    n = t.columns[0].tags.shape[0] if t.columns[0].tags is not None else t.columns[0].codes.shape[0]
+    shards, keep = [], []
+    for r in range(world):
+        lo, hi = n * r // world, n * (r + 1) // world
+        sub = n1o.Table([n1o.Column(c.name, c.kind, tags=None if c.tags is None else c.tags[lo:hi],
+                                    payload=None if c.payload is None else c.payload[lo:hi],
+                                    codes=None if c.codes is None else c.codes[lo:hi]) for c in t.columns], t.dictionary)
+        dev, k = _device_cols(sub, paths)
+        keep.append(k)
+        shards.append((hi - lo, dev))
+    return shards, keep
+
+
+def _paths(cond, keys, aggs):
+    probe = query_amd.GpuFilterGroup(plan.filter_group_plan(cond, keys, aggs))
+    paths = probe.column_paths
+    probe.done()
+    return paths
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["rows", "partials", "gathered"])
+@pytest.mark.parametrize("site,when", [(1, 0), (1, 1), (2, 1), (3, 1), ("batch", 0), ("batch", 1)],
+                         ids=["buffers-first-step", "buffers-later-step", "partition-or-export", "receiving-part", "bad-batch-first-step",
+                              "bad-batch-later-step"])
+def test_a_ranks_failure_around_the_collective_reaches_every_rank(mode, site, when):
+    """One rank of three fails at a chosen point of ONE step (option inject_failure on its sender: 1 = the exchange's buffers
+    cannot be had, 2 = its partition / export fails, 3 = its receiving part fails; or a batch whose tag pointer is null), in
+    its first step (no buffers yet: it ships one scratch region to every peer) or after a good one.  Whatever the point, every
+    rank returns from that step with the failing rank's status — nobody is left waiting in the all-to-all or in the gather —
+    and the next step, without the fault, gives the oracle's groups on every rank (the communicator is still in step)."""
+    from query_amd import distributed as qd
+    from query_amd.gpu_operator import GroupRows
+    world, bad = 3, 1
+    n = 60_003
+    t = n1o.synth_table(n, k_cat=37)
+    aggs = sorted(["count(*)", "sum(%s)" % D("price")])
+    ora = n1o.run(t, COND, KEYS, aggs)
+    comms = qd.Comm.loopback(world, 0)
+    shards, keep = _shards(t, _paths(COND, KEYS, aggs), world)
+    if site == "batch" and mode != "rows":
+        pytest.skip("a batch is validated by the push of the shard in these modes: covered by the export site")
+
+    def rank_body(r):
+        op = qd.ShardedFilterGroup(COND, KEYS, aggs, t.dictionary, r, world, 0, comm=comms[r])
+        fn = {"rows": op.run_rows, "partials": op.run_partials, "gathered": op.run_gathered}[mode]
+        rows_n, dev = shards[r]
+        seen = []
+        for step in range(3):
+            faulty = r == bad and step == when
+            if faulty and site != "batch":
+                op.sender.set_option("inject_failure", site)
+            if faulty and site == "batch":
+                good = op._batch(rows_n, dev)
+                for i in range(len(op.send_paths)):
+                    if good[0].cols[i].kind == _ffi.COL_TAGGED64:
+                        saved, good[0].cols[i].tags = good[0].cols[i].tags, None
+                        which = i
+                        break
+            try:
+                raw, _info = fn(rows_n, dev)
+                cache = {}
+                seen.append(GroupRows(1, len(aggs), op.merger._py_values(raw["keys"], cache), op.merger._py_values(raw["aggs"], cache), []))
+            except query_amd.N1kError as e:
+                seen.append(e)
+            if faulty and site == "batch":
+                good[0].cols[which].tags = saved
+        return seen
+
+    outs = _run_ranks(world, rank_body)
+    want = {1: _ffi.OOM, 2: _ffi.DEVICE_ERROR, 3: _ffi.DEVICE_ERROR, "batch": _ffi.INVALID}[site]
+    for r in range(world):
+        for step in range(3):
+            got = outs[r][step]
+            if step == when and site == 3 and mode == "gathered" and r != bad:
+                # (every rank merged every rank's groups and no gather follows: the receiving part is each rank's own)
+                assert not isinstance(got, Exception), (r, step, got)
+                pu.assert_same_groups(got, ora, aggs=aggs)
+            elif step == when:
+                assert isinstance(got, query_amd.N1kError), "rank %d returned groups from the faulty step" % r
+                assert got.status == want, (r, got.status, got.message)
+            else:
+                assert not isinstance(got, Exception), (r, step, got)
+                pu.assert_same_groups(got, ora, aggs=aggs)
+    if site == 3:  # the receiving part is one rank's own: its peers were told in the gather (gathered mode has none)
+        told = sum(isinstance(outs[r][when], Exception) and "peer rank" in outs[r][when].message for r in range(world))
+        assert told == (0 if mode == "gathered" else world - 1), [o[when].message for o in outs]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("case", ["array-under-less-than", "float-key-without-wide-values"])
+def test_what_a_senders_partition_finds_reaches_every_rank(case):
+    """The row exchange's SENDER side sees the data first: a Filter that has to order an array, a group key value that does
+    not pack (a float key with wide_values = 0).  Its partition kernel drops such rows and raises its own error flags —
+    which now travel in the verdict word of every region it ships: every rank's step fails with N1K_UNSUPPORTED_DATA, as the
+    single-GPU path does for the same data, instead of returning groups that miss rows."""
+    from query_amd import distributed as qd
+    world, n = 2, 6000
+    rng = np.random.default_rng(11)
+    dictionary = [b"k%d" % i for i in range(8)] + [b"[1]", b"[2]"]
+    codes = rng.integers(0, 8, n).astype(np.uint32)
+    tags = np.full(n, n1o.T_INT, np.uint8)
+    pay = rng.integers(0, 1000, n).astype(np.uint64)
+    opts = {}
+    if case == "array-under-less-than":
+        tags[n - 5], pay[n - 5] = n1o.T_ARRAY, 8  # one array, in the second shard
+        # (an array against an array: only then does `<` have to order arrays, which the device cannot)
+        cond, keys = "(%s < %s)" % (D("v"), D("w")), [D("s")]
+        wt, wp = tags.copy(), (pay + 1).astype(np.uint64)
+        wp[n - 5] = 9  # (another array: equal codes are equal values and need no ordering)
+        cols = [n1o.Column(D("s"), n1o.COL_DICT32, codes=codes), n1o.Column(D("v"), n1o.COL_TAGGED64, tags=tags, payload=pay),
+                n1o.Column(D("w"), n1o.COL_TAGGED64, tags=wt, payload=wp)]
+    else:
+        ftags = np.full(n, n1o.T_FLOAT, np.uint8)
+        fpay = (rng.integers(0, 50, n) + 0.5).astype(np.float64).view(np.uint64)
+        cond, keys = None, [D("f")]
+        cols = [n1o.Column(D("f"), n1o.COL_TAGGED64, tags=ftags, payload=fpay), n1o.Column(D("v"), n1o.COL_TAGGED64, tags=tags, payload=pay)]
+        opts = {"wide_values": 0}
+    aggs = sorted(["count(*)", "sum(%s)" % D("v")])
+    t = n1o.Table(cols, dictionary)
+    comms = qd.Comm.loopback(world, 0)
+    shards, keep = _shards(t, _paths(cond, keys, aggs), world)
+
+    def rank_body(r):
+        op = qd.ShardedFilterGroup(cond, keys, aggs, t.dictionary, r, world, 0, comm=comms[r])
+        for k, v in opts.items():
+            for h in (op.sender, op.receiver):
+                h.set_option(k, v)
+        rows_n, dev = shards[r]
+        try:
+            op.run_rows(rows_n, dev)
+        except query_amd.N1kError as e:
+            return e
+        return None
+
+    outs = _run_ranks(world, rank_body)
+    assert all(isinstance(o, query_amd.N1kError) for o in outs), outs
+    assert all(o.status == _ffi.UNSUPPORTED_DATA for o in outs), [(o.status, o.message) for o in outs]
+
+
+@pytest.mark.timeout(300)
+def test_several_exchanges_per_step_on_one_communicator():
+    """processItem* then afterItems: a rank sends its shard in several batches, one n1k_exchange_rows each, before the
+    owner's n1k_finish.  Every exchange reuses the communicator's two buffers: it waits (on the device) for the owner's scans
+    of the previous one.  World size 2 over the loopback transport, three batches per rank, against the oracle."""
+    from query_amd import distributed as qd
+    from query_amd.gpu_operator import GroupRows
+    world, nb = 2, 3
+    n = 300_000
+    t = n1o.synth_table(n, k_cat=53)
+    aggs = sorted(["count(*)", "sum(%s)" % D("price"), "count(distinct %s)" % D("user_id")])
+    ora = n1o.run(t, COND, KEYS, aggs)
+    comms = qd.Comm.loopback(world, 0)
+    paths = _paths(COND, KEYS, aggs)
+    pieces, keep = _shards(t, paths, world * nb)
+
+    def rank_body(r):
+        op = qd.ShardedFilterGroup(COND, KEYS, aggs, t.dictionary, r, world, 0, comm=comms[r])
+        lib = op.sender._lib
+        op.receiver.reopen()
+        op.sender.reopen()
+        for b in range(nb):
+            rows_n, dev = pieces[r * nb + b]
+            batch = op.sender.make_device_batch(rows_n, [dev[p] for p in op.send_paths])
+            op.sender._check(lib.n1k_exchange_rows(op.comm._h, op.sender._h, C.byref(batch[0]), op.receiver._h, n))
+        raw = op.receiver.after_items_raw()
+        local = _ffi.Result()
+        keys_a, aggs_a = np.ascontiguousarray(raw["keys"]), np.ascontiguousarray(raw["aggs"])
+        local.ngroups, local.nkeys, local.naggs = raw["ngroups"], raw["nkeys"], raw["naggs"]
+        local.keys = C.cast(keys_a.ctypes.data, C.POINTER(_ffi.Value)) if keys_a.size else None
+        local.aggs = C.cast(aggs_a.ctypes.data, C.POINTER(_ffi.Value)) if aggs_a.size else None
+        out = _ffi.Result()
+        op.merger._check(lib.n1k_gather_groups(op.comm._h, op.merger._h, C.byref(local), C.byref(out)))
+        res = op._result_dict(out)
+        cache = {}
+        return GroupRows(1, len(aggs), op.merger._py_values(res["keys"], cache), op.merger._py_values(res["aggs"], cache), [])
+
+    for rows in _run_ranks(world, rank_body):
+        pu.assert_same_groups(rows, ora, aggs=aggs)
+
+
+@pytest.mark.timeout(900)
+def test_world_size_8_configs_4_and_5_over_the_loopback_transport():
+    """BASELINE configs 4 and 5 are 8-rank configurations: their own queries at world size 8 on one GPU (loopback transport).
+    Config 4 = config 2's and config 3's queries with rows hash-partitioned on cat by the all-to-all (the row exchange; for
+    config 2 also both partial-group modes); config 5 = GROUP BY cat, region_id ORDER BY SUM(price) DESC LIMIT 100 (row
+    exchange and hash-partitioned partial groups, each owner's top rows gathered and cut).  Every rank must end with the
+    oracle's answer over the whole table, and every survivor must reach exactly one owner."""
+    from query_amd import distributed as qd
+    from query_amd.gpu_operator import GroupRows
+    world = 8
+    n = 400_003
+    t = n1o.synth_table(n, k_cat=1000)
+    aggs2 = ["sum(%s)" % D("price")]
+    aggs3 = sorted(["count(distinct %s)" % D("user_id"), "avg(%s)" % D("price")])
+    keys5 = [D("cat"), D("region_id")]
+    order5, limit5 = [("sum(%s)" % D("price"), True)], 100
+    paths = _paths(COND, keys5, sorted(aggs2 + aggs3))
+    shards, keep = _shards(t, paths, world)
+    comms = {k: qd.Comm.loopback(world, 0) for k in ("c2", "c3", "c5")}
+
+    def rank_body(r):
+        rows_n, dev = shards[r]
+        got = {}
+
+        def rows_of(op, raw, nk, na):
+            cache = {}
+            return GroupRows(nk, na, op.merger._py_values(raw["keys"], cache), op.merger._py_values(raw["aggs"], cache), [])
+
+        op2 = qd.ShardedFilterGroup(COND, KEYS, aggs2, t.dictionary, r, world, 0, comm=comms["c2"][r])
+        for mode, fn in (("rows", op2.run_rows), ("partials", op2.run_partials), ("gathered", op2.run_gathered)):
+            raw, info = fn(rows_n, dev)
+            got["c2-" + mode] = (rows_of(op2, raw, 1, 1), info)
+        op3 = qd.ShardedFilterGroup(None, KEYS, aggs3, t.dictionary, r, world, 0, comm=comms["c3"][r])
+        raw, info = op3.run_rows(rows_n, dev)
+        got["c3-rows"] = (rows_of(op3, raw, 1, 2), info)
+        op5 = qd.ShardedFilterGroup(None, keys5, aggs2, t.dictionary, r, world, 0, order=order5, limit=limit5, comm=comms["c5"][r])
+        for mode, fn in (("rows", op5.run_rows), ("partials", op5.run_partials)):
+            raw, info = fn(rows_n, dev)
+            got["c5-" + mode] = (rows_of(op5, raw, 2, 1), info)
+        return got
+
+    outs = _run_ranks(world, rank_body)
+    ora2 = n1o.run(t, COND, KEYS, aggs2, threads=4)
+    ora3 = n1o.run(t, None, KEYS, aggs3, threads=4)
+    ora5 = n1o.run(t, None, keys5, aggs2, threads=4)
+    for r in range(world):
+        for mode in ("rows", "partials", "gathered"):
+            pu.assert_same_groups(outs[r]["c2-" + mode][0], ora2, aggs=aggs2)
+        pu.assert_same_groups(outs[r]["c3-rows"][0], ora3, aggs=aggs3)
+        for mode in ("rows", "partials"):
+            pu.assert_ordered_groups(outs[r]["c5-" + mode][0], ora5, keys5, aggs2, order5, limit5, None)
+    assert sum(outs[r]["c2-rows"][1]["recv_rows"] for r in range(world)) == ora2.rows_passed
+    assert sum(outs[r]["c3-rows"][1]["recv_rows"] for r in range(world)) == n
+    assert sum(outs[r]["c5-rows"][1]["recv_rows"] for r in range(world)) == n
