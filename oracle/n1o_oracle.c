@@ -232,7 +232,8 @@ static val num_imod(val a, val b) {
 enum {
     E_CONST, E_PATH, E_ADD, E_SUB, E_MULT, E_DIV, E_MOD, E_NEG, E_IDIV, E_IMOD, E_EQ, E_LT, E_LE, E_BETWEEN,
     E_AND, E_OR, E_NOT, E_ISNULL, E_ISNOTNULL, E_ISMISSING, E_ISNOTMISSING, E_ISVALUED, E_ISNOTVALUED,
-    E_ROUND, E_TRUNC, E_ABS, E_CEIL, E_FLOOR, E_SIGN, E_SQRT /* expression/func_num.go */
+    E_ROUND, E_TRUNC, E_ABS, E_CEIL, E_FLOOR, E_SIGN, E_SQRT, /* expression/func_num.go */
+    E_GREATEST, E_LEAST /* expression/func_comp.go:54-67, 124-138 */
 };
 
 typedef struct node {
@@ -458,6 +459,20 @@ static node *parse_function(parser *p) {
         }
         if (!eat_char(p, ')')) { perr(p, "expected )"); free_node(nd); return NULL; }
         if (nd->nch > ((kind == E_ROUND || kind == E_TRUNC) ? 2 : 1)) { perr(p, "too many arguments to %s", name); free_node(nd); return NULL; }
+        return nd;
+    } else if (!strcmp(name, "greatest") || !strcmp(name, "least")) {
+        /* GREATEST / LEAST: two or more arguments (func_comp.go:73-79) */
+        kind = !strcmp(name, "greatest") ? E_GREATEST : E_LEAST;
+        if (!eat_char(p, '(')) { perr(p, "expected ( after %s", name); return NULL; }
+        node *nd = mknode(kind);
+        for (;;) {
+            node *a = parse_expr(p);
+            if (!a) { free_node(nd); return NULL; }
+            addch(nd, a);
+            if (!eat_char(p, ',')) break;
+        }
+        if (!eat_char(p, ')')) { perr(p, "expected )"); free_node(nd); return NULL; }
+        if (nd->nch < 2) { perr(p, "%s takes at least 2 arguments", name); free_node(nd); return NULL; }
         return nd;
     } else {
         perr(p, "function %s is outside the oracle subset", name);
@@ -815,6 +830,21 @@ static val eval(const node *n, uint64_t row, ectx *cx) {
         case E_SIGN: return new_value_f64(v < 0.0 ? -1.0 : (v > 0.0 ? 1.0 : 0.0));
         default: return new_value_f64(sqrt(v));
         }
+    }
+    case E_GREATEST: case E_LEAST: {
+        /* Greatest.Apply func_comp.go:54-67 / Least.Apply :124-138: the largest (smallest) argument above NULL in
+         * value.Collate order, the first one on ties; NULL when there is none */
+        val rv = V_NULL;
+        for (int i = 0; i < n->nch; i++) {
+            val a = eval(n->ch[i], row, cx);
+            if (a.type <= TY_NULL) continue;
+            if (rv.type == TY_NULL) rv = a;
+            else {
+                int c = collate(a, rv, &cx->unsupported);
+                if (n->kind == E_GREATEST ? c > 0 : c < 0) rv = a;
+            }
+        }
+        return rv;
     }
     case E_CONST: return n->cval;
     case E_PATH: return load_col(cx->t, n->col, row);
@@ -1741,10 +1771,16 @@ int n1o_eval(const char *expr, const n1o_table *t, n1k_value *outv, char *err, s
     for (uint64_t r = 0; r < t->nrows; r++) {
         val v = eval(n, r, &cx);
         if ((v.type == TY_STRING) && v.code == UINT32_MAX) {
-            /* constant string result: report tag only */
+            /* constant string result (GREATEST / LEAST may return one): its code if the table's dictionary holds the same
+             * bytes, else the tag only */
             memset(&outv[r], 0, sizeof outv[r]);
             outv[r].tag = N1K_T_STRING;
             outv[r].v.code = UINT32_MAX;
+            for (uint32_t c = 0; c < t->dict_n; c++)
+                if (t->dict_offsets[c + 1] - t->dict_offsets[c] == v.slen && !memcmp(t->dict_bytes + t->dict_offsets[c], v.s, v.slen)) {
+                    outv[r].v.code = c;
+                    break;
+                }
         } else
             out_value(v, &outv[r], &bad);
     }

@@ -70,12 +70,28 @@ bool to_operand(n1k_handle* h, const Expr* e, Operand& o, PlanError& err) {
     if (e->kind == EK::Func) {
         const std::string& f = e->fname;
         op = f == "round" ? AR_ROUND : f == "trunc" ? AR_TRUNC : f == "abs" ? AR_ABS : f == "ceil" ? AR_CEIL
-             : f == "floor" ? AR_FLOOR : f == "sign" ? AR_SIGN : AR_SQRT;
+             : f == "floor" ? AR_FLOOR : f == "sign" ? AR_SIGN : f == "sqrt" ? AR_SQRT : f == "greatest" ? AR_GREATEST : AR_LEAST;
         n1k_handle::Derived d{};
         d.op = op;
+        if (op >= AR_GREATEST) h->need_rank = true;  // (strings collate by their bytewise rank)
         for (auto& c : e->ch) {
             Operand x;
             if (!to_operand(h, c.get(), x, err)) return false;
+            if (d.nops == 4) {
+                // GREATEST / LEAST of more than four arguments: the winner so far is the first argument of the next node
+                // (exact: arguments at or below NULL are skipped, ties keep the earlier one)
+                if (h->plan.paths.size() + h->derived.size() >= (size_t)kMaxCols) {
+                    err.unsupported = true;
+                    err.msg = "too many columns (inputs + arithmetic nodes > 16)";
+                    return false;
+                }
+                Operand acc{};
+                acc.col = (uint32_t)(h->plan.paths.size() + h->derived.size());
+                h->derived.push_back(d);
+                d = n1k_handle::Derived{};
+                d.op = op;
+                d.ops[d.nops++] = acc;
+            }
             d.ops[d.nops++] = x;
         }
         if (h->plan.paths.size() + h->derived.size() >= (size_t)kMaxCols) {
@@ -715,6 +731,8 @@ n1k_status n1k_reset(n1k_handle* h) {
         h->groups_seen = 0;
         h->out_count_dirty = false;
         h->pending.count = 0;
+        if (h->device_clean) return N1K_OK;  // the last query's final kernel left the device as the launches below would
+        h->device_clean = true;
         // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
         if (h->table.capacity) HIP_TRY(h, launch_init_table(h->prog, h->table, 0, h->table.capacity, h->d_counters.p, h->stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_counters.p, 0, kCounters * sizeof(unsigned long long), h->stream));
@@ -791,6 +809,8 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
     else if (n == "pinned_out") h->opt_pinned_out = value ? 1 : 0;
     else if (n == "lean_topk") h->opt_lean_topk = value ? 1 : 0;
+    else if (n == "fused_tail") h->opt_fused_tail = value ? 1 : 0;
+    else if (n == "merge_chunks") h->opt_merge_chunks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 16);
     else if (n == "inject_failure") h->opt_inject_failure = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
     else if (n == "part_block") h->opt_part_block = value == 256 ? 256 : 512;
     else if (n == "part_subs") h->opt_part_subs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);  // 0 off, 1 large batches, 2 always (tests)
@@ -885,7 +905,11 @@ n1k_status n1k_run_device_batch(n1k_handle* h, const n1k_batch* batch, n1k_resul
     if (!h || !batch || !out) return N1K_INVALID;
     n1k_status st = n1k_reset(h);
     if (st == N1K_OK) st = n1k_push_device_batch(h, batch);
-    if (st == N1K_OK) st = n1k_finish(h, out);
+    if (st == N1K_OK) {
+        h->clear_on_finish = true;  // the result leaves the device; the state behind it is the next execution's reset
+        st = n1k_finish(h, out);
+        h->clear_on_finish = false;
+    }
     return st;
 }
 
@@ -1004,11 +1028,11 @@ n1k_status n1k_sync(n1k_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     drain_events(h);
-    if (h->plan.has_group) {
+    if (h->plan.has_group && !h->device_clean) {  // (clean: the query was finished and its counters zeroed behind the result)
         h->stats.rows_selected = counters[0];
         h->stats.groups_out = h->pending.count ? h->pending.count : counters[1];  // groups so far (in the table, or in the kept region)
     }
-    h->stats.wide_key_values = counters[13];
+    if (!h->device_clean) h->stats.wide_key_values = counters[13];
     return N1K_OK;
     });
 }

@@ -137,6 +137,12 @@ struct n1k_handle {
     bool failure_global = false;  // the last failure reported on this handle was learnt from (or told through) the verdict words of an
                                   // exchange: every rank's step fails alike, nobody enters the gather (n1k_failure_is_global)
     uint32_t opt_inject_failure = 0;  // tests: the exchange pretends that its site 1 (buffers) / 2 (partition, export) / 3 (receiving part) failed, once
+    // One-call executions (n1k_run_device_batch): the query's last kernel (finalize_small_kernel) leaves table and counters as
+    // n1k_reset would, so the next execution starts with its scan — device_clean says that the device state is what a reset
+    // produces (any push / merge / partition clears it), clear_on_finish asks n1k_finish for that last kernel
+    bool device_clean = false, clear_on_finish = false;
+    uint32_t opt_fused_tail = 1;    // 0: finalize_kernel + publish_counters_kernel as separate launches (ablation)
+    uint32_t opt_merge_chunks = 0;  // merge_slabs_kernel: block rows (0 = from the grid)
     bool out_count_dirty = true;  // the finalize position counter holds a previous finish's count
     char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
     unsigned long long* pin_counters = nullptr;  // pinned host copy of the device counters (one D2H per decision point)

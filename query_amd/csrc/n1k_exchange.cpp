@@ -11,6 +11,7 @@ using namespace n1k_eng;
 // plan's shape when there is one (large batches, or jit = 2: n1k_spec.h scan_spec_partition_body — wide loads, arithmetic
 // in registers, survivors written in runs), else the interpreting partition_kernel over materialised derived columns.
 static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) {
+    h->device_clean = false;
     // packed regions (the row exchange): A.sub_rows = rows per sub-region; whoever writes dense runs converts the counts
     const uint64_t seg_rows = A.region_bytes ? A.sub_rows : 0;
     A.nsub = 1;
@@ -144,6 +145,7 @@ n1k_status n1k_export_partials_async(n1k_handle* h, uint32_t nparts, uint64_t ca
     }
     if (!h->plan.has_group) return fail(h, N1K_INVALID, "no groups in a Filter-only plan");
     if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
+    h->device_clean = false;  // (an overflow raises this handle's error flags)
     n1k_status st = ensure_device(h);
     if (st != N1K_OK) return st;
     uint64_t region_words = 2 + capacity_groups * (1 + (uint64_t)h->prog.glob_words);
@@ -186,6 +188,7 @@ n1k_status n1k_merge_partials_device(n1k_handle* h, uint32_t nregions, uint64_t 
     if (!h || !in || nregions == 0 || capacity_groups == 0) return N1K_INVALID;
     if (h->has_distinct) return fail(h, N1K_UNSUPPORTED, "DISTINCT sets do not travel with partial groups");
     if (!h->layout_fixed) return fail(h, N1K_INVALID, "merge needs the key layout: push a batch (even an empty one) first");
+    h->device_clean = false;
     if (h->pending.count) {
         n1k_status pst = flush_pending(h);
         if (pst != N1K_OK) return pst;

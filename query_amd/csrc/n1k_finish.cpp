@@ -41,6 +41,18 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
                 HIP_TRY(h, hipHostMalloc((void**)&h->pin_out, total + sizeof counters, hipHostMallocDefault));
                 h->pin_cap = total + sizeof counters;
             }
+            const bool fused_tail = h->opt_pinned_out && h->opt_fused_tail && h->table.capacity <= 8192;
+            if (fused_tail) {
+                // small tables: FinalGroup, the counters behind it and — for a one-call execution, when nothing else on the
+                // device needs a reset (no wide-value tables) — the state the next execution starts from, in ONE last kernel
+                const bool clear = h->clear_on_finish && !h->prog.wide_int;
+                char* d = h->pin_out;
+                HIP_TRY(h, launch_finalize_small(h->prog, h->table, (OutValue*)d, (OutValue*)(d + off_aggs), (OutPartial*)(d + off_parts),
+                                                 (uint64_t*)(d + off_rep), h->d_counters.p, (unsigned long long*)(h->pin_out + total), spec_groups,
+                                                 h->d_errp, clear, h->stream));
+                h->out_count_dirty = !clear;
+                h->device_clean = clear;
+            } else {
             if (h->out_count_dirty) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
             h->out_count_dirty = true;  // (reopen zeroes every counter in its one launch)
             if (h->opt_pinned_out) {
@@ -57,6 +69,7 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
                                            (uint64_t*)(d + off_rep), h->d_counters.p + 2, spec_groups, h->d_errp, h->stream));
                 HIP_TRY(h, hipMemcpyAsync(h->pin_out, d, total, hipMemcpyDeviceToHost, h->stream));
                 HIP_TRY(h, hipMemcpyAsync(h->pin_out + total, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+            }
             }
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             memcpy(counters, h->pin_out + total, sizeof counters);

@@ -46,7 +46,7 @@ hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTa
 hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                             uint32_t grid, uint32_t block, uint32_t rows_per_lane, hipStream_t st);
 hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalTable& G, uint32_t nblocks,
-                              unsigned long long* ngroups, hipStream_t st);
+                              unsigned long long* ngroups, hipStream_t st, uint32_t ychunks_opt = 0);
 // ORDER BY ... LIMIT over the finalised groups: order images of the first sort term, radix select of the keep-th image,
 // candidate indices (image <= threshold) and compaction of their records
 // high-cardinality GROUP BY: rows -> records (key + operands), [radix passes], per-bin LDS aggregation
@@ -115,6 +115,11 @@ const std::vector<SpecEntry>& spec_registry();
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,
                            OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count, uint64_t max_out,
                            uint32_t* err_flags, hipStream_t st);
+// one workgroup, tables of at most 8192 slots: FinalGroup + the counters published to the host (+ table and counters left as
+// n1k_reset leaves them): the one last kernel of a query
+hipError_t launch_finalize_small(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs, OutPartial* out_parts,
+                                 uint64_t* out_rep, unsigned long long* counters, unsigned long long* host_counters, uint64_t max_out,
+                                 uint32_t* err_flags, bool clear, hipStream_t st);
 hipError_t launch_filter_mask(const Program& P, uint64_t nrows, uint64_t* mask_words, uint32_t* tile_counts,
                               uint32_t* err_flags, uint32_t grid, hipStream_t st);
 hipError_t launch_tile_scan(const uint32_t* counts, uint64_t* offsets, uint64_t ntiles, unsigned long long* total,

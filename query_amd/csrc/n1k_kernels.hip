@@ -214,7 +214,21 @@ __global__ void arith_kernel(const ArithArgs A) {
     }
     uint32_t rt;
     uint64_t rp;
-    arith_apply(A.op, A.nops, tg, pv, rt, rp);
+    if (A.op == AR_GREATEST || A.op == AR_LEAST) {
+        // Greatest.Apply / Least.Apply (expression/func_comp.go:54-67, 124-138): the largest (smallest) argument above NULL
+        // in value.Collate order, the first one on ties; NULL when there is none
+        rt = T_NULL;
+        rp = 0;
+        uint32_t unsupported = 0;
+        for (uint32_t k = 0; k < A.nops; k++) {
+            if (tg[k] <= T_NULL) continue;
+            if (rt == T_NULL) { rt = tg[k]; rp = pv[k]; continue; }
+            const int c = collate(tg[k], pv[k], rt, rp, A.str_rank, &unsupported);
+            if (A.op == AR_GREATEST ? c > 0 : c < 0) { rt = tg[k]; rp = pv[k]; }
+        }
+        if (unsupported) atomicOr(A.err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
+    } else
+        arith_apply(A.op, A.nops, tg, pv, rt, rp);
     A.out_tags[i] = (uint8_t)rt;
     A.out_payload[i] = rp;
 }
@@ -1832,6 +1846,74 @@ __global__ __launch_bounds__(256) void finalize_kernel(const Program P, const Gl
     }
 }
 
+// FinalGroup of a SMALL table (capacity <= kFinalizeSmallMax slots) as the one last kernel of a query: one workgroup finalises
+// every group in table order, publishes the counters (with the number of output rows in [2]) into pinned host memory
+// behind the rows, and — `clear` — leaves the table and the counters as n1k_reset would: the next execution of the operator
+// over resident columns (n1k_run_device_batch) then starts with its scan, no reopen kernel in front of it.  Replaces
+// finalize_kernel + publish_counters_kernel (+ the next init_table_kernel): three dependent launches of a few microseconds
+// each, which is what a query over 10 M cached rows is made of.
+constexpr uint32_t kFinalizeSmallMax = 8192;
+__global__ __launch_bounds__(1024) void finalize_small_kernel(const Program P, const GlobalTable G, OutValue* out_keys, OutValue* out_aggs,
+                                                             OutPartial* out_parts, uint64_t* out_rep, unsigned long long* counters,
+                                                             unsigned long long* host_counters, uint64_t max_out, uint32_t* err_flags,
+                                                             uint32_t clear) {
+    __shared__ uint32_t wave_cnt[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long next = 0;
+    for (uint64_t s0 = 0; s0 < G.capacity; s0 += 1024) {
+        const uint64_t s = s0 + tid;
+        const uint64_t key = s < G.capacity ? G.keys[s] : kEmptyKey;
+        const bool used = key != kEmptyKey;
+        const unsigned long long m = __ballot(used);
+        __syncthreads();
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, step_total = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            before += w < wave ? wave_cnt[w] : 0u;
+            step_total += wave_cnt[w];
+        }
+        const unsigned long long idx = next + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        next += step_total;
+        if (!used) continue;
+        uint64_t* g = &G.acc[(size_t)s * P.glob_words];
+        if (idx < max_out) {
+            for (uint32_t k = 0; k < P.nkeys; k++) {
+                const KeySpec& ks = P.keys[k];
+                uint64_t field = ks.bits >= 64 ? key : ((key >> ks.shift) & ((1ull << ks.bits) - 1ull));
+                uint32_t tag;
+                uint64_t p;
+                unpack_key_field(P, ks.mode, field, tag, p);
+                put_value(&out_keys[idx * P.nkeys + k], tag, p);
+            }
+            for (uint32_t a = 0; a < P.naggs; a++)
+                finalize_agg(P, P.aggs[a], g, &out_aggs[idx * P.naggs + a], &out_parts[idx * P.naggs + a], err_flags);
+            if (out_rep) out_rep[idx] = P.emit_packed_key ? key : (G.rep_row ? G.rep_row[s] : ~0ull);
+        }
+        if (clear) {
+            G.keys[s] = kEmptyKey;
+            if (G.rep_row) G.rep_row[s] = ~0ull;
+            glob_row_init(P, g);
+        }
+    }
+    __syncthreads();  // (every error flag of this launch is raised)
+    if (tid == 0) counters[2] = next;
+    __syncthreads();
+    if (tid < kCounters) {
+        host_counters[tid] = __hip_atomic_load(&counters[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (clear) counters[tid] = 0;
+    }
+}
+
+hipError_t launch_finalize_small(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs, OutPartial* out_parts,
+                                 uint64_t* out_rep, unsigned long long* counters, unsigned long long* host_counters, uint64_t max_out,
+                                 uint32_t* err_flags, bool clear, hipStream_t st) {
+    if (G.capacity > kFinalizeSmallMax) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(finalize_small_kernel, dim3(1), dim3(1024), 0, st, P, G, out_keys, out_aggs, out_parts, out_rep, counters,
+                       host_counters, max_out, err_flags, clear ? 1u : 0u);
+    return hipGetLastError();
+}
+
 // FinalGroup straight from a region of partial groups with unique keys ([count][0][keys: cap][accumulators]): record i
 // is output row i (no table, no position counter).  Two lean forms for ORDER BY ... LIMIT over millions of groups (only
 // the top-k candidates need rows; writing every group's row was 0.72 GB per 6.4 M groups):
@@ -2495,9 +2577,12 @@ hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTab
 }
 
 hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalTable& G, uint32_t nblocks,
-                              unsigned long long* ngroups, hipStream_t st) {
+                              unsigned long long* ngroups, hipStream_t st, uint32_t ychunks_opt) {
     uint32_t blocks = (F.lds_slots + 63) / 64;
-    uint32_t ychunks = nblocks >= 512 ? 4 : (nblocks >= 128 ? 2 : 1);  // 16 * ychunks parallel chunks of workgroups
+    // 16 * ychunks parallel chunks of workgroups; enough blocks for every CU (64 blocks read 25 MB of slabs at 1.25 TB/s)
+    uint32_t ychunks = nblocks >= 512 ? 4 : (nblocks >= 128 ? 2 : 1);
+    while (ychunks < 16 && blocks * ychunks < 256 && nblocks >= 32 * ychunks) ychunks *= 2;
+    if (ychunks_opt) ychunks = ychunks_opt;
     hipLaunchKernelGGL(merge_slabs_kernel, dim3(blocks, ychunks), dim3(64, 16), 0, st, P, F, G, nblocks, ngroups);
     return hipGetLastError();
 }

@@ -378,6 +378,22 @@ struct EParser {
                     if (e->ch.empty() || e->ch.size() > maxargs) return bad(w + " takes 1" + (maxargs == 2 ? " or 2" : "") + " arguments");
                     return e;
                 }
+                if ((w == "greatest" || w == "least") && lx.toks[p + 1].kind == TK::LParen) {  // expression/func_comp.go
+                    p += 2;
+                    auto e = mk(EK::Func);
+                    e->fname = w;
+                    for (;;) {
+                        auto a = primary();
+                        if (!a) return nullptr;
+                        e->ch.push_back(std::move(a));
+                        if (cur().kind == TK::Comma) { p++; continue; }
+                        break;
+                    }
+                    if (cur().kind != TK::RParen) return bad("expected ) in " + w);
+                    p++;
+                    if (e->ch.size() < 2) return bad(w + " takes at least 2 arguments");
+                    return e;
+                }
                 return unsupported("function or keyword '" + w + "'");
             }
             case TK::LBrack: return unsupported("array constructor");

@@ -20,6 +20,7 @@ bool build_fast_args(n1k_handle* h, uint32_t max_slots, FastArgs& F, bool fuse, 
         for (uint32_t d = 0; d < nd; d++)
             for (uint32_t k = 0; k < h->derived[d].nops; k++) {
                 const Operand& o = h->derived[d].ops[k];
+                if (h->derived[d].op >= AR_GREATEST) return false;  // (collation needs the string ranks: derived columns)
                 if (!o.is_const && o.col >= ni + d) return false;
                 if (o.is_const) F.dconst[d][k] = o.cpayload;
             }
@@ -396,7 +397,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 }
                 if (spec) HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, L, h->stream));
                 else HIP_TRY(h, jit_launch(jit, P, F, h->table, h->d_counters.p + 1, g, wide, L, ndist, h->stream));
-                if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
+                if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream, h->opt_merge_chunks));
                 F.slabs = nullptr;
                 if (n_main < n) {
                     for (uint32_t c = 0; c < F.ncols; c++) {
@@ -422,7 +423,7 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 F.block_selected = h->d_block_sel.p;
             }
             HIP_TRY(h, launch_scan_fast(P, F, h->table, h->d_counters.p + 1, g, fblock, frpl, h->stream));
-            if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream));
+            if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream, h->opt_merge_chunks));
             F.slabs = nullptr;
         }
         if (e1) (void)hipEventRecord(e1, h->stream);
@@ -559,6 +560,12 @@ n1k_status materialize_derived(n1k_handle* h, const n1k_batch* b) {
     Program& P = h->prog;
     if (h->derived_ready) return N1K_OK;
     const uint32_t ni = (uint32_t)h->plan.paths.size();
+    for (const auto& d : h->derived)
+        if (d.op >= AR_GREATEST) {  // GREATEST / LEAST collate strings by rank: the table must cover this batch's dictionary
+            n1k_status rst = ensure_rank(h);
+            if (rst != N1K_OK) return rst;
+            break;
+        }
     h->dv_tags.resize(h->derived.size());
     h->dv_payload.resize(h->derived.size());
     for (size_t i = 0; i < h->derived.size(); i++) {
@@ -574,6 +581,8 @@ n1k_status materialize_derived(n1k_handle* h, const n1k_batch* b) {
         A.nrows = b->nrows;
         A.out_tags = h->dv_tags[i].p;
         A.out_payload = h->dv_payload[i].p;
+        A.str_rank = h->d_rank.p;
+        A.err_flags = h->d_errp;
         HIP_TRY(h, launch_arith(A, h->stream));
         DevCol& d = P.cols[ni + i];
         d.kind = COLK_TAGGED64;
@@ -587,6 +596,7 @@ n1k_status materialize_derived(n1k_handle* h, const n1k_batch* b) {
 
 n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
+    h->device_clean = false;
     n1k_status st = ensure_device(h);
     if (st != N1K_OK) return st;
     st = validate_batch(h, b);

@@ -82,6 +82,11 @@ n1k_status build_projection(n1k_handle* h) {
         }
         h->project_ops.push_back(o);
     }
+    for (const auto& d : f->derived)
+        if (d.op >= AR_GREATEST) {  // (the inner operator sees this handle's dictionary codes, not its own: no string ranks there)
+            g_create_error = "GREATEST / LEAST as a projection term over the groups does not run on the device";
+            return N1K_UNSUPPORTED;
+        }
     f->prog.ncols = (uint32_t)(f->plan.paths.size() + f->derived.size());
     return N1K_OK;
 }

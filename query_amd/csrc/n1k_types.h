@@ -412,7 +412,8 @@ constexpr uint32_t kRowSubs = 8;  // sub-regions (segments) of a packed row regi
 // temporary TAGGED64 column; the scan kernels then see them as ordinary columns
 enum : uint32_t { AR_ADD = 0, AR_MULT, AR_SUB, AR_DIV, AR_MOD, AR_NEG, AR_IDIV, AR_IMOD,
                   // expression/func_num.go: ROUND / TRUNC (value [, digits]), ABS, CEIL, FLOOR, SIGN, SQRT
-                  AR_ROUND, AR_TRUNC, AR_ABS, AR_CEIL, AR_FLOOR, AR_SIGN, AR_SQRT };
+                  AR_ROUND, AR_TRUNC, AR_ABS, AR_CEIL, AR_FLOOR, AR_SIGN, AR_SQRT,
+                  AR_GREATEST, AR_LEAST };  // expression/func_comp.go: by value.Collate (derived columns only: they need the string ranks)
 struct ArithArgs {
     uint32_t op, nops;
     Operand ops[4];
@@ -420,6 +421,8 @@ struct ArithArgs {
     uint64_t nrows;
     uint8_t* out_tags;
     uint64_t* out_payload;
+    const uint32_t* str_rank;  // AR_GREATEST / AR_LEAST: bytewise rank of every dictionary string
+    uint32_t* err_flags;       // ... and where ordering two arrays / objects is reported
 };
 
 constexpr uint32_t kMaxParts = 64;  // destinations of one partition launch (ranks of a node, with room)

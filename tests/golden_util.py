@@ -218,9 +218,11 @@ def encode_value(v: Any, d: Dictionary):
     raise TypeError(type(v))
 
 
-def build_table(docs: Sequence[dict], paths: Sequence[str]) -> n1o.Table:
-    """Documents -> TAGGED64 leaf columns + dictionary."""
+def build_table(docs: Sequence[dict], paths: Sequence[str], strings: Sequence[str] = ()) -> n1o.Table:
+    """Documents -> TAGGED64 leaf columns + dictionary (`strings`: string constants of the plan a result may hold)."""
     d = Dictionary()
+    for s in strings:
+        d.code(s.encode())
     cols = []
     for p in paths:
         steps = path_steps(p)
@@ -483,3 +485,17 @@ def sorted_values(alias: str, values: Sequence[Any]) -> List[dict]:
     """[{alias: v}] in value.Collate order (execution/order.go:121-169): the result rows of SELECT expr AS alias ... ORDER BY alias."""
     import functools
     return [{alias: v} for v in sorted(values, key=functools.cmp_to_key(collate))]
+
+
+import re as _re
+
+
+def string_constants(text: str):
+    """the "..." constants of an expression text (a result of GREATEST / LEAST may be one of them)"""
+    return _re.findall(r'"((?:[^"\\]|\\.)*)"', text)
+
+def values_ordered_by(alias: str, values: Sequence[Any], keys: Sequence[Any]) -> List[dict]:
+    """[{alias: v}] in the value.Collate order of `keys`: the result rows of SELECT expr ... ORDER BY another_field."""
+    import functools
+    order = sorted(range(len(values)), key=functools.cmp_to_key(lambda i, j: collate(keys[i], keys[j])))
+    return [{alias: values[i]} for i in order]

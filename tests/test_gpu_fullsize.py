@@ -107,6 +107,60 @@ def test_full_size_properties(columns):
             assert close(a, b)
 
 
+def test_headline_kernel_at_its_benchmarked_size(columns):
+    """bench.py's headline is config 2's own plan (SELECT cat, SUM(price) ... WHERE price > 50 GROUP BY cat) at 100 M rows on
+    the PREBUILT plan-specialised kernel scan_spec_kernel<Spec_gt_sum, 2, 512, true> (stats.spec_kernel == 1).  That very
+    instantiation, at that size, through the one-call entry point the bench times (n1k_run_device_batch): every group present,
+    the Filter's survivor count equal to an independent Filter-only count, batching invariance (the same kernel over unequal
+    batches, and twice in a row: the one-call path leaves the device clean behind it), the same groups as the kernel family
+    test_full_size_properties pins (per-group SUM from the 4-aggregate plan on the bounded-shape kernel), and the oracle on a
+    prefix."""
+    import bench
+    aggs = ["sum(%s)" % D("price")]
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, KEYS, aggs))
+    op.intern(bench.synth_dictionary(K_CAT))
+    batch = op.make_device_batch(ROWS, [columns.by_path[p] for p in op.column_paths])
+    first = op.run_device_batch_raw(batch)
+    st = op.stats()
+    assert st["spec_kernel"] == 1 and st["agg_mode"] == _ffi.MODE_LDS_DIRECT  # the prebuilt instantiation, perfect-hash table
+    second = op.run_device_batch_raw(batch)  # (no reopen kernel in front of this one: the first left the device clean)
+    third = op.run_device_batch_raw(batch)
+    op.done()
+    d1, d2, d3 = as_dict(first), as_dict(second), as_dict(third)
+    assert first["ngroups"] == K_CAT and d1.keys() == d2.keys() == d3.keys()
+    for k in d1:
+        assert close(d1[k][0], d2[k][0]) and close(d1[k][0], d3[k][0]), k
+    # the survivors: an independent kernel family counts them again
+    sel, fst = run(columns, COND, [], [], [(0, ROWS)], filter_only=True)
+    assert st["rows_selected"] == fst["rows_selected"] == len(sel["selected"])
+    # unequal batches through the same specialised kernel (three calls: reset / push x 4 / finish)
+    cuts = [0, 24_999_999, 50_000_001, 75_000_003, ROWS]
+    parts, pst = run(columns, COND, KEYS, aggs, list(zip(cuts[:-1], cuts[1:])))
+    assert pst["spec_kernel"] == 1 and pst["rows_selected"] == st["rows_selected"]
+    dp = as_dict(parts)
+    for k in d1:
+        assert close(d1[k][0], dp[k][0]), (k, d1[k], dp[k])
+    # another kernel family over the same rows: the 4-aggregate plan of test_full_size_properties (bounded-shape kernel)
+    other, ost = run(columns, COND, KEYS, AGGS, [(0, ROWS)])
+    assert ost["spec_kernel"] == 0
+    do, si = as_dict(other), AGGS.index("sum(%s)" % D("price"))
+    for k in d1:
+        assert close(d1[k][0], do[k][si]), (k, d1[k], do[k][si])
+    # and the oracle on a prefix of the same data set, through the same kernel
+    n = 2_000_000
+    t = n1o.synth_table(n, k_cat=K_CAT, total_rows=ROWS)
+    ora = n1o.run(t, COND, KEYS, aggs, threads=4)
+    raw, rst = run(columns, COND, KEYS, aggs, [(0, n)])
+    assert rst["spec_kernel"] == 1 and rst["rows_selected"] == ora.rows_passed
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(COND, KEYS, aggs))
+    op.intern(bench.synth_dictionary(K_CAT))
+    cache = {}
+    from query_amd.gpu_operator import GroupRows
+    got = GroupRows(1, 1, op._py_values(raw["keys"], cache), op._py_values(raw["aggs"], cache), [])
+    op.done()
+    pu.assert_same_groups(got, ora, aggs=aggs)
+
+
 def test_full_size_prefix_matches_oracle(columns):
     """The first 2 M rows of the 100 M-row device data set through the oracle (same generator on the CPU)."""
     n = 2_000_000

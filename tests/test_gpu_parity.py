@@ -45,6 +45,15 @@ def test_golden_cases_on_device(case):
             got = gu.sorted_values(alias, [gu.decode_value(a[0]) for a in rows.aggs])
             assert gu.same_json(got, case["results"]), (got, case["results"])
             return
+        if "row_expr_by" in plan:
+            # one value per document in the order of another field (case_func_comp.json): one group per value of that field
+            alias, text, by = plan["row_expr_by"]
+            table = gu.build_table(docs, gu.leaf_paths({"condition": None, "group_keys": [by, text], "aggregates": []}))
+            rows, _ = pu.run_gpu(table, None, [by], ["max(%s)" % text])
+            assert len(rows.keys) == len(docs)
+            got = gu.values_ordered_by(alias, [gu.decode_value(a[0]) for a in rows.aggs], [gu.decode_value(k[0]) for k in rows.keys])
+            assert gu.same_json(got, case["results"]), (got, case["results"])
+            return
         table = gu.build_table(docs, gu.leaf_paths(plan))
         if plan.get("filter_only"):
             rows, _ = pu.run_gpu(table, plan["condition"], [], [], filter_only=True)

@@ -49,7 +49,7 @@ def _expected(table):
     return out
 
 
-CASES = [c for c in gu.load_cases() if not c["plan"].get("filter_only") and "exprs" not in c["plan"] and "row_expr" not in c["plan"]]
+CASES = [c for c in gu.load_cases() if not c["plan"].get("filter_only") and "exprs" not in c["plan"] and "row_expr" not in c["plan"] and "row_expr_by" not in c["plan"]]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
