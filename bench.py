@@ -89,6 +89,12 @@ def workloads():
             "aggs": ["count(*)", "sum(%s)" % D("region_id")],
             "bytes_per_row": 22,
         },
+        # Filter alone (execution/filter.go:49-61): ascending ordinals of the rows whose condition is TRUE.  9 B per row read,
+        # 8 B per survivor written (half the rows pass: 13 B per row in all)
+        "filter": {
+            "sql": "SELECT RAW meta().id FROM default WHERE price > 50   (Filter only: the survivors' row ordinals)",
+            "cond": "(50 < %s)" % D("price"), "keys": [], "aggs": [], "filter_only": True, "bytes_per_row": 13,
+        },
         "config5_keys": {
             "sql": "SELECT cat, region_id, SUM(price) FROM default GROUP BY cat, region_id",
             "cond": None, "keys": [D("cat"), D("region_id")], "aggs": ["sum(%s)" % D("price")],
@@ -254,22 +260,144 @@ def ingest_rates(args, wl, cols) -> dict:
 
 
 def kernel_label(st: dict, wl: dict) -> str:
-    """What `roofline.kernel_ms` (the HIP-event time of the batch's kernels) covers for this workload."""
+    """What the batches' kernels are for this workload (`kernel_split["batch kernels"]`: the HIP-event time of n1k_push_device_batch's launches)."""
     if st.get("agg_mode") == 4:
-        return ("partitioned GROUP BY pipeline: key probe + scan_spec_records_kernel + radix_scatter_sub_kernel + agg_bins16_kernel "
-                "(FinalGroup / top-k not included)")
+        return "key probe + scan_spec_records_kernel + radix_scatter_sub_kernel + agg_bins16_kernel"
     if any("distinct" in a for a in wl["aggs"]):
-        return "scan_spec_kernel incl. the member words' first partition pass (second pass and LDS sets run in n1k_finish: not included)"
+        return "scan_spec_kernel incl. the member words' first partition pass (+merge_slabs_kernel)"
     if st.get("spec_kernel") == 3:
         return "run-time-built scan_spec_body with the plan's arithmetic in registers (+merge_slabs_kernel)"
     return "scan_spec_kernel(+merge_slabs_kernel)" if st.get("spec_kernel") else "scan_fast/scan_group_kernel"
 
 
-def by_rows(args, wl, local_rank: int) -> dict:
+def roofline_of(wl: dict, rows: int, st: dict, workload: str, kcat: int, opts) -> dict:
+    """ONE definition for every workload: the query's algorithmic bytes (rows x the referenced columns' widths)
+    over the HIP-event time of the WHOLE query on the handle's stream — reopen, every kernel of the batches, DISTINCT sets /
+    partition passes / top-k, FinalGroup, and the gaps between them (n1k_stats.query_ms).  The split by kernel family is the
+    sub-record `kernel_split`; `traffic` is the whole query's HBM traffic from the committed PMC passes of the same command."""
+    alg = wl["bytes_per_row"] * rows
+    if wl.get("filter_only"):
+        # the Filter-only kernel alone: its survivors' ordinals (8 B each) then cross PCIe to the host, which is the consumer's
+        # cost at the link's 52 GB/s, not the kernel's
+        alg = 9 * rows + 8 * int(st["rows_selected"])
+        ach = alg / (st["device_ms"] * 1e-3) / 1e9 if st["device_ms"] else 0.0
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "what": "Filter-only kernel (predicate + ordered compaction in one pass): 9 B per row read + 8 B per survivor written / its "
+                        "HIP-event time; the copy of the ordinals to the host is not in it",
+                "query_ms": st["device_ms"], "algorithmic_bytes_per_launch": alg}
+    q = st.get("query_ms") or 0.0
+    ach = alg / (q * 1e-3) / 1e9 if q > 0 else 0.0
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+         "what": "whole query: algorithmic bytes / HIP-event time from reopen to FinalGroup's last kernel on the handle's stream",
+         "query_ms": q, "algorithmic_bytes_per_launch": alg,
+         "kernel_split": {"batch kernels": {"ms": st["device_ms"], "what": kernel_label(st, wl),
+                                            "achieved_GB/s": alg / (st["device_ms"] * 1e-3) / 1e9 if st["device_ms"] else None},
+                          "rest of the query (reopen, sets / passes of n1k_finish, FinalGroup, top-k, gaps)": {"ms": max(0.0, q - st["device_ms"])}}}
+    # HBM traffic of the whole query from the committed PMC passes of this same command (rocprofv3 --pmc cannot run inside
+    # the timed process): per kernel 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM: gfx950 counts a wide coalesced read at half its
+    # bytes) + WRITE_SIZE, KB per dispatch x dispatches per query, summed over the query's kernels.  The figure belongs to
+    # the build the profile was taken from (`source_hash`; tools/profile_round.sh): re-profile after kernel changes.
+    pmc = None
+    for tag in ("r03", "r02"):
+        f = os.path.join(ROOT, "profiles", "%s_bench_%s_100M_pmc_fetch_write.json" % (tag, workload))
+        if os.path.exists(f):
+            pmc = f
+            break
+    if pmc and rows == 100_000_000 and kcat == (100_000 if workload.startswith("config5") else 1000) and not opts:
+        try:
+            with open(pmc) as fh:
+                c = json.load(fh)
+            from query_amd import build as qbuild
+            if c.get("source_hash") in (None, qbuild.source_hash()):  # (None: profiles taken before the stamp existed)
+                nq = c.get("queries") or min(v["dispatches"] for k, v in c["FETCH_SIZE"].items() if "scan_spec" in k or "n1k_jit" in k)
+                tot = 0.0
+                for k, v in c["FETCH_SIZE"].items():
+                    if "synth_kernel" in k:
+                        continue
+                    w = c["WRITE_SIZE"].get(k, {"avg_KB": 0.0})
+                    tot += 1024.0 * (2.0 * v["avg_KB"] + w["avg_KB"]) * v["dispatches"] / nq
+                r["traffic"] = tot
+                r["traffic_source"] = "profiles/%s (sum over the query's kernels of 2*FETCH_SIZE + WRITE_SIZE)" % os.path.basename(pmc)
+            else:
+                r["traffic_source"] = "none: profiles/%s belongs to other kernel sources (%s)" % (os.path.basename(pmc), c.get("source_hash"))
+        except Exception as e:
+            r["traffic_source"] = "none: %r" % (e,)
+    return r
+
+
+def run_resident(workload: str, rows: int, kcat: int, zipf: bool, local_rank: int, steps: int, warmup: int, opts=(), cols=None,
+                 three_calls=False) -> dict:
+    """`steps` timed executions of one workload over columns resident in HBM (n1k_run_device_batch: reopen + scan + FinalGroup in
+    one call through the ABI).  Checks once, outside the timed region, that the groups are all there and that the Filter's
+    survivors equal an independent Filter-only count."""
+    import torch
+    import query_amd
+    wl = workloads()[workload]
+    own = cols is None
+    if own:
+        cols = DeviceColumns(rows, kcat, zipf, 0, rows, local_rank)
+    pj = query_amd.plan.filter_group_plan(wl["cond"], wl["keys"], wl["aggs"], order=wl.get("order"), limit=wl.get("limit"),
+                                          filter_only=bool(wl.get("filter_only")))
+    op = query_amd.GpuFilterGroup(pj, device=local_rank)
+    for o in opts:
+        k, v = o.split("=")
+        op.set_option(k, int(v))
+    op.intern(synth_dictionary(kcat))
+    batch = op.make_device_batch(rows, [cols.by_path[p] for p in op.column_paths])
+
+    def step():
+        if three_calls:
+            op.reopen()
+            op.process_device_batch(batch)
+            return op.after_items_raw()
+        return op.run_device_batch_raw(batch)
+
+    for _ in range(warmup):
+        res = step()
+    op.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    op.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = op.stats()  # (reopen zeroes the stats each step: these are the last query's)
+    ngroups = int(res["ngroups"])
+    if wl.get("filter_only"):
+        sel = res["selected"]
+        assert len(sel) == st["rows_selected"] and (len(sel) < 2 or bool((sel[1:] > sel[:-1]).all())), "ordinals not ascending"
+    # parity seams, outside the timed region: every group of the key domain is there (uniform keys at these sizes), and an
+    # independent kernel family (Filter-only: mask + compaction) counts the same survivors
+    checks = {}
+    if len(wl["keys"]) == 1 and not wl.get("limit") and not zipf and rows >= 1000 * kcat:
+        assert ngroups == kcat, "%s: %d groups, the key domain has %d" % (workload, ngroups, kcat)
+        checks["groups == K_cat"] = True
+    if wl["cond"] and not wl.get("filter_only"):
+        fo = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(wl["cond"], [], [], filter_only=True), device=local_rank)
+        fo.intern(synth_dictionary(kcat))
+        fb = fo.make_device_batch(rows, [cols.by_path[p] for p in fo.column_paths])
+        fo.reopen()
+        fo.process_device_batch(fb)
+        nsel = len(fo.after_items_raw()["selected"])
+        fo.done()
+        assert nsel == st["rows_selected"], "%s: the scan kept %d rows, the Filter-only kernels %d" % (workload, st["rows_selected"], nsel)
+        checks["rows_selected == Filter-only count"] = True
+    out = {"workload": workload, "sql": wl["sql"], "rows": rows, "k_cat": kcat, "zipf": bool(zipf), "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3, "value": rows * steps / elapsed, "unit": "rows/s", "groups": ngroups,
+           "rows_selected": st["rows_selected"], "agg_mode": st["agg_mode"], "spec_kernel": st["spec_kernel"],
+           "roofline": roofline_of(wl, rows, st, workload, kcat, opts), "checks": checks}
+    op.done()
+    if own:
+        del cols, batch
+        torch.cuda.empty_cache()
+    return out
+
+
+def by_rows(args, local_rank: int) -> dict:
     """north_star: rows/sec at 10 M / 100 M / 1 B rows.  The same query at the two other sizes on this GPU (columns resident
     in HBM, 1 B rows = 13 GB of config 2's columns): 10 untimed + 10 timed executions each.  Never the headline `value`."""
     import torch
-    import query_amd
     out = {}
     for label, n in (("10M", 10_000_000), ("1B", 1_000_000_000)):
         if n == args.rows:
@@ -278,25 +406,31 @@ def by_rows(args, wl, local_rank: int) -> dict:
         if n * 31 * 1.2 > free:  # (the generator fills all seven arrays: 31 B per row)
             out[label] = {"skipped": "not enough free HBM"}
             continue
-        cols = DeviceColumns(n, args.kcat, False, 0, n, local_rank)
-        pj = query_amd.plan.filter_group_plan(wl["cond"], wl["keys"], wl["aggs"], order=wl.get("order"), limit=wl.get("limit"))
-        op = query_amd.GpuFilterGroup(pj, device=local_rank)
-        op.intern(synth_dictionary(args.kcat))
-        batch = op.make_device_batch(n, [cols.by_path[p] for p in op.column_paths])
-        for _ in range(10):
-            op.run_device_batch_raw(batch)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            op.run_device_batch_raw(batch)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 10
-        st = op.stats()
-        out[label] = {"rows": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "rows/s",
-                      "kernel_ms": st["device_ms"], "achieved_GB/s": wl["bytes_per_row"] * n / (st["device_ms"] * 1e-3) / 1e9 if st["device_ms"] else None}
-        op.done()
-        del cols, batch
-        torch.cuda.empty_cache()
+        r = run_resident("config2", n, args.kcat, False, local_rank, 10, 10)
+        out[label] = {"rows": n, "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "rows/s", "query_ms": r["roofline"]["query_ms"],
+                      "frac": r["roofline"]["frac"], "batch_kernels_ms": r["roofline"]["kernel_split"]["batch kernels"]["ms"]}
+    return out
+
+
+def by_config(args, local_rank: int, cols) -> dict:
+    """BASELINE.json's other single-GPU query shapes at 100 M rows in the driver's own record: config 3 (COUNT(DISTINCT user_id)
+    + AVG(price) GROUP BY cat — the only 100 M-row single-GPU entry of `configs`) over the headline's resident columns, and
+    one shard of config 5 (GROUP BY cat, region_id ORDER BY SUM(price) DESC LIMIT 100, K_cat = 100 000: 6.4 M groups).  Whole
+    query wall time per step, whole-query roofline fraction, kernel split.  Never the headline `value`."""
+    out = {}
+    out["config3"] = run_resident("config3", args.rows, 1000, False, local_rank, 10, 3, cols=cols if args.kcat == 1000 else None)
+    out["config5"] = run_resident("config5", args.rows, 100_000, False, local_rank, 10, 3)
+    return out
+
+
+def zipf_record(args, local_rank: int) -> dict:
+    """Skew (cat ~ Zipf(s = 1.0)): config 2 at 100 M rows with Zipf keys over K = 1000 and K = 16 categories next to
+    uniform keys over K = 16 (K = 1000 uniform is the headline)."""
+    out = {}
+    for label, k, z in (("zipf_K1000", 1000, True), ("uniform_K16", 16, False), ("zipf_K16", 16, True)):
+        r = run_resident("config2", args.rows, k, z, local_rank, 10, 3)
+        out[label] = {"ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "rows/s", "query_ms": r["roofline"]["query_ms"],
+                      "frac": r["roofline"]["frac"], "batch_kernels_ms": r["roofline"]["kernel_split"]["batch kernels"]["ms"], "groups": r["groups"]}
     return out
 
 
@@ -429,51 +563,16 @@ def main():
     wl = workloads()[args.workload]
     total_rows = args.rows
     cols = DeviceColumns(args.rows, args.kcat, bool(args.zipf), 0, total_rows, local_rank)
-    pj = query_amd.plan.filter_group_plan(wl["cond"], wl["keys"], wl["aggs"], order=wl.get("order"), limit=wl.get("limit"))
-    op = query_amd.GpuFilterGroup(pj, device=local_rank)
-    for o in args.opt:
-        k, v = o.split("=")
-        op.set_option(k, int(v))
-    op.intern(synth_dictionary(args.kcat))
-    batch = op.make_device_batch(args.rows, [cols.by_path[p] for p in op.column_paths])
-
-    def step():
-        # n1k_run_device_batch = n1k_reset (groups dropped: one kernel, no host sync) + n1k_push_device_batch (scan + merge
-        # kernels, asynchronous) + n1k_finish (FinalGroup, groups on the host: the one sync) — one call through the ABI, as
-        # a compiled host would issue them back to back; --three-calls drives the three entry points from Python instead
-        if args.three_calls:
-            op.reopen()
-            op.process_device_batch(batch)
-            return op.after_items_raw()
-        return op.run_device_batch_raw(batch)
-
-    for _ in range(args.warmup):
-        rows = step()
-    op.sync()
-    torch.cuda.synchronize()
-    base = op.stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rows = step()
-    op.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    st = op.stats()
-    # reopen() zeroes the stats each step: the last step's numbers are one launch of the scan kernel
-    scan_ms = st["device_ms"]
-    ngroups = int(rows["ngroups"])
-    alg_bytes = wl["bytes_per_row"] * args.rows
-    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-
+    r = run_resident(args.workload, args.rows, args.kcat, bool(args.zipf), local_rank, args.steps, args.warmup, opts=args.opt, cols=cols,
+                     three_calls=args.three_calls)
     out = {
         "metric": METRIC,
-        "value": args.rows * args.steps / elapsed,
+        "value": r["value"],
         "unit": "rows/s",
         "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": r["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -481,47 +580,29 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s: %s @ %d rows, K_cat=%d%s, columns resident in HBM" %
                                (args.workload, wl["sql"], args.rows, args.kcat, " zipf" if args.zipf else ""),
-                   "rows_per_gpu": args.rows, "groups": ngroups, "rows_selected": st["rows_selected"],
-                   "agg_mode": st["agg_mode"]},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": kernel_label(st, wl),
-                     "kernel_ms": scan_ms,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                   "rows_per_gpu": args.rows, "groups": r["groups"], "rows_selected": r["rows_selected"],
+                   "agg_mode": r["agg_mode"], "spec_kernel": r["spec_kernel"], "checks": r["checks"]},
+        "roofline": r["roofline"],
     }
-    # HBM traffic of the dominant kernel from the committed PMC passes of this same command (rocprofv3 --pmc cannot run
-    # inside the timed process): FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950 counts a wide coalesced
-    # read at half its bytes), WRITE_SIZE is exact; both are KB per dispatch.  The figure belongs to the build the
-    # profile was taken from (tools/profile_round.sh; `traffic_source` names the file): re-profile after kernel changes.
-    pmc = os.path.join(ROOT, "profiles", "r02_bench_%s_100M_pmc_fetch_write.json" % args.workload)
-    if args.rows == 100_000_000 and args.kcat == (100_000 if args.workload.startswith("config5") else 1000) and os.path.exists(pmc) \
-            and not args.opt:
-        try:
-            with open(pmc) as fh:
-                c = json.load(fh)
-            k = [n for n in c["FETCH_SIZE"] if "scan_spec_" in n or "n1k_jit_wide" in n][0]
-            from query_amd import build as qbuild
-            if c.get("source_hash") in (None, qbuild.source_hash()):  # (None: profiles taken before the stamp existed)
-                out["roofline"]["traffic"] = 1024.0 * (2.0 * c["FETCH_SIZE"][k]["avg_KB"] + c["WRITE_SIZE"][k]["avg_KB"])
-                out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc) + " (%s, 2*FETCH_SIZE + WRITE_SIZE)" % k.split("<")[0].split("::")[-1]
-            else:
-                out["roofline"]["traffic_source"] = "none: profiles/%s belongs to other kernel sources (%s)" % (os.path.basename(pmc), c.get("source_hash"))
-        except Exception:
-            pass
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(wl, args.kcat, bool(args.zipf), total_rows,
                                            min(args.cpu_sample, args.rows))
     if not args.no_ingest and not args.zipf:
-        op.done()
         try:
             out.update(ingest_rates(args, wl, cols))
         except Exception as e:  # the sub-records never cost the headline line
             out["ingest_error"] = repr(e)[:300]
     if not args.no_sizes and args.workload == "config2" and not args.zipf and not args.opt:
-        try:
-            out["by_rows"] = by_rows(args, wl, local_rank)
-        except Exception as e:  # the sub-records never cost the headline line
-            out["by_rows"] = {"error": repr(e)[:300]}
+        keep = [cols]
+        for name, fn in (("by_config", lambda: by_config(args, local_rank, keep[0])), ("zipf", lambda: zipf_record(args, local_rank)),
+                         ("by_rows", lambda: by_rows(args, local_rank))):
+            if name == "by_rows":
+                cols = keep[0] = None  # (1 B rows need the room)
+                torch.cuda.empty_cache()
+            try:
+                out[name] = fn()
+            except Exception as e:  # the sub-records never cost the headline line
+                out[name] = {"error": repr(e)[:300]}
     print(json.dumps(out))
 
 

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define N1K_ABI_VERSION 2 /* 2: n1k_result.nproj / proj, projection and communicator entry points */
+#define N1K_ABI_VERSION 3 /* 2: n1k_result.nproj / proj, projection and communicator entry points; 3: n1k_stats.query_ms,
+                             N1K_REGION_FULL, n1k_partials_step, n1k_failure_is_global */
 
 /* ---------------------------------------------------------------- status -- */
 
@@ -160,6 +161,9 @@ typedef struct n1k_stats {
                                 pairs), bit 1 radix partition + LDS sets (one-word members), bit 2 global one-word set (fallback) */
     uint32_t reserved0;
     uint64_t topk_candidates; /* ORDER BY ... LIMIT: groups that left the device after the top-k filter (0 = filter not used) */
+    double query_ms;        /* hipEvent time of the last WHOLE query on the handle's stream: from n1k_reset (reopen) to the last
+                               kernel / copy of n1k_finish — every kernel of the query and the gaps between them; 0 until a
+                               finish has completed.  device_ms above covers the batches' kernels only. */
 } n1k_stats;
 
 typedef enum n1k_agg_mode {

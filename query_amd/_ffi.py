@@ -61,7 +61,7 @@ class Stats(C.Structure):
                 ("batches", C.c_uint64), ("device_ms", C.c_double), ("bytes_scanned", C.c_uint64),
                 ("agg_mode", C.c_uint32), ("spec_kernel", C.c_uint32),
                 ("wide_key_values", C.c_uint64), ("distinct_path", C.c_uint32), ("reserved0", C.c_uint32),
-                ("topk_candidates", C.c_uint64)]
+                ("topk_candidates", C.c_uint64), ("query_ms", C.c_double)]
 
 
 class SynthSpec(C.Structure):

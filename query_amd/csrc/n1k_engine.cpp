@@ -633,6 +633,10 @@ void n1k_destroy(n1k_handle* h) {
     }
 }
 static void destroy_handle(n1k_handle* h) {
+    if (h->host_us[5] > 0)
+        fprintf(stderr, "n1k host trace: %.0f one-call executions; per call: reset %.1f us, push %.1f us, finish %.1f us (of which waiting %.1f us, after the wait %.1f us)\n",
+                h->host_us[5], h->host_us[0] / h->host_us[5], h->host_us[1] / h->host_us[5], h->host_us[2] / h->host_us[5],
+                h->host_us[3] / h->host_us[5], h->host_us[4] / h->host_us[5]);
     if (h->having) n1k_destroy(h->having);
     h->having = nullptr;
     if (h->project) n1k_destroy(h->project);
@@ -642,6 +646,8 @@ static void destroy_handle(n1k_handle* h) {
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         drain_events(h);
         for (auto e : h->event_pool) (void)hipEventDestroy(e);
+        if (h->ev_q0) (void)hipEventDestroy(h->ev_q0);
+        if (h->ev_q1) (void)hipEventDestroy(h->ev_q1);
         h->d_rank.release();
         h->d_keys.release();
         h->d_acc.release();
@@ -731,6 +737,12 @@ n1k_status n1k_reset(n1k_handle* h) {
         h->groups_seen = 0;
         h->out_count_dirty = false;
         h->pending.count = 0;
+        if (!h->ev_q0) {
+            (void)hipEventCreate(&h->ev_q0);
+            (void)hipEventCreate(&h->ev_q1);
+        }
+        h->q1_recorded = false;
+        h->q0_recorded = h->ev_q0 && hipEventRecord(h->ev_q0, h->stream) == hipSuccess;  // the query starts here (stats.query_ms)
         if (h->device_clean) return N1K_OK;  // the last query's final kernel left the device as the launches below would
         h->device_clean = true;
         // one launch, no host synchronisation: table back to empty and all counters / error flags to zero
@@ -809,6 +821,7 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
     else if (n == "pinned_out") h->opt_pinned_out = value ? 1 : 0;
     else if (n == "lean_topk") h->opt_lean_topk = value ? 1 : 0;
+    else if (n == "filter_stream") h->opt_filter_stream = value ? 1 : 0;
     else if (n == "fused_tail") h->opt_fused_tail = value ? 1 : 0;
     else if (n == "merge_chunks") h->opt_merge_chunks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 16);
     else if (n == "inject_failure") h->opt_inject_failure = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
@@ -903,12 +916,23 @@ n1k_status n1k_push_device_batch(n1k_handle* h, const n1k_batch* batch) {
 
 n1k_status n1k_run_device_batch(n1k_handle* h, const n1k_batch* batch, n1k_result* out) {
     if (!h || !batch || !out) return N1K_INVALID;
+    static const bool trace = getenv("N1K_HOST_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = trace ? now() : 0;
     n1k_status st = n1k_reset(h);
+    const double t1 = trace ? now() : 0;
     if (st == N1K_OK) st = n1k_push_device_batch(h, batch);
+    const double t2 = trace ? now() : 0;
     if (st == N1K_OK) {
         h->clear_on_finish = true;  // the result leaves the device; the state behind it is the next execution's reset
         st = n1k_finish(h, out);
         h->clear_on_finish = false;
+    }
+    if (trace) {
+        h->host_us[0] += t1 - t0;
+        h->host_us[1] += t2 - t1;
+        h->host_us[2] += now() - t2;  // (finish in all; its wait is accounted inside)
+        h->host_us[5] += 1;
     }
     return st;
 }
@@ -1087,6 +1111,10 @@ n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
         if (pr.first) m->event_pool.push_back(pr.first);
         m->event_pool.push_back(pr.second);
         m->events.erase(m->events.begin());
+    }
+    if (m->q0_recorded && m->q1_recorded && hipEventQuery(m->ev_q1) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->ev_q0, m->ev_q1) == hipSuccess) m->stats.query_ms = ms;
     }
     *out = h->stats;
     return N1K_OK;

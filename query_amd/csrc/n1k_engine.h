@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -141,6 +142,7 @@ struct n1k_handle {
     // n1k_reset would, so the next execution starts with its scan — device_clean says that the device state is what a reset
     // produces (any push / merge / partition clears it), clear_on_finish asks n1k_finish for that last kernel
     bool device_clean = false, clear_on_finish = false;
+    uint32_t opt_filter_stream = 1; // Filter-only plans: the one-pass kernel (0: mask + scan + compaction, the ablation)
     uint32_t opt_fused_tail = 1;    // 0: finalize_kernel + publish_counters_kernel as separate launches (ablation)
     uint32_t opt_merge_chunks = 0;  // merge_slabs_kernel: block rows (0 = from the grid)
     bool out_count_dirty = true;  // the finalize position counter holds a previous finish's count
@@ -237,7 +239,12 @@ struct n1k_handle {
     std::vector<char> out_host;
     std::vector<char> export_blob;
 
+    // host-side timing of the one-call path (N1K_HOST_TRACE=1: printed at destroy): [0] reset [1] push (launches) [2] finish up to
+    // the wait [3] the wait [4] finish after the wait, in microseconds, and the number of calls
+    double host_us[6] = {0, 0, 0, 0, 0, 0};
     // stats
+    hipEvent_t ev_q0 = nullptr, ev_q1 = nullptr;  // the whole query on the stream: recorded by n1k_reset / before n1k_finish's last wait
+    bool q0_recorded = false, q1_recorded = false;
     n1k_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;

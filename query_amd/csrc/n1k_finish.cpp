@@ -5,6 +5,11 @@
 using namespace n1k;
 using namespace n1k_eng;
 
+// stats.query_ms: the last device work of the query is behind this point of the stream (the wait that follows completes it)
+static void mark_query_end(n1k_handle* h) {
+    if (h->q0_recorded && h->ev_q1 && hipEventRecord(h->ev_q1, h->stream) == hipSuccess) h->q1_recorded = true;
+}
+
 extern "C" {
 
 n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
@@ -13,6 +18,12 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     memset(out, 0, sizeof *out);
     h->failure_global = false;
     if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
+    std::chrono::steady_clock::time_point wait_end;
+    bool waited = false;
+    struct AfterWait {  // (host trace: what n1k_finish does behind its wait)
+        n1k_handle* h; const std::chrono::steady_clock::time_point* t; const bool* on;
+        ~AfterWait() { if (*on) h->host_us[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - *t).count(); }
+    } after_wait{h, &wait_end, &waited};
     const ParsedPlan& pl = h->plan;
     uint32_t nk = (uint32_t)pl.keys.size(), na = (uint32_t)pl.aggs.size();
     out->nkeys = nk;
@@ -71,10 +82,18 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
                 HIP_TRY(h, hipMemcpyAsync(h->pin_out + total, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
             }
             }
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            mark_query_end(h);
+            {
+                const auto w0 = std::chrono::steady_clock::now();
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                wait_end = std::chrono::steady_clock::now();
+                h->host_us[3] += std::chrono::duration<double, std::micro>(wait_end - w0).count();
+                waited = true;
+            }
             memcpy(counters, h->pin_out + total, sizeof counters);
         } else {
             HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+            mark_query_end(h);
             HIP_TRY(h, hipStreamSynchronize(h->stream));
         }
         err_flags = (uint32_t)counters[12];
@@ -214,6 +233,7 @@ redo_sets:
             HIP_TRY(h, hipMemcpyAsync(h->out_host.data(), src, copy_bytes, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
             if (sets_deferred) HIP_TRY(h, hipMemcpyAsync(veto, h->d_counters.p + 20, 8, hipMemcpyDeviceToHost, h->stream));
+            mark_query_end(h);
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             if (sets_deferred && (veto[0] | veto[1])) {
                 // a set or a bin overflowed on the optimistic path: no counts were added; once more, exactly

@@ -6,6 +6,7 @@
 
 namespace n1k {
 
+constexpr int kFilterStreamTile = 8192;  // rows per tile of the one-pass Filter-only kernel (4 passes of 256 threads x 8 rows)
 constexpr int kFilterTile = 4096;  // rows per tile of the Filter-only path (64 ballot words)
 
 struct OutValue {  // same 16-byte layout as n1k_value
@@ -126,6 +127,11 @@ hipError_t launch_tile_scan(const uint32_t* counts, uint64_t* offsets, uint64_t 
                             hipStream_t st);
 hipError_t launch_filter_compact(const uint64_t* mask_words, const uint64_t* tile_offsets, uint64_t nrows,
                                  uint64_t row_base, uint64_t* out_rows, uint32_t grid, hipStream_t st);
+// Filter alone in one pass: predicate + ordered compaction, tile offsets by a chained scan (tile_state: ntiles + 1 words, the
+// last one the tile counter; zeroed here)
+hipError_t launch_filter_stream(const Program& P, uint64_t nrows, uint64_t row_base, uint64_t* out_rows, unsigned long long* tile_state,
+                                unsigned long long* tile_counter, unsigned long long* total, uint32_t* err_flags, uint32_t grid,
+                                hipStream_t st);
 hipError_t launch_synth(const SynthArgs& a, hipStream_t st);
 
 }  // namespace n1k

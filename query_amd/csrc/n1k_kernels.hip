@@ -2387,6 +2387,125 @@ __global__ __launch_bounds__(BLOCK) void filter_mask_kernel(const Program P, uin
     if (unsupported) atomicOr(err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
 }
 
+// K2 in ONE pass (execution/filter.go:49-61: the rows whose condition is TRUE, in input order): predicate, survivor count and
+// ordered compaction of a tile by one workgroup, the tiles' output offsets by a chained scan with decoupled look-back — no
+// mask array, no single-workgroup scan between two kernels, no host round trip before the ordinals are written.
+//   * tiles (8192 rows) are handed out in order by one counter: a workgroup only ever waits for tiles that were handed out
+//     before its own;
+//   * tile t publishes ONE 64-bit word: [flag:2][count:62], flag 1 = the tile's own count (aggregate), 2 = the count of
+//     tiles 0..t (inclusive prefix).  The word is the whole message — relaxed agent-scope store / load, nothing to order;
+//   * wave 0 looks back 64 tiles at a time: it adds aggregates until it meets an inclusive prefix;
+//   * survivors leave in row order: lane-private ranks from ballots, per-(j, wave) counts in LDS.
+// Algorithmic traffic: the predicate's columns once + 8 B per survivor.
+constexpr unsigned long long kTileAgg = 1ull << 62, kTilePrefix = 2ull << 62, kTileValue = (1ull << 62) - 1ull;
+
+// A tile = SUB passes of BLOCK x R rows: the predicate runs pass by pass (R rows per thread in registers at a time), what it
+// leaves per pass is one bit per row and the per-(pass, j, wave) survivor counts in LDS; then ONE look-back for the tile and
+// the survivors' ordinals pass by pass.  (Tiles of 1024 rows with one ticket each were 97 k same-address atomics per 100 M
+// rows — at ~ 12 ns each they alone took 1.2 ms; several tiles per ticket serialise: a tile's aggregate must be out before
+// its workgroup looks back.)
+template <int R, int BLOCK, int SUB>
+__global__ __launch_bounds__(BLOCK) void filter_stream_kernel(const Program P, uint64_t nrows, uint64_t row_base, uint64_t* out_rows,
+                                                             unsigned long long* tile_state, unsigned long long* tile_counter,
+                                                             unsigned long long* total, uint32_t* err_flags) {
+    constexpr int NW = BLOCK / 64;
+    __shared__ uint32_t wcnt[SUB][R][NW];
+    __shared__ unsigned long long s_tile, s_prefix;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t pass_rows = (uint64_t)BLOCK * R, tile_rows = pass_rows * SUB, ntiles = (nrows + tile_rows - 1) / tile_rows;
+    uint32_t unsupported = 0;
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(tile_counter, 1ull);
+        __syncthreads();
+        const uint64_t tile = s_tile;
+        if (tile >= ntiles) break;  // (uniform: every thread reads the same LDS word)
+        uint32_t bits[SUB];  // this thread's rows of pass u that passed (bit j)
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+            uint64_t row[R];
+            bool valid[R], pass[R];
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                row[j] = tile * tile_rows + (uint64_t)u * pass_rows + (uint64_t)j * BLOCK + tid;
+                valid[j] = row[j] < nrows;
+            }
+            eval_predicate<R>(P, row, valid, pass, unsupported);
+            bits[u] = 0;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const unsigned long long m = __ballot(pass[j]);
+                if (pass[j]) bits[u] |= 1u << j;
+                if (lane == 0) wcnt[u][j][wave] = (uint32_t)__popcll(m);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // the tile's survivors: SUB x R x NW counts, summed by the wave
+            uint32_t c = 0;
+            for (uint32_t i = lane; i < (uint32_t)(SUB * R * NW); i += 64) c += (&wcnt[0][0][0])[i];
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+            const uint32_t block_total = __shfl(c, 0, 64);
+            unsigned long long excl = 0;
+            if (tile > 0) {
+                if (lane == 0) __hip_atomic_store(&tile_state[tile], kTileAgg | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int64_t hi = (int64_t)tile - 1; hi >= 0; hi -= 64) {  // the window hi, hi - 1, ... hi - 63
+                    const int64_t t = hi - (int64_t)lane;
+                    unsigned long long v = kTilePrefix;  // (in front of tile 0: an empty prefix)
+                    if (t >= 0) {
+                        do {
+                            v = __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } while ((v >> 62) == 0);  // handed out before this tile: it will publish
+                    }
+                    const unsigned long long pm = __ballot((v >> 62) == 2);
+                    const int stop = pm ? __ffsll((long long)pm) - 1 : 63;  // nearest tile with an inclusive prefix
+                    unsigned long long add = (int)lane <= stop ? (v & kTileValue) : 0ull;
+                    for (int off = 32; off > 0; off >>= 1) add += __shfl_down(add, off, 64);
+                    excl += __shfl(add, 0, 64);
+                    if (pm) break;
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&tile_state[tile], kTilePrefix | (excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = excl;
+                if (tile == ntiles - 1) *total = excl + block_total;
+            }
+        }
+        __syncthreads();
+        unsigned long long at = s_prefix;  // first output position of (pass u, j, wave 0)
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const bool p = (bits[u] >> j) & 1u;
+                uint32_t before = 0, all = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    if (w < (int)wave) before += wcnt[u][j][w];
+                    all += wcnt[u][j][w];
+                }
+                const unsigned long long m = __ballot(p);
+                if (p) out_rows[at + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] =
+                           row_base + tile * tile_rows + (uint64_t)u * pass_rows + (uint64_t)j * BLOCK + tid;
+                at += all;
+            }
+        }
+        __syncthreads();  // (wcnt / s_prefix / s_tile are written again by the next tile)
+    }
+    if (unsupported) atomicOr(err_flags, (uint32_t)ERR_UNSUPPORTED_VALUE);
+}
+
+hipError_t launch_filter_stream(const Program& P, uint64_t nrows, uint64_t row_base, uint64_t* out_rows, unsigned long long* tile_state,
+                                unsigned long long* tile_counter, unsigned long long* total, uint32_t* err_flags, uint32_t grid,
+                                hipStream_t st) {
+    const uint64_t ntiles = (nrows + kFilterStreamTile - 1) / kFilterStreamTile;
+    hipError_t e = hipMemsetAsync(tile_state, 0, (size_t)(ntiles + 1) * sizeof(unsigned long long), st);  // (+1: the tile counter behind it)
+    if (e != hipSuccess) return e;
+    static_assert(kFilterStreamTile == 256 * 8 * 4, "tile = 4 passes of 256 threads x 8 rows");
+    hipLaunchKernelGGL((filter_stream_kernel<8, 256, 4>), dim3(grid), dim3(256), 0, st, P, nrows, row_base, out_rows, tile_state, tile_counter,
+                       total, err_flags);
+    return hipGetLastError();
+}
+
 // exclusive scan of the tile counts (single workgroup, looping) -> tile offsets + total
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* counts, uint64_t* offsets, uint64_t ntiles,
                                                         unsigned long long* total) {

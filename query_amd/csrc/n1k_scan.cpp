@@ -484,19 +484,43 @@ interpreter:
 
 n1k_status run_filter_batch(n1k_handle* h, const n1k_batch* b) {
     Program& P = h->prog;
+    if (b->nrows == 0) return N1K_OK;
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    unsigned long long total = 0;
+    if (h->opt_filter_stream) {
+        // ONE pass (filter_stream_kernel): predicate, ordered compaction and the tiles' offsets by a chained scan; the ordinals
+        // land in a buffer sized for every row, the host reads the count and copies that many
+        const uint64_t ntiles = (b->nrows + kFilterStreamTile - 1) / kFilterStreamTile;
+        HIP_TRY(h, h->d_tile_off.ensure(ntiles + 1));
+        HIP_TRY(h, h->d_sel.ensure(b->nrows));
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)h->num_cus * 4);  // (124 VGPRs: four 256-thread workgroups per CU)
+        if (e0) (void)hipEventRecord(e0, h->stream);
+        HIP_TRY(h, launch_filter_stream(P, b->nrows, h->row_base, h->d_sel.p, (unsigned long long*)h->d_tile_off.p,
+                                        (unsigned long long*)h->d_tile_off.p + ntiles, h->d_counters.p + 3, h->d_errp, grid, h->stream));
+        if (e1) (void)hipEventRecord(e1, h->stream);  // device time excludes the PCIe copy of the ordinals
+        HIP_TRY(h, hipMemcpyAsync(&total, h->d_counters.p + 3, sizeof total, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (total) {
+            size_t old = h->selected.size();
+            h->selected.resize(old + total);
+            HIP_TRY(h, hipMemcpyAsync(h->selected.data() + old, h->d_sel.p, total * 8, hipMemcpyDeviceToHost, h->stream));
+        }
+        h->events.emplace_back(e0, e1);
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->stats.rows_selected += total;
+        return N1K_OK;
+    }
+    // three kernels (ablation, option filter_stream = 0): ballot mask + per-tile counts, single-workgroup scan, compaction
     uint64_t ntiles = (b->nrows + kFilterTile - 1) / kFilterTile;
-    if (ntiles == 0) return N1K_OK;
     HIP_TRY(h, h->d_mask.ensure(ntiles * (kFilterTile / 64)));
     HIP_TRY(h, h->d_tile_cnt.ensure(ntiles));
     HIP_TRY(h, h->d_tile_off.ensure(ntiles));
     uint64_t nchunks = (b->nrows + 1023) / 1024;
     uint32_t grid = (uint32_t)std::min<uint64_t>(nchunks, (uint64_t)h->num_cus * 8);
-    hipEvent_t e0 = get_event(h), e1 = get_event(h);
     if (e0) (void)hipEventRecord(e0, h->stream);
     HIP_TRY(h, hipMemsetAsync(h->d_tile_cnt.p, 0, ntiles * sizeof(uint32_t), h->stream));
     HIP_TRY(h, launch_filter_mask(P, b->nrows, h->d_mask.p, h->d_tile_cnt.p, h->d_errp, grid, h->stream));
     HIP_TRY(h, launch_tile_scan(h->d_tile_cnt.p, h->d_tile_off.p, ntiles, h->d_counters.p + 3, h->stream));
-    unsigned long long total = 0;
     HIP_TRY(h, hipMemcpyAsync(&total, h->d_counters.p + 3, sizeof total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (total) {

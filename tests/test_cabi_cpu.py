@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_ffi.LIB_PATH)
     for s in sorted(declared):
         assert hasattr(L, s), "libn1k.so does not export " + s
-    assert _ffi.lib().n1k_abi_version() == 2
+    assert _ffi.lib().n1k_abi_version() == 3
 
 
 def test_plan_json_binding_and_names():

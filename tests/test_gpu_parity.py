@@ -442,12 +442,27 @@ def test_run_device_batch_is_reset_push_finish():
     op.done()
 
 
-def test_filter_only_selected_rows():
+@pytest.mark.parametrize("stream", [1, 0], ids=["one-pass", "mask-scan-compact"])
+def test_filter_only_selected_rows(stream):
     t = n1o.synth_table(100_003, k_cat=10)
     for cond in ["(50 < %s)" % D("price"), "(%s is missing)" % D("price"), "(%s = \"cat_3\")" % D("cat")]:
         ora = n1o.run(t, cond, [], [], has_group=False)
-        gpu, stats = pu.run_gpu(t, cond, [], [], filter_only=True, batches=2)
+        gpu, stats = pu.run_gpu(t, cond, [], [], filter_only=True, batches=2, filter_stream=stream)
         assert np.array_equal(gpu.selected, ora.selected)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 8192, 8193, 600_001, 3_000_001])
+def test_one_pass_filter_ragged_sizes_and_selectivities(n):
+    """The one-pass Filter-only kernel (chained scan with decoupled look-back) against the oracle: no rows, one row, sizes
+    around a tile (1024 rows), more tiles than one look-back window (64), millions of rows (thousands of tiles in flight);
+    conditions nothing passes, everything passes, about half passes; one batch and three (ordinals continue across batches)."""
+    t = n1o.synth_table(n, k_cat=7)
+    for cond in ["(%s < -1)" % D("price"), "(%s is not missing)" % D("cat"), "(50 < %s)" % D("price")]:
+        ora = n1o.run(t, cond, [], [], has_group=False)
+        for batches in (1, 3):
+            gpu, stats = pu.run_gpu(t, cond, [], [], filter_only=True, batches=batches, device_resident=n > 100_000)
+            assert np.array_equal(gpu.selected, ora.selected), (cond, batches)
+            assert stats["rows_selected"] == len(ora.selected)
 
 
 def test_synth_generator_matches_cpu():

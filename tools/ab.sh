@@ -13,6 +13,6 @@ done
 for f in gpurun_out/ab_*.log; do echo $f; tail -1 $f | python3 -c "
 import sys,json
 try:
-    d=json.loads(sys.stdin.read()); print('  ms_per_step %.4f kernel_ms %.4f frac %.3f' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']))
+    d=json.loads(sys.stdin.read()); print('  ms_per_step %.4f query_ms %.4f frac %.3f' % (d['ms_per_step'], d['roofline'].get('query_ms', d['roofline'].get('kernel_ms', 0)), d['roofline']['frac']))
 except Exception as e: print('  ERR', e)
 "; done

@@ -15,7 +15,7 @@ fi
 if [ "$MODE" = "pmc" ] || [ "$MODE" = "all" ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-ingest --no-sizes "$@" > $OUT/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-ingest --no-sizes "$@" > $OUT/write.log 2>&1
-  python3 $ROOT/tools/summarise_pmc.py $OUT > $OUT/pmc_fetch_write.json
+  python3 $ROOT/tools/summarise_pmc.py $OUT 4 > $OUT/pmc_fetch_write.json
 fi
 if [ "$MODE" = "sq" ]; then
   # where the waves' cycles go (one pass: 8 SQ slots) — per kernel: wave-cycles parked / issue-stalled / active, instruction mix

@@ -6,6 +6,8 @@ import csv, glob, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 out = {}
+if len(sys.argv) > 2:
+    out["queries"] = int(sys.argv[2])  # executions of the query in each PMC pass (steps + warm-up): dispatches / queries = launches per query
 for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     acc = {}
     for f in glob.glob(os.path.join(root, d, "**", "*counter_collection.csv"), recursive=True):
