@@ -477,6 +477,11 @@ n1k_status ensure_table_groups(n1k_handle* h, uint64_t groups) {
     return N1K_OK;
 }
 
+n1k_status ensure_pinned_counters(n1k_handle* h) {
+    if (!h->pin_counters) HIP_TRY(h, hipHostMalloc((void**)&h->pin_counters, (kCounters + kPinScratch) * sizeof(unsigned long long), hipHostMallocDefault));
+    return N1K_OK;
+}
+
 hipEvent_t get_event(n1k_handle* h) {
     if (!h->event_pool.empty()) {
         hipEvent_t e = h->event_pool.back();
@@ -681,6 +686,7 @@ static void destroy_handle(n1k_handle* h) {
         h->d_wide_flt.release();
         if (h->pin_out) (void)hipHostFree(h->pin_out);
         if (h->pin_counters) (void)hipHostFree(h->pin_counters);
+        if (h->pin_rows) (void)hipHostFree(h->pin_rows);
         h->d_emit.release();
         h->d_rregion.release();
         h->d_rbins.release();
@@ -821,6 +827,7 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fuse_arith") h->opt_fuse_arith = value ? 1 : 0;
     else if (n == "pinned_out") h->opt_pinned_out = value ? 1 : 0;
     else if (n == "lean_topk") h->opt_lean_topk = value ? 1 : 0;
+    else if (n == "topk_sample") h->opt_topk_sample = value ? 1 : 0;
     else if (n == "filter_stream") h->opt_filter_stream = value ? 1 : 0;
     else if (n == "fused_tail") h->opt_fused_tail = value ? 1 : 0;
     else if (n == "merge_chunks") h->opt_merge_chunks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 16);
@@ -868,6 +875,9 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
         h->opt_partition_probe_rows = (uint64_t)std::max<int64_t>(value, 1);
     } else if (n == "partition_min_groups") {
         h->opt_partition_min_groups = (uint64_t)std::max<int64_t>(value, 1);
+    } else if (n == "partition_sticky") {
+        h->opt_partition_sticky = value ? 1 : 0;
+        h->sticky.valid = false;
     } else if (n == "partition_levels") {
         h->opt_partition_levels = (int32_t)std::min<int64_t>(std::max<int64_t>(value, -1), 2);
     } else if (n == "topk_min_groups") {

@@ -87,6 +87,7 @@ struct n1k_handle {
     uint32_t opt_block = 0, opt_rows_per_lane = 4, opt_fast = 1, opt_spec = 1, opt_wide = 1, opt_slabs = 1;
     uint32_t opt_jit = 1;                 // 0 off, 1 auto (large batches only), 2 always
     uint64_t opt_jit_min_rows = 4u << 20;
+    uint32_t opt_topk_sample = 1;  // ORDER BY ... LIMIT: threshold of the device top-k filter from a sample first (0: always the exact radix select)
     uint32_t opt_lean_topk = 1;    // ORDER BY ... LIMIT over a kept region: order values first, rows for the candidates only
     uint32_t opt_part_block = 256; // workgroup size of the run-time-built partition kernel (256 | 512; measured 0.43 vs 0.58 ms per 100 M rows)
     uint32_t opt_part_subs = 1;    // row exchange: sub-regions per destination with their own counters (0: one dense run)
@@ -113,6 +114,12 @@ struct n1k_handle {
     //  14.4 vs 9.8 ms: the LDS hash stage holds about a thousand groups, beyond that rows turn into global atomics)
     uint64_t opt_partition_min_rows = 8u << 20, opt_partition_probe_rows = 512u << 10, opt_partition_min_groups = 4096;
     int32_t opt_partition_levels = -1;
+    // A handle that has just run a batch of about this size through the partitioned path (groups estimated from a probe of its
+    // first rows) takes the next execution's batch the same way without probing again (a prepared statement executed again over
+    // the same keyspace): the path checks itself (fixed-capacity regions and bins raise flags: exact path), and a batch that
+    // would have been better off on the scan kernels is only slower, never wrong.  Forgotten when the path falls back.
+    struct { bool valid = false; uint64_t rows = 0, groups_est = 0; } sticky;
+    uint32_t opt_partition_sticky = 1;
     uint64_t groups_seen = 0;
     DevBuf<uint64_t> d_images;   // ORDER BY ... LIMIT: order images, candidate indices, select state, compacted records
     DevBuf<uint32_t> d_cand;
@@ -147,7 +154,10 @@ struct n1k_handle {
     uint32_t opt_merge_chunks = 0;  // merge_slabs_kernel: block rows (0 = from the grid)
     bool out_count_dirty = true;  // the finalize position counter holds a previous finish's count
     char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
-    unsigned long long* pin_counters = nullptr;  // pinned host copy of the device counters (one D2H per decision point)
+    unsigned long long* pin_counters = nullptr;  // pinned host copy of the device counters (one D2H per decision point): kCounters words,
+                                                 // then kPinScratch words for the small reads of n1k_finish (candidate count, flags)
+    char* pin_rows = nullptr;                    // pinned landing place of n1k_finish's sized output copy (pageable D2H copies are staged
+    size_t pin_rows_cap = 0;                     //  by the runtime: ~ 35 us per copy + wait where the pinned one takes ~ 10)
     size_t pin_cap = 0;
     std::string jit_log;
     int device = -1;
@@ -262,6 +272,7 @@ n1k_status fail(n1k_handle* h, n1k_status st, const char* fmt, ...);
                         hipGetErrorString(_e));                                                           \
     } while (0)
 
+constexpr uint32_t kPinScratch = 16;
 constexpr uint64_t kWordSubs = 256ull * kRecSubs;  // sub-regions of a DISTINCT aggregate's member words
 
 // n1k_engine.cpp: plan binding, device and table management
@@ -275,6 +286,7 @@ n1k_status fix_layout(n1k_handle* h, const n1k_batch* b);
 n1k_status ensure_table(n1k_handle* h, uint64_t incoming_rows);
 n1k_status ensure_table_groups(n1k_handle* h, uint64_t groups);
 hipEvent_t get_event(n1k_handle* h);
+n1k_status ensure_pinned_counters(n1k_handle* h);
 void drain_events(n1k_handle* h);
 n1k_status validate_batch(n1k_handle* h, const n1k_batch* b);
 uint64_t batch_bytes_per_row(const n1k_handle* h);

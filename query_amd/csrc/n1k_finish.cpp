@@ -38,6 +38,10 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
     uint64_t spec_groups = 0;
     if (h->device_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
+        {
+            n1k_status pst = ensure_pinned_counters(h);
+            if (pst != N1K_OK) return pst;
+        }
         const bool topk_forced = pl.has_order && pl.limit >= 0 && !pl.has_having && h->opt_topk_min_groups < 4096;  // tests
         // (a table of millions of slots is not worth scanning twice: the sized pass alone then)
         if (pl.has_group && !h->has_distinct && h->table.capacity && h->table.capacity <= (1u << 20) && !topk_forced && !h->pending.count) {
@@ -92,9 +96,10 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             }
             memcpy(counters, h->pin_out + total, sizeof counters);
         } else {
-            HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->pin_counters, h->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, h->stream));
             mark_query_end(h);
             HIP_TRY(h, hipStreamSynchronize(h->stream));
+            memcpy(counters, h->pin_counters, sizeof counters);
         }
         err_flags = (uint32_t)counters[12];
         drain_events(h);
@@ -200,17 +205,24 @@ redo_sets:
                 // ORDER BY ... LIMIT: only the groups that can be among the first offset+limit rows leave the device
                 const OrderTerm& t0 = pl.order[0];
                 HIP_TRY(h, h->d_images.ensure(ng));
-                HIP_TRY(h, h->d_cand.ensure(ng));
+                HIP_TRY(h, h->d_cand.ensure(topk_cand_entries(ng)));
                 HIP_TRY(h, h->d_topk.ensure(topk_state_bytes()));
                 n1k_status rst = ensure_rank(h);
                 if (rst != N1K_OK) return rst;
                 const OutValue* vals = lean || t0.key_index >= 0 ? (const OutValue*)d : (const OutValue*)(d + off_aggs);
-                HIP_TRY(h, launch_topk_select(h->prog, vals, lean ? 1u : (t0.key_index >= 0 ? nk : na),
-                                              lean ? 0u : (uint32_t)(t0.key_index >= 0 ? t0.key_index : t0.agg_index), ng, t0.desc, keep,
-                                              h->d_images.p, h->d_topk.p, h->d_cand.p, h->stream));
+                // the threshold from a sample of the groups first (one small kernel instead of eight histogram passes); exact
+                // whenever at least `keep` candidates come out, else the radix select over all images
+                const bool sampled = h->opt_topk_sample && topk_can_sample(ng, keep);
                 unsigned long long ncand = 0;
-                HIP_TRY(h, hipMemcpyAsync(&ncand, h->d_topk.p + topk_ncand_offset(), sizeof ncand, hipMemcpyDeviceToHost, h->stream));
-                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                for (int attempt = sampled ? 0 : 1; attempt < 2; attempt++) {
+                    HIP_TRY(h, launch_topk_select(h->prog, vals, lean ? 1u : (t0.key_index >= 0 ? nk : na),
+                                                  lean ? 0u : (uint32_t)(t0.key_index >= 0 ? t0.key_index : t0.agg_index), ng, t0.desc, keep,
+                                                  h->d_images.p, h->d_topk.p, h->d_cand.p, h->stream, attempt == 0, attempt == 1 && sampled));
+                    HIP_TRY(h, hipMemcpyAsync(h->pin_counters + kCounters, h->d_topk.p + topk_ncand_offset(), sizeof ncand, hipMemcpyDeviceToHost, h->stream));
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                    ncand = h->pin_counters[kCounters];
+                    if (ncand >= keep) break;
+                }
                 o_aggs = ncand * rec_keys;
                 o_parts = o_aggs + ncand * rec_aggs;
                 o_rep = o_parts + ncand * rec_parts;
@@ -228,20 +240,34 @@ redo_sets:
                 h->stats.topk_candidates = ncand;
                 ng = ncand;
             }
-            h->out_host.resize(copy_bytes);
             uint32_t veto[2] = {0, 0};
-            HIP_TRY(h, hipMemcpyAsync(h->out_host.data(), src, copy_bytes, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipMemcpyAsync(&err_flags, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
-            if (sets_deferred) HIP_TRY(h, hipMemcpyAsync(veto, h->d_counters.p + 20, 8, hipMemcpyDeviceToHost, h->stream));
+            // results up to a few MB land in pinned memory (grown on demand); larger ones — millions of groups without a LIMIT —
+            // in the pageable vector, whose copy the link's time dominates anyway
+            const bool pinned_rows = copy_bytes <= (8u << 20);
+            if (pinned_rows && h->pin_rows_cap < copy_bytes) {
+                if (h->pin_rows) (void)hipHostFree(h->pin_rows);
+                h->pin_rows = nullptr;
+                h->pin_rows_cap = 0;
+                const size_t want = std::max<size_t>(copy_bytes, 64u << 10);
+                HIP_TRY(h, hipHostMalloc((void**)&h->pin_rows, want, hipHostMallocDefault));
+                h->pin_rows_cap = want;
+            }
+            if (!pinned_rows) h->out_host.resize(copy_bytes);
+            char* const landing = pinned_rows ? h->pin_rows : h->out_host.data();
+            HIP_TRY(h, hipMemcpyAsync(landing, src, copy_bytes, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->pin_counters + kCounters + 1, h->d_errp, 4, hipMemcpyDeviceToHost, h->stream));
+            if (sets_deferred) HIP_TRY(h, hipMemcpyAsync(h->pin_counters + kCounters + 2, h->d_counters.p + 20, 8, hipMemcpyDeviceToHost, h->stream));
             mark_query_end(h);
             HIP_TRY(h, hipStreamSynchronize(h->stream));
+            memcpy(&err_flags, h->pin_counters + kCounters + 1, 4);
+            if (sets_deferred) memcpy(veto, h->pin_counters + kCounters + 2, 8);
             if (sets_deferred && (veto[0] | veto[1])) {
                 // a set or a bin overflowed on the optimistic path: no counts were added; once more, exactly
                 sets_exact = true;
                 ng = counters[1];
                 goto redo_sets;
             }
-            hp = h->out_host.data();
+            hp = landing;
         }
         h->r_keys.assign((const n1k_value*)hp, (const n1k_value*)hp + ng * nk);
         h->r_aggs.assign((const n1k_value*)(hp + o_aggs), (const n1k_value*)(hp + o_aggs) + ng * na);

@@ -63,7 +63,9 @@ hipError_t launch_agg_bins(const Program& P, const BinAggArgs& A, const GlobalTa
 size_t topk_state_bytes();
 size_t topk_ncand_offset();
 hipError_t launch_topk_select(const Program& P, const OutValue* vals, uint32_t stride, uint32_t index, uint64_t n, bool desc,
-                              uint64_t keep, uint64_t* images, void* state, uint32_t* cand, hipStream_t st);
+                              uint64_t keep, uint64_t* images, void* state, uint32_t* cand, hipStream_t st, bool sampled = false, bool images_done = false);
+bool topk_can_sample(uint64_t n, uint64_t keep);
+uint64_t topk_cand_entries(uint64_t n);  // entries of the candidate buffer launch_topk_select needs for n groups  // enough groups for the sampled threshold (else the exact radix select)
 hipError_t launch_topk_compact(const uint32_t* cand, uint64_t ncand, uint32_t nk, uint32_t na, const OutValue* keys,
                                const OutValue* aggs, const OutPartial* parts, const uint64_t* rep, OutValue* okeys, OutValue* oaggs,
                                OutPartial* oparts, uint64_t* orep, hipStream_t st);

@@ -2251,11 +2251,13 @@ N1K_DEV uint64_t order_image(const Program& P, uint64_t tag, uint64_t p, bool de
     return desc ? ~img : img;
 }
 
+constexpr uint32_t kTopkSegs = 256;  // candidate lists of the sampled path (one counter each: thousands of candidates on ONE counter serialise)
 struct TopkState {
     unsigned long long prefix;     // digits of T fixed so far (high to low)
     unsigned long long remaining;  // rank of T among the images that share the prefix (1-based)
     unsigned long long hist[256];
     unsigned long long ncand;
+    unsigned long long seg_count[kTopkSegs * 16];  // sampled path: candidates per segment, 128 B apart
 };
 
 __global__ void topk_images_kernel(const Program P, const OutValue* vals, uint32_t stride, uint32_t index, uint64_t n, uint32_t desc,
@@ -2267,6 +2269,12 @@ __global__ void topk_images_kernel(const Program P, const OutValue* vals, uint32
         st->ncand = 0;
     }
     if (i < n) images[i] = order_image(P, vals[i * stride + index].tag, vals[i * stride + index].payload, desc != 0);
+}
+
+__global__ void topk_state_kernel(TopkState* st, uint64_t keep) {
+    st->prefix = 0;
+    st->remaining = keep;
+    st->ncand = 0;
 }
 
 // pass d (0 = top byte): histogram of byte d over the images that share the prefix of the bytes above it
@@ -2329,6 +2337,183 @@ __global__ void topk_pick_kernel(uint32_t pass, TopkState* st) {
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) st->hist[lane * 4 + k] = 0;
+}
+
+// ORDER BY ... LIMIT over millions of groups, the cheap way to the threshold.  Three small kernels instead of eight
+// (histogram + pick) passes over all images (0.2 ms per 6.4 M groups):
+//   1. topk_sample_kernel: the images of a SAMPLE of the groups (one workgroup, kTopkSample images in LDS), the r-th smallest
+//      of them by a radix select inside LDS = a first threshold T'; r is chosen so that about 2 x keep + 16 n / kTopkSample
+//      groups are expected at or below T';
+//   2. topk_gather_seg_kernel: the groups with image <= T' into kTopkSegs lists (segment = workgroup number mod kTopkSegs, its
+//      own counter: thousands of candidates on ONE counter serialise at ~ 12 ns each);
+//   3. topk_refine_kernel: the lists packed into cand[]; when at least `keep` and at most kTopkSample groups came through, the
+//      EXACT threshold T = the keep-th smallest image among them (the same radix select, in LDS) and only the groups with
+//      image <= T stay — the candidate set of the exact path: the first `keep` rows of the order and every tie on the first term.
+// Fewer than `keep` candidates (the sample was unlucky: T' < T): the host sees it in ncand and runs the exact radix select.
+constexpr uint32_t kTopkSample = 16384;
+
+// the rank-th smallest (1-based) of the n <= kTopkSample images in LDS; all 1024 threads of the workgroup call it.  Lanes of a
+// wave that count the same bin add once (early passes put every image in one bin: 16 k same-address LDS atomics were 27 us).
+N1K_DEV uint64_t lds_radix_select(const uint64_t* smp, uint32_t n, unsigned long long rank, uint32_t* h, unsigned long long* s_prefix,
+                                  unsigned long long* s_rem) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) {
+        *s_prefix = 0;
+        *s_rem = rank;
+    }
+    __syncthreads();
+    for (uint32_t pass = 0; pass < 8; pass++) {
+        const uint32_t shift = 56 - 8 * pass;
+        if (tid < 256) h[tid] = 0;
+        __syncthreads();
+        const unsigned long long prefix = *s_prefix;
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+            const uint32_t i = i0 + tid;
+            const uint64_t x = i < n ? smp[i] : 0;
+            const bool in = i < n && (pass == 0 || (x >> (shift + 8)) == (prefix >> (shift + 8)));
+            const uint32_t bin = (uint32_t)(x >> shift) & 255u;
+            unsigned long long todo = __ballot(in);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t lb = (uint32_t)__shfl((int)bin, leader, 64);
+                const unsigned long long same = __ballot(in && bin == lb) & todo;
+                if ((int)lane == leader) atomicAdd(&h[lb], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {  // one wave: lane l owns bins 4l .. 4l + 3 (as topk_pick_kernel)
+            const unsigned long long rem = *s_rem;
+            unsigned long long c[4], mine = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c[k] = h[tid * 4 + k];
+                mine += c[k];
+            }
+            unsigned long long incl = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long t = __shfl_up(incl, off, 64);
+                if ((int)tid >= off) incl += t;
+            }
+            unsigned long long run = incl - mine, before = 0;
+            uint32_t d = 256;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (d == 256 && run + c[k] >= rem) {
+                    d = tid * 4 + k;
+                    before = run;
+                }
+                run += c[k];
+            }
+            const unsigned long long found = __ballot(d != 256);
+            const int src = found ? __ffsll((long long)found) - 1 : 63;
+            uint32_t dd = (uint32_t)__shfl((int)d, src, 64);
+            unsigned long long bb = __shfl(before, src, 64);
+            if (!found) {
+                dd = 255;
+                bb = __shfl(incl, 63, 64);
+            }
+            if (tid == 0) {
+                *s_prefix = prefix | ((unsigned long long)dd << shift);
+                *s_rem = rem - bb;
+            }
+        }
+        __syncthreads();
+    }
+    return *s_prefix;
+}
+
+__global__ __launch_bounds__(1024) void topk_sample_kernel(const uint64_t* images, uint64_t n, uint32_t rank, TopkState* st) {
+    extern __shared__ uint64_t smp[];  // kTopkSample images
+    __shared__ uint32_t h[256];
+    __shared__ unsigned long long s_prefix, s_rem;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t stride = (uint32_t)(n / kTopkSample);  // (the caller made sure that 4 * kTopkSample <= n < 2^32)
+#pragma unroll 4
+    for (uint32_t i = tid; i < kTopkSample; i += 1024) {
+        const uint32_t off = (uint32_t)mix64(0x5EEDull + i) % stride;  // one image out of every `stride`, at a scattered place
+        smp[i] = images[(uint64_t)i * stride + off];
+    }
+    __syncthreads();
+    const uint64_t t = lds_radix_select(smp, kTopkSample, rank, h, &s_prefix, &s_rem);
+    if (tid == 0) {
+        st->prefix = t;
+        st->ncand = 0;
+    }
+}
+
+__global__ void topk_gather_seg_kernel(const uint64_t* images, uint64_t n, TopkState* st, uint32_t* seg_lists, uint64_t seg_cap) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (images[i] <= st->prefix) {
+        const uint32_t sg = blockIdx.x % kTopkSegs;
+        const unsigned long long at = atomicAdd(&st->seg_count[sg * 16], 1ull);
+        if (at < seg_cap) seg_lists[(size_t)sg * seg_cap + at] = (uint32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_refine_kernel(const uint64_t* images, TopkState* st, const uint32_t* seg_lists, uint64_t seg_cap,
+                                                          uint32_t* cand, uint64_t keep) {
+    extern __shared__ uint64_t smp[];  // up to kTopkSample candidate images
+    __shared__ uint32_t h[256];
+    __shared__ unsigned long long s_prefix, s_rem;
+    __shared__ uint32_t off[kTopkSegs + 1], kept;
+    const uint32_t tid = threadIdx.x;
+    // the lists' lengths -> offsets (one wave, four segments per lane)
+    if (tid < 64) {
+        uint32_t c[4], mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long x = st->seg_count[(tid * 4 + k) * 16];
+            c[k] = (uint32_t)(x < seg_cap ? x : seg_cap);
+            mine += c[k];
+        }
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if ((int)tid >= o) incl += t;
+        }
+        uint32_t run = incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            off[tid * 4 + k] = run;
+            run += c[k];
+        }
+        if (tid == 63) off[kTopkSegs] = run;
+    }
+    if (tid == 0) kept = 0;
+    __syncthreads();
+    const uint32_t M = off[kTopkSegs];
+    const bool refine = M >= keep && M <= kTopkSample;
+    // pack: four threads per segment
+    for (uint32_t sg = tid >> 2; sg < kTopkSegs; sg += 256) {
+        const uint32_t c = off[sg + 1] - off[sg];
+        for (uint32_t j = tid & 3u; j < c; j += 4) {
+            const uint32_t g = seg_lists[(size_t)sg * seg_cap + j];
+            cand[off[sg] + j] = g;
+            if (refine) smp[off[sg] + j] = images[g];
+        }
+    }
+    __syncthreads();
+    if (!refine) {
+        if (tid == 0) st->ncand = M;
+        return;
+    }
+    __syncthreads();
+    const uint64_t t = lds_radix_select(smp, M, keep, h, &s_prefix, &s_rem);
+    // the groups at or below the exact threshold stay (cand is rewritten front to back: reads of a round precede its writes)
+    for (uint32_t i0 = 0; i0 < M; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        const bool keepit = i < M && smp[i] <= t;
+        const uint32_t g = i < M ? cand[i] : 0u;
+        __syncthreads();
+        if (keepit) cand[atomicAdd(&kept, 1u)] = g;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        st->prefix = t;
+        st->ncand = kept;
+    }
 }
 
 __global__ void topk_gather_kernel(const uint64_t* images, uint64_t n, TopkState* st, uint32_t* cand) {
@@ -2744,12 +2929,35 @@ hipError_t launch_agg_bins(const Program& P, const BinAggArgs& A, const GlobalTa
 
 size_t topk_state_bytes() { return sizeof(TopkState); }
 
+uint64_t topk_cand_entries(uint64_t n) { return n + (uint64_t)kTopkSegs * (n / kTopkSegs + 320); }  // the candidates + the segment lists
+bool topk_can_sample(uint64_t n, uint64_t keep) { return n >= 4ull * kTopkSample && n < (1ull << 32) && keep * 2 * kTopkSample / n + 16 <= kTopkSample / 4; }
+
+// sampled = true: the threshold from a sample (the caller checks that at least `keep` candidates came out, and calls again
+// with sampled = false — the images are in place: images_done — when they did not)
 hipError_t launch_topk_select(const Program& P, const OutValue* vals, uint32_t stride, uint32_t index, uint64_t n, bool desc,
-                              uint64_t keep, uint64_t* images, void* state, uint32_t* cand, hipStream_t st) {
+                              uint64_t keep, uint64_t* images, void* state, uint32_t* cand, hipStream_t st, bool sampled,
+                              bool images_done) {
     TopkState* S = (TopkState*)state;
     (void)hipMemsetAsync(S, 0, sizeof(TopkState), st);
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(topk_images_kernel, dim3(blocks), dim3(256), 0, st, P, vals, stride, index, n, desc ? 1u : 0u, images, S, keep);
+    if (!images_done)
+        hipLaunchKernelGGL(topk_images_kernel, dim3(blocks), dim3(256), 0, st, P, vals, stride, index, n, desc ? 1u : 0u, images, S, keep);
+    else
+        hipLaunchKernelGGL(topk_state_kernel, dim3(1), dim3(1), 0, st, S, keep);
+    if (sampled) {
+        const uint32_t rank = (uint32_t)(keep * 2 * kTopkSample / n) + 16;  // ~ 2 keep + 16 n / kTopkSample groups expected below it
+        auto k = topk_sample_kernel;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTopkSample * 8));
+        hipLaunchKernelGGL(k, dim3(1), dim3(1024), kTopkSample * 8, st, images, n, rank, S);
+        // (the segment lists live behind the n entries of `cand`: the caller sized it with topk_cand_entries)
+        const uint64_t seg_cap = n / kTopkSegs + 320;  // every image of a segment's workgroups fits
+        uint32_t* seg_lists = cand + n;
+        hipLaunchKernelGGL(topk_gather_seg_kernel, dim3(blocks), dim3(256), 0, st, images, n, S, seg_lists, seg_cap);
+        auto kr = topk_refine_kernel;
+        (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTopkSample * 8));
+        hipLaunchKernelGGL(kr, dim3(1), dim3(1024), kTopkSample * 8, st, images, S, seg_lists, seg_cap, cand, keep);
+        return hipGetLastError();
+    }
     const uint32_t hb = (uint32_t)std::min<uint64_t>(blocks, 1024);
     for (uint32_t pass = 0; pass < 8; pass++) {
         hipLaunchKernelGGL(topk_hist_kernel, dim3(hb), dim3(256), 0, st, images, n, pass, S);

@@ -329,7 +329,10 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
         HIP_TRY(h, launch_agg_bins16(P, B, bgrid, block, h->opt_rec_unroll ? h->opt_rec_unroll : (uint32_t)std::min<uint64_t>(per_thread, 4), h->stream));
     }
     // one copy of the counters into pinned memory (the region's group count joins them first): one host round trip
-    if (!h->pin_counters) HIP_TRY(h, hipHostMalloc((void**)&h->pin_counters, kCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    {
+        n1k_status pst = ensure_pinned_counters(h);
+        if (pst != N1K_OK) return pst;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_counters.p + 26, h->d_emit.p, 8, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->pin_counters, h->d_counters.p, kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -666,6 +666,11 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
     if (st != N1K_OK) return st;
     bool partition = can_partition && head == 0 && b->nrows > 0;
     uint64_t groups_est = b->nrows;
+    if (decide && first_rows && h->opt_partition_sticky && h->sticky.valid && b->nrows >= h->sticky.rows / 2 && b->nrows <= h->sticky.rows * 2) {
+        decide = false;  // as the last execution over a batch of this size went: no probe (see n1k_handle::sticky)
+        partition = true;
+        groups_est = std::min<uint64_t>(b->nrows, h->sticky.groups_est * b->nrows / std::max<uint64_t>(h->sticky.rows, 1) + 1024);
+    }
     if (decide) {
         // probe: Filter + group key of the first `head` rows into the table (keys only), counted before and after
         st = ensure_table(h, head);
@@ -704,6 +709,9 @@ n1k_status push_device(n1k_handle* h, const n1k_batch* b) {
         else if (partition) {
             bool done = false;
             st = run_group_records(h, &v, pp, groups_est, first_rows, &done);
+            h->sticky.valid = st == N1K_OK && done && first_rows && h->opt_agg_mode == N1K_MODE_AUTO;
+            h->sticky.rows = b->nrows;
+            h->sticky.groups_est = groups_est;
             if (st == N1K_OK && !done) st = run_group_partitioned(h, &v, pp, groups_est, first_rows);
         } else
             st = run_group_batch(h, &v);

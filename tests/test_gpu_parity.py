@@ -912,6 +912,25 @@ def test_topk_over_the_partitioned_paths_kept_region(order, limit, offset, lean)
     assert stats["agg_mode"] == 4 and 0 < stats["topk_candidates"] < len(ora.keys)
 
 
+@pytest.mark.parametrize("sample", [1, 0], ids=["sampled-threshold", "radix-select"])
+@pytest.mark.parametrize("order,limit,offset", [
+    ([("sum(%s)" % D("price"), True)], 100, None),               # config 5's tail
+    ([("count(*)", True), (D("cat"), False)], 40, 5),             # few distinct first-term values: a flood of ties below any threshold
+    ([("sum(%s)" % D("price"), False), (D("cat"), True)], 2000, 0),  # a limit the sample's rank has to follow
+])
+def test_topk_threshold_from_a_sample(order, limit, offset, sample):
+    """Hundreds of thousands of groups: the device top-k filter takes its threshold from a sample of the groups' order images
+    (topk_sample_kernel) and the host checks that at least offset + limit candidates came out (else the exact radix select
+    runs); either way the rows are the oracle's, in the reference's order — against the exact radix select as well."""
+    t = n1o.synth_table(400_000, k_cat=50_000)
+    keys, aggs = [D("cat"), D("region_id")], sorted(["sum(%s)" % D("price"), "count(*)"])
+    ora = n1o.run(t, None, keys, aggs, threads=4)
+    assert len(ora.keys) > 4 * 16384  # (enough groups for the sampled path)
+    gpu, stats = pu.run_gpu(t, None, keys, aggs, order=order, limit=limit, offset=offset, topk_sample=sample, device_resident=True)
+    pu.assert_ordered_groups(gpu, ora, keys, aggs, order, limit, offset)
+    assert (limit + (offset or 0)) <= stats["topk_candidates"] < len(ora.keys)
+
+
 PART_AGGS = sorted(["sum(%s)" % D("price"), "count(*)", "min(%s)" % D("price"), "avg(%s)" % D("price"),
                     "max(%s)" % D("region_id"), "countn(%s)" % D("price")])
 
