@@ -1327,6 +1327,16 @@ static void group_key(node *const *keys, uint32_t nkeys, uint64_t row, ectx *cx,
         case TY_NULL: sb_put(b, "n", 1); break;
         case TY_BOOLEAN: sb_put(b, k.b ? "t" : "f", 1); break;
         case TY_NUMBER: {
+            if (k.isf && (isnan(k.f) || isinf(k.f))) {
+                /* value/float.go:31-48: NaN / +Inf / -Inf marshal as the JSON STRINGS "NaN" / "+Infinity" / "-Infinity": such a
+                 * key is the same map key as that string */
+                const char *t = isnan(k.f) ? "NaN" : (k.f > 0 ? "+Infinity" : "-Infinity");
+                uint32_t l = (uint32_t)strlen(t);
+                sb_put(b, "s", 1);
+                sb_put(b, &l, 4);
+                sb_put(b, t, l);
+                break;
+            }
             sb_put(b, "#", 1);
             if (k.isf) format_float_f(k.f, b);
             else {

@@ -370,6 +370,29 @@ N1K_DEV bool wide_code(uint64_t* tab, uint32_t bits, unsigned long long* count, 
     return false;
 }
 
+// The INT whose decimal text is strconv.FormatFloat(d, 'f', -1, 64) for an integral |d| in [2^53, 2^63): the shortest run of
+// significant digits that parses back to d, then zeros (value/float.go:31-48 writes group keys with it, so the float and that
+// INT are one group).  false: the text does not fit an int64 (the float then keeps a key of its own).
+N1K_DEV bool float_key_text_int(double d, int64_t& out) {
+    const double a = d < 0 ? -d : d;
+    if (!(a >= 9007199254740992.0 && a < 9223372036854775808.0)) return false;
+    const unsigned long long v = (unsigned long long)a;  // exact: an integer below 2^63
+    int n = 1;
+    for (unsigned long long t = v; t >= 10ull; t /= 10ull) n++;  // 16 .. 19 digits
+    for (int p = 1; p <= 17 && p <= n; p++) {
+        unsigned long long scale = 1;
+        for (int i = 0; i < n - p; i++) scale *= 10ull;
+        const unsigned long long lo = v / scale * scale, hi = lo + scale;  // the two p-digit decimals around v
+        const bool rlo = (double)lo == a, rhi = (double)hi == a;
+        if (!rlo && !rhi) continue;
+        const unsigned long long c = rlo && rhi ? (v - lo <= hi - v ? lo : hi) : (rlo ? lo : hi);
+        if (c > 9223372036854775807ull) return false;
+        out = d < 0 ? -(int64_t)c : (int64_t)c;
+        return true;
+    }
+    return false;
+}
+
 // field classes of a TAGGED key: 0 MISSING 1 NULL 2 FALSE 3 TRUE 4 INT (zigzag in the field) 5 STRING 6 ARRAY
 // 7 OBJECT (dictionary code) 8 wide INT 9 FLOAT (code of the value table).  `canon` is a handle-independent
 // image of the field (what the multi-GPU row exchange hashes).
@@ -397,10 +420,21 @@ N1K_DEV bool pack_key_field(const Program& P, const KeySpec& k, uint32_t tag, ui
             double d = as_f64(p);
             // 5.0 and 5 are one group: both print "5" (value/float.go:31-48).  From 2^53 up FormatFloat's shortest
             // digits are no longer the integer's own ("-9223372036854776000" for -2^63), so such floats stay floats.
+            int64_t shortest;
             if (is_int_f64(d) && d > -9007199254740992.0 && d < 9007199254740992.0) {
                 cls = 4;
                 num = true;
                 iv = go_f2i(d);
+            } else if (is_int_f64(d) && float_key_text_int(d, shortest)) {
+                // From 2^53 up the key's text is FormatFloat's SHORTEST digits followed by zeros — float 2^60 prints
+                // "1152921504606847000" — and that text is the map key: the float groups with the INT of that text.
+                cls = 4;
+                num = true;
+                iv = shortest;
+            } else if (d != d || d == __longlong_as_double(0x7FF0000000000000ll) || d == __longlong_as_double((long long)0xFFF0000000000000ull)) {
+                // NaN / +Inf / -Inf marshal as JSON STRINGS (value/float.go:31-48): one group with the string of that text
+                cls = 5;
+                sub = d != d ? P.nan_code : (d > 0 ? P.pinf_code : P.ninf_code);
             } else {
                 cls = 9;
                 uint64_t bits = d != d ? 0x7FF8000000000000ull : p;  // one NaN

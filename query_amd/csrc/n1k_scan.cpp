@@ -563,6 +563,13 @@ n1k_status bind_columns(n1k_handle* h, const n1k_batch* b, bool defer) {
         P.cols[c].payload = b->cols[c].payload;
         P.cols[c].codes = b->cols[c].codes;
     }
+    bool tagged_key = false;
+    for (uint32_t k = 0; k < P.nkeys; k++) tagged_key |= P.keys[k].mode == KEYM_TAGGED;  // (fix_layout came first)
+    if (tagged_key) {  // FLOAT group keys that are NaN / +-Inf are the strings they marshal to (n1k_device.h pack_key_field)
+        P.nan_code = intern(h, "NaN");
+        P.pinf_code = intern(h, "+Infinity");
+        P.ninf_code = intern(h, "-Infinity");
+    }
     P.dict_size = (uint32_t)h->dict.size();
     P.empty_str_code = lookup_code(h, "");
     P.empty_arr_code = lookup_code(h, "[]");

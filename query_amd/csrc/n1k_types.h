@@ -177,6 +177,7 @@ struct Program {
                                // matches the logged operands to the groups by it)
     uint32_t lds_words;     // words per LDS slot (key + accumulators)
     uint32_t glob_words;    // words per global row (accumulators only)
+    uint32_t nan_code, pinf_code, ninf_code;  // dictionary codes of "NaN" / "+Infinity" / "-Infinity": what such FLOAT group keys marshal to
     uint32_t want_rep_row;  // keep min row ordinal per group
     uint32_t rep_lds_word;  // LDS word of the rep row (when wanted)
     uint32_t dict_size;

@@ -110,10 +110,16 @@ def _canon_key(k):
     (both print "5"; from 2^53 up the float's shortest digits differ from the integer's and the keys stay apart)."""
     out = []
     for tag, v in k:
-        if tag == n1o.T_FLOAT and not math.isnan(v) and not math.isinf(v) and v == int(v) and abs(v) < 2.0 ** 53:
-            tag, v = n1o.T_INT, int(v)
-        elif tag == n1o.T_FLOAT and math.isnan(v):
-            v = "NaN"
+        if tag == n1o.T_FLOAT and (math.isnan(v) or math.isinf(v)):
+            # NaN / +-Inf marshal as JSON strings (value/float.go:31-48): the group of that string
+            tag, v = n1o.T_STRING, (b"NaN" if math.isnan(v) else (b"+Infinity" if v > 0 else b"-Infinity"))
+        elif tag == n1o.T_FLOAT and v == int(v):
+            # the key's text is FormatFloat(f, 'f', -1): an integral float IS the int of that text — its own value below 2^53,
+            # its shortest digits followed by zeros above (2^60 prints 1152921504606847000) — while the text fits an int64
+            import decimal
+            as_int = int(decimal.Decimal(repr(v)))
+            if -2 ** 63 <= as_int < 2 ** 63:
+                tag, v = n1o.T_INT, as_int
         out.append((tag, v))
     return tuple(out)
 

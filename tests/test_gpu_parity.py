@@ -610,6 +610,37 @@ def test_wide_key_values_group_like_the_reference(keys, opts):
     assert stats["wide_key_values"] >= 5000
 
 
+@pytest.mark.parametrize("opts", [{}, {"fast": 0, "spec": 0}, {"jit": 2}, {"agg_mode": 4}], ids=["auto", "interp", "jit", "partitioned"])
+def test_group_keys_are_their_json_text(opts):
+    """execution/group_util.go:18-35 groups on the MARSHALLED key (value/float.go:31-48), with two consequences only computed or
+    column-fed floats can reach: an integral float from 2^53 up prints its shortest digits followed by zeros — float 2^60 is
+    "1152921504606847000" — and is one group with the INT of that text; NaN / +Inf / -Inf print as the JSON strings "NaN" /
+    "+Infinity" / "-Infinity" and are one group with those strings.  Floats beyond int64 and ordinary floats keep their own."""
+    f60 = float(2 ** 60)
+    rows = [(n1o.T_FLOAT, f60), (n1o.T_INT, 1152921504606847000), (n1o.T_INT, 2 ** 60),      # two groups: the text, and the exact int
+            (n1o.T_FLOAT, -float(2 ** 62)), (n1o.T_INT, -4611686018427388000),                 # one group
+            (n1o.T_FLOAT, float(2 ** 53)), (n1o.T_INT, 2 ** 53), (n1o.T_INT, 2 ** 53 + 1),    # 9007199254740992: float and int alike
+            (n1o.T_FLOAT, float("nan")), (n1o.T_STRING, b"NaN"), (n1o.T_FLOAT, float("inf")), (n1o.T_STRING, b"+Infinity"),
+            (n1o.T_FLOAT, float("-inf")), (n1o.T_STRING, b"-Infinity"), (n1o.T_STRING, b"Infinity"),
+            (n1o.T_FLOAT, float(2 ** 63)), (n1o.T_FLOAT, 1e300), (n1o.T_FLOAT, 2.5), (n1o.T_FLOAT, 7.0), (n1o.T_INT, 7)]
+    rows = rows * 3
+    dictionary = [b"NaN", b"+Infinity", b"-Infinity", b"Infinity"]
+    n = len(rows)
+    tags = np.array([t for t, _ in rows], np.uint8)
+    pay = np.zeros(n, np.uint64)
+    for i, (t, v) in enumerate(rows):
+        pay[i] = (np.int64(v).view(np.uint64) if t == n1o.T_INT else np.float64(v).view(np.uint64) if t == n1o.T_FLOAT
+                  else np.uint64(dictionary.index(v)))
+    vals = np.arange(n, dtype=np.int64)
+    t = n1o.Table([n1o.Column(D("k"), n1o.COL_TAGGED64, tags=tags, payload=pay),
+                   n1o.Column(D("v"), n1o.COL_TAGGED64, tags=np.full(n, n1o.T_INT, np.uint8), payload=vals.view(np.uint64))], dictionary)
+    aggs = sorted(["count(*)", "sum(%s)" % D("v")])
+    ora = n1o.run(t, None, [D("k")], aggs, threads=1)
+    assert len(ora.keys) == 13  # 20 distinct values, 13 distinct texts
+    gpu, _ = pu.run_gpu(t, None, [D("k")], aggs, batches=2, **opts)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+
+
 def test_wide_key_value_table_overflow_is_reported():
     t = _wide_key_table(40_000)
     with pytest.raises(query_amd.N1kError) as ei:
