@@ -161,6 +161,7 @@ typedef struct n1k_stats {
                                 pairs), bit 1 radix partition + LDS sets (one-word members), bit 2 global one-word set (fallback) */
     uint32_t reserved0;
     uint64_t topk_candidates; /* ORDER BY ... LIMIT: groups that left the device after the top-k filter (0 = filter not used) */
+    uint64_t json_device_docs; /* documents of n1k_push_json whose leaf values the DEVICE extractor produced (the rest: the host's) */
     double query_ms;        /* hipEvent time of the last WHOLE query on the handle's stream: from n1k_reset (reopen) to the last
                                kernel / copy of n1k_finish — every kernel of the query and the gaps between them; 0 until a
                                finish has completed.  device_ms above covers the batches' kernels only. */
@@ -489,6 +490,14 @@ typedef struct n1k_synth_spec {
 n1k_status n1k_synth_columns(int device, void *stream, const n1k_synth_spec *spec, uint32_t *cat_codes,
                              uint8_t *price_tags, uint64_t *price_payload, uint8_t *user_tags,
                              uint64_t *user_payload, uint8_t *region_tags, uint64_t *region_payload);
+
+/* The same rows as raw JSON documents (bench / test input for n1k_push_json): from HOST copies of the arrays
+ * n1k_synth_columns filled, document i = {"id":"d<i>","cat":"cat_<c>","price":<p>,"user_id":<u>,"region_id":<r>,"pad":"x..."}
+ * (a MISSING value leaves its field out, NULL prints null, floats print their shortest round-trip digits; `pad` x's).
+ * offsets: nrows + 1 entries.  N1K_OOM: `cap` bytes do not hold them (*used then says how many it takes). */
+n1k_status n1k_synth_documents(uint64_t nrows, uint64_t first_id, const uint32_t *cat_codes, const uint8_t *price_tags,
+                               const uint64_t *price_payload, const uint64_t *user_payload, const uint64_t *region_payload,
+                               uint32_t pad, char *bytes, size_t cap, uint64_t *offsets, size_t *used);
 
 int n1k_abi_version(void);
 /* number of visible HIP devices (0 when none); never initialises a context */

@@ -61,7 +61,7 @@ class Stats(C.Structure):
                 ("batches", C.c_uint64), ("device_ms", C.c_double), ("bytes_scanned", C.c_uint64),
                 ("agg_mode", C.c_uint32), ("spec_kernel", C.c_uint32),
                 ("wide_key_values", C.c_uint64), ("distinct_path", C.c_uint32), ("reserved0", C.c_uint32),
-                ("topk_candidates", C.c_uint64), ("query_ms", C.c_double)]
+                ("topk_candidates", C.c_uint64), ("json_device_docs", C.c_uint64), ("query_ms", C.c_double)]
 
 
 class SynthSpec(C.Structure):
@@ -80,7 +80,7 @@ SYMBOLS = [
     "n1k_merge_partials_device",
     "n1k_comm_unique_id", "n1k_comm_create", "n1k_comm_destroy", "n1k_comm_last_error", "n1k_comm_rank", "n1k_comm_world",
     "n1k_comm_max_u64", "n1k_exchange_partials", "n1k_exchange_rows", "n1k_gather_groups", "n1k_gather_groups_status", "n1k_rows_step", "n1k_partials_step", "n1k_failure_is_global",
-    "n1k_abi_version", "n1k_device_count",
+    "n1k_synth_documents", "n1k_abi_version", "n1k_device_count",
 ]
 
 _lib = None
@@ -204,6 +204,9 @@ def lib():
     L.n1k_gather_groups.argtypes = [H, H, C.POINTER(Result), C.POINTER(Result)]
     L.n1k_synth_columns.restype = C.c_int
     L.n1k_synth_columns.argtypes = [C.c_int, C.c_void_p, C.POINTER(SynthSpec)] + [C.c_void_p] * 7
+    L.n1k_synth_documents.restype = C.c_int
+    L.n1k_synth_documents.argtypes = [C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.POINTER(C.c_size_t)]
     L.n1k_abi_version.restype = C.c_int
     L.n1k_device_count.restype = C.c_int
     _lib = L

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libn1k.so")
-SOURCES = ["n1k_kernels.hip", "n1k_bins.hip", "n1k_plan.cpp", "n1k_engine.cpp", "n1k_scan.cpp", "n1k_partitioned.cpp", "n1k_distinct.cpp",
+SOURCES = ["n1k_kernels.hip", "n1k_bins.hip", "n1k_jsondev.hip", "n1k_jsonpush.cpp", "n1k_plan.cpp", "n1k_engine.cpp", "n1k_scan.cpp", "n1k_partitioned.cpp", "n1k_distinct.cpp",
            "n1k_finish.cpp", "n1k_tail.cpp", "n1k_exchange.cpp", "n1k_jit.cpp", "n1k_json.cpp"]
 HEADERS = ["n1k_types.h", "n1k_device.h", "n1k_tables.h", "n1k_scatter.h", "n1k_spec.h", "n1k_jit.h", "n1k_kernels.h", "n1k_plan.h", os.path.join("..", "..", "include", "n1k.h")]
 HOST_HEADERS = ["n1k_engine.h"]  # host-only: not part of source_hash()

@@ -710,6 +710,19 @@ static void destroy_handle(n1k_handle* h) {
         }
         if (h->st_copied) (void)hipEventDestroy(h->st_copied);
         if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+        h->jd_bytes.release();
+        h->jd_offsets.release();
+        h->jd_new_first.release();
+        h->jd_patch_docs.release();
+        h->jd_patch_pay.release();
+        h->jd_tab.release();
+        h->jd_status.release();
+        h->jd_patch_tags.release();
+        h->jd_new_list.release();
+        h->jd_code_of.release();
+        h->jd_codes.release();
+        for (auto& b : h->jd_tags) b.release();
+        for (auto& b : h->jd_payload) b.release();
         h->d_mask.release();
         h->d_tile_off.release();
         h->d_sel.release();
@@ -867,6 +880,12 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     } else if (n == "dedupe_block") {
         if ((value | 1) != 257 && (value | 1) != 513 && (value | 1) != 1025) return fail(h, N1K_INVALID, "dedupe_block must be 256, 512 or 1024 (+1: probe word by word)");
         h->opt_dedupe_block = (uint32_t)value;
+    } else if (n == "json_device") {
+        h->opt_json_device = value ? 1 : 0;
+    } else if (n == "json_device_left_pct") {
+        h->opt_json_device_left_pct = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100);
+    } else if (n == "json_device_min_docs") {
+        h->opt_json_device_min_docs = (uint64_t)std::max<int64_t>(value, 0);
     } else if (n == "json_threads") {
         h->opt_json_threads = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64);
     } else if (n == "partition_min_rows") {
@@ -1027,6 +1046,21 @@ n1k_status n1k_extract_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offse
 
 n1k_status n1k_push_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offsets, const char* bytes) {
     return guarded(h, [&]() -> n1k_status {
+    if (!h || (ndocs && (!offsets || !bytes))) return N1K_INVALID;
+    if (h->stop_flag.load()) return fail(h, N1K_STOPPED, "operator was stopped");
+    // large batches: the device extractor (the bytes cross PCIe as they are; n1k_jsonpush.cpp) — it takes the batch or
+    // leaves all of it to the host path below
+    if (h->json_paths_state == 0) {
+        h->json_paths.resize(h->plan.paths.size());
+        h->json_paths_state = 1;
+        for (size_t c = 0; c < h->plan.paths.size(); c++)
+            if (!parse_leaf_path(h->plan.paths[c], h->json_paths[c])) h->json_paths_state = -1;
+    }
+    if (h->json_paths_state > 0 && ndocs) {
+        bool done = false;
+        n1k_status dst = push_json_device(h, ndocs, offsets, bytes, &done);
+        if (dst != N1K_OK || done) return dst;
+    }
     n1k_batch b{};
     n1k_status st = n1k_extract_json(h, ndocs, offsets, bytes, &b);
     if (st != N1K_OK) return st;
@@ -1127,6 +1161,81 @@ n1k_status n1k_get_stats(const n1k_handle* h, n1k_stats* out) {
         if (hipEventElapsedTime(&ms, m->ev_q0, m->ev_q1) == hipSuccess) m->stats.query_ms = ms;
     }
     *out = h->stats;
+    return N1K_OK;
+    });
+}
+
+n1k_status n1k_synth_documents(uint64_t nrows, uint64_t first_id, const uint32_t* cat_codes, const uint8_t* price_tags,
+                               const uint64_t* price_payload, const uint64_t* user_payload, const uint64_t* region_payload, uint32_t pad,
+                               char* bytes, size_t cap, uint64_t* offsets, size_t* used) {
+    return guarded(nullptr, [&]() -> n1k_status {
+    if (!cat_codes || !price_tags || !price_payload || !user_payload || !region_payload || !offsets || !used || (cap && !bytes)) return N1K_INVALID;
+    const uint32_t nthreads = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), nrows / 65536 + 1));
+    std::vector<std::string> part(nthreads);
+    std::vector<std::vector<uint32_t>> lens(nthreads);
+    auto work = [&](uint32_t t) {
+        const uint64_t lo = nrows * t / nthreads, hi = nrows * (t + 1) / nthreads;
+        std::string& o = part[t];
+        o.reserve((size_t)(hi - lo) * (110 + pad));
+        lens[t].reserve((size_t)(hi - lo));
+        const std::string padding(pad, 'x');
+        char num[32];
+        for (uint64_t i = lo; i < hi; i++) {
+            const size_t at = o.size();
+            o += "{\"id\":\"d";
+            o += std::to_string(first_id + i);
+            o += "\"";
+            if (cat_codes[i] == 0xFFFFFFFEu) o += ",\"cat\":null";
+            else if (cat_codes[i] != 0xFFFFFFFFu) {
+                o += ",\"cat\":\"cat_";
+                o += std::to_string(cat_codes[i]);
+                o += "\"";
+            }
+            switch (price_tags[i]) {
+                case N1K_T_MISSING: break;
+                case N1K_T_NULL: o += ",\"price\":null"; break;
+                case N1K_T_INT: snprintf(num, sizeof num, "%lld", (long long)price_payload[i]); o += ",\"price\":"; o += num; break;
+                case N1K_T_FLOAT: {
+                    double d;
+                    memcpy(&d, &price_payload[i], 8);
+                    o += ",\"price\":";
+                    format_float(d, o);
+                    break;
+                }
+                default: o += ",\"price\":\"n/a\""; break;
+            }
+            snprintf(num, sizeof num, "%lld", (long long)user_payload[i]);
+            o += ",\"user_id\":";
+            o += num;
+            snprintf(num, sizeof num, "%lld", (long long)region_payload[i]);
+            o += ",\"region_id\":";
+            o += num;
+            o += ",\"pad\":\"";
+            o += padding;
+            o += "\"}";
+            lens[t].push_back((uint32_t)(o.size() - at));
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < nthreads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    size_t total = 0;
+    for (auto& p : part) total += p.size();
+    *used = total;
+    if (total > cap) return N1K_OOM;
+    size_t at = 0;
+    uint64_t row = 0;
+    for (uint32_t t = 0; t < nthreads; t++) {
+        memcpy(bytes + at, part[t].data(), part[t].size());
+        size_t o = at;
+        for (uint32_t l : lens[t]) {
+            offsets[row++] = o;
+            o += l;
+        }
+        at += part[t].size();
+    }
+    offsets[nrows] = total;
     return N1K_OK;
     });
 }

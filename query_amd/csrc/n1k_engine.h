@@ -142,6 +142,17 @@ struct n1k_handle {
     std::vector<std::vector<uint64_t>> js_payload;
     std::vector<n1k_col> js_cols;
     uint32_t opt_json_threads = 0;  // 0 = hardware concurrency (at most 16)
+    // n1k_push_json through the device extractor (n1k_jsondev.hip): the batch's bytes, offsets, status, columns, string table
+    uint32_t opt_json_device = 1;
+    uint64_t opt_json_device_min_docs = 4096;
+    uint32_t opt_json_device_left_pct = 12;  // more documents than this left to the host: the host path takes the whole batch
+    DevBuf<char> jd_bytes;
+    DevBuf<uint64_t> jd_offsets, jd_new_first, jd_patch_docs, jd_patch_pay, jd_tab;
+    DevBuf<uint8_t> jd_status, jd_patch_tags;
+    DevBuf<uint32_t> jd_new_list, jd_code_of, jd_codes;
+    std::vector<DevBuf<uint8_t>> jd_tags;
+    std::vector<DevBuf<uint64_t>> jd_payload;
+    std::vector<uint8_t> jd_host_status;
     bool failure_global = false;  // the last failure reported on this handle was learnt from (or told through) the verdict words of an
                                   // exchange: every rank's step fails alike, nobody enters the gather (n1k_failure_is_global)
     uint32_t opt_inject_failure = 0;  // tests: the exchange pretends that its site 1 (buffers) / 2 (partition, export) / 3 (receiving part) failed, once
@@ -319,6 +330,9 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
 // n1k_distinct.cpp: the sets of the DISTINCT aggregates at finish
 n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64_t nwords, bool hist_counted = true, const uint64_t* log = nullptr);
 n1k_status distinct_regions_finish(n1k_handle* h, const AggSpec& ag, uint64_t nover, bool force_exact, bool* deferred);
+
+// n1k_jsonpush.cpp: n1k_push_json through the device extractor (done = false: the host path takes the batch)
+n1k_status push_json_device(n1k_handle* h, uint64_t ndocs, const uint64_t* offsets, const char* bytes, bool* done);
 
 // n1k_tail.cpp: what follows FinalGroup (HAVING, projection, ORDER BY / OFFSET / LIMIT, ARRAY_AGG assembly)
 n1k_status build_projection(n1k_handle* h);

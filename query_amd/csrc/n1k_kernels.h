@@ -134,6 +134,33 @@ hipError_t launch_filter_compact(const uint64_t* mask_words, const uint64_t* til
 hipError_t launch_filter_stream(const Program& P, uint64_t nrows, uint64_t row_base, uint64_t* out_rows, unsigned long long* tile_state,
                                 unsigned long long* tile_counter, unsigned long long* total, uint32_t* err_flags, uint32_t grid,
                                 hipStream_t st);
+// ---- raw JSON documents -> leaf columns on the device (n1k_jsondev.hip)
+constexpr uint32_t kJsonMaxSteps = 4;  // field names of a leaf path below the keyspace alias
+struct JsonDevPath {
+    uint32_t nsteps;
+    uint32_t name_off[kJsonMaxSteps], name_len[kJsonMaxSteps];  // the names' bytes in JsonDevArgs::names
+};
+struct JsonDevArgs {
+    const uint8_t* bytes;     // the batch's documents, back to back (+ 32 spare bytes); document d = [offsets[d] - base, offsets[d + 1] - base)
+    const uint64_t* offsets;  // ndocs + 1
+    uint64_t base, ndocs;
+    uint32_t npaths, tab_bits;
+    JsonDevPath paths[kMaxCols];
+    char names[1024];
+    uint8_t* out_tags[kMaxCols];
+    uint64_t* out_payload[kMaxCols];
+    uint8_t* status;                    // per document: 0 extracted here, 1 left to the host's scalar extractor
+    unsigned long long* tab_hash;       // the batch's string table: 1 << tab_bits slots, 0 = free
+    unsigned long long* tab_first;      // [63] valid [offset of the first occurrence in `bytes` : 39][length : 24]
+    uint32_t* new_list;                 // slots taken by this batch, in no particular order
+    unsigned long long* new_count;
+    uint32_t new_cap;
+};
+hipError_t launch_json_extract(const JsonDevArgs& A, uint32_t num_cus, hipStream_t st);
+hipError_t launch_json_remap(const JsonDevArgs& A, const uint32_t* code_of, hipStream_t st);
+hipError_t launch_json_gather_first(const JsonDevArgs& A, uint64_t n, unsigned long long* out, hipStream_t st);
+hipError_t launch_json_scatter_codes(const uint32_t* new_list, const uint32_t* codes, uint64_t n, uint32_t* code_of, hipStream_t st);
+hipError_t launch_json_patch(const JsonDevArgs& A, const uint64_t* docs, const uint8_t* tags, const uint64_t* payload, uint64_t n, hipStream_t st);
 hipError_t launch_synth(const SynthArgs& a, hipStream_t st);
 
 }  // namespace n1k

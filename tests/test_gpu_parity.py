@@ -1044,6 +1044,106 @@ def test_raw_json_documents_end_to_end(cond, keys, aggs):
     pu.assert_same_groups(gpu, ora, aggs=aggs)
 
 
+def _tricky_docs(n, rng):
+    """Documents that walk the device extractor's branches: nested wanted paths, first-field-wins duplicates, escapes in wanted
+    strings and in names, array / object values, numbers at the edges of its exact conversions, documents that are not
+    objects, one larger than a wave's LDS share, whitespace everywhere."""
+    import json
+    docs = []
+    strs = ["alpha", "beta", "g\"q", "tab\there", "\u00e9t\u00e9", "", "x" * 300, "NaN"]
+    nums = ["0", "-0", "7", "-12", "123456789012345678", "1234567890123456789", "9223372036854775807", "9223372036854775808",
+            "1.5", "-2.25", "12.34", "0.1", "1e3", "1E3", "2.5e-3", "1e22", "1e23", "123456789012345.6", "1234567890123456.7",
+            "5.0", "-0.0", "1e400", "4.9e-324", "0.30000000000000004", "100e-2", "3.0e0"]
+    for i in range(n):
+        k = int(rng.integers(0, 12))
+        s = json.dumps(strs[int(rng.integers(0, len(strs)))]) if k != 0 else None
+        num = nums[int(rng.integers(0, len(nums)))]
+        inner = '{"y": %s, "z": [1, {"y": 5}]}' % nums[int(rng.integers(0, len(nums)))]
+        if k == 1:
+            doc = '{"pad": "p", "s": %s, "n": %s, "x": %s, "s": "second", "n": 99}' % (s, num, inner)  # duplicates: the first counts
+        elif k == 2:
+            doc = ' {\n\t"n" :%s ,\r\n "x" : %s , "s":%s } ' % (num, inner, s)
+        elif k == 3:
+            doc = '{"s": %s, "n": [1, 2, {"a": "b"}], "x": {"y": {"deep": true}}}' % s  # array / object values of wanted paths
+        elif k == 4:
+            doc = '{"\\u0073": "escaped name", "s": %s, "n": %s, "x": 5}' % (s, num)  # "x" is a scalar: x.y is MISSING
+        elif k == 5:
+            doc = '{"s": %s, "n": %s, "big": "%s", "x": %s}' % (s, num, "b" * 20000, inner)  # larger than 16 KB
+        elif k == 6:
+            doc = ['42', '[1, 2, 3]', '"just a string"', 'null', '{}'][int(rng.integers(0, 5))]
+        elif k == 7:
+            doc = '{"n": true, "s": null, "x": {"y": false}}'
+        elif k == 8:
+            doc = '{"skip": {"s": "inner s does not count", "a": [[], {}, [{"q": "\\\\"}]]}, "s": %s, "n": %s}' % (s, num)
+        else:
+            doc = '{"id": "d%d", "s": %s, "n": %s, "x": %s, "pad": "%s"}' % (i, s if s else '"none"', num, inner, "x" * int(rng.integers(0, 50)))
+        docs.append(doc.encode())
+    return docs
+
+
+def _groups_from_json(docs, device, aggs, keys, min_docs=1):
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(None, keys, aggs), json_device=device, json_device_min_docs=min_docs,
+                                 json_device_left_pct=100)
+    half = len(docs) // 2
+    op.process_json(docs[:half])
+    op.process_json(docs[half:])
+    rows = op.after_items()
+    st = op.stats()
+    op.done()
+    return rows, st
+
+
+def test_device_json_extractor_against_the_host_extractor():
+    """n1k_push_json through the device extractor (json_extract_kernel: one lane per document, bytes staged in LDS, strings as
+    ids of a per-batch table) gives the groups the host's scalar extractor gives — FirstFind (value/parsed.go:159-207), NewValue
+    typing (value/value.go:367-430) — over documents that exercise every hand-over to the host, and most documents never
+    visit the host."""
+    rng = np.random.default_rng(77)
+    docs = _tricky_docs(20_000, rng)
+    # (every typed value is looked at: s and n as group keys — strings, numbers, arrays by their canonical text — x.y through
+    #  SUM / COUNT / COUNTN; MIN / MAX would have to order arrays, which no path of the device does)
+    keys = ["(`d`.`s`)", "(`d`.`n`)"]
+    aggs = sorted(["count(*)", "sum(((`d`.`x`).`y`))", "count(((`d`.`x`).`y`))", "countn(((`d`.`x`).`y`))"])
+    host, hst = _groups_from_json(docs, 0, aggs, keys)
+    dev, dst = _groups_from_json(docs, 1, aggs, keys)
+    assert hst["json_device_docs"] == 0 and dst["json_device_docs"] > 0.2 * len(docs)  # (most of THESE documents are built to need the host)
+    assert dev.nkeys == host.nkeys and len(dev.keys) == len(host.keys)
+    hm = {pu._canon_key(k): a for k, a in zip(host.keys, host.aggs)}
+    dm = {pu._canon_key(k): a for k, a in zip(dev.keys, dev.aggs)}
+    assert hm.keys() == dm.keys()
+    for k in hm:
+        for i, (x, y) in enumerate(zip(dm[k], hm[k])):
+            assert pu.values_match(x, y, 1e-12, float_agg=aggs[i].startswith("sum")), (k, aggs[i], x, y)
+
+
+def test_device_json_extractor_plain_documents_stay_on_the_device():
+    """The synthetic data set's documents need no host help at all, and the groups are the oracle's."""
+    n = 40_000
+    t = n1o.synth_table(n, k_cat=40, total_rows=20_000)
+    docs = _docs_of(t, n)
+    cond, keys = "(50 < %s)" % D("price"), [D("cat")]
+    aggs = sorted(["count(*)", "sum(%s)" % D("price"), "max(%s)" % D("user_id")])
+    ora = n1o.run(t, cond, keys, aggs, threads=2)
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(cond, keys, aggs))
+    op.process_json(docs)
+    gpu = op.after_items()
+    st = op.stats()
+    op.done()
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert st["json_device_docs"] >= 0.99 * n  # (json.dumps prints a few prices with 16 - 17 digits: those documents are the host's)
+
+
+@pytest.mark.parametrize("device", [1, 0])
+def test_malformed_document_is_named_by_either_extractor(device):
+    docs = [b'{"s": "a", "n": %d}' % i for i in range(6000)]
+    docs[4321] = b'{"s": "a", "n": 1,}'
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(None, ["(`d`.`s`)"], ["sum((`d`.`n`))"]), json_device=device, json_device_min_docs=1)
+    with pytest.raises(query_amd.N1kError) as ei:
+        op.process_json(docs)
+    op.done()
+    assert ei.value.status == _ffi.INVALID and "document 4321" in ei.value.message
+
+
 @pytest.mark.parametrize("having,check", [
     ("(33000 < sum(%s))" % D("price"), lambda k, a: a["sum"][1] is not None and a["sum"][1] > 33000),
     ("((count(*) < 700) and (%s is not null))" % D("cat"), lambda k, a: a["count"][1] < 700 and k[0][0] > n1o.T_NULL),
