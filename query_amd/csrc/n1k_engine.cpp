@@ -1010,7 +1010,11 @@ n1k_status n1k_extract_json(n1k_handle* h, uint64_t ndocs, const uint64_t* offse
     for (uint32_t t = 0; t < nthreads; t++)
         if (threw[t]) return fail(h, N1K_OOM, "out of host memory while scanning the documents");
     for (uint32_t t = 0; t < nthreads; t++)
-        if (bad[t] >= 0) return fail(h, N1K_INVALID, "document %lld is not valid JSON: %s", bad[t], errs[t].c_str());
+        if (bad[t] >= 0) {
+            if (errs[t].find("nested deeper than 256") != std::string::npos)  // (well formed, but beyond what the extractor re-serialises)
+                return fail(h, N1K_UNSUPPORTED_DATA, "document %lld: %s", bad[t], errs[t].c_str());
+            return fail(h, N1K_INVALID, "document %lld is not valid JSON: %s", bad[t], errs[t].c_str());
+        }
     // one dictionary: the threads' local strings get the handle's codes
     h->js_tags.assign(np, std::vector<uint8_t>());
     h->js_payload.assign(np, std::vector<uint64_t>());

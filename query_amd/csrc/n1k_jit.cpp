@@ -63,7 +63,10 @@ uint64_t headers_hash() {
     for (const char* n : names) {
         std::string path = csrc_dir() + "/" + n;
         FILE* f = fopen(path.c_str(), "rb");
-        if (!f) continue;
+        if (!f) {  // a header the key cannot cover: no cache at all rather than a key that silently leaves it out
+            cached = 0;
+            return 0;
+        }
         char buf[65536];
         size_t got;
         while ((got = fread(buf, 1, sizeof buf, f)) > 0) h = fnv1a(buf, got, h);
@@ -78,9 +81,31 @@ uint64_t headers_hash() {
     return cached;
 }
 
+// The cached object carries a trailer — magic, size, two independent 64-bit checksums of the bytes — which cache_read
+// verifies: a truncated, corrupted or foreign file is recompiled, not loaded onto the GPU.
+struct CacheTrailer {
+    char magic[8];
+    uint64_t size, sum_a, sum_b;
+};
+constexpr char kTrailerMagic[8] = {'N', '1', 'K', 'C', 'O', 'v', '1', 0};
+void trailer_of(const char* p, size_t n, CacheTrailer& t) {
+    memcpy(t.magic, kTrailerMagic, 8);
+    t.size = n;
+    t.sum_a = fnv1a(p, n, 0xCBF29CE484222325ull);
+    uint64_t b = 0x9E3779B97F4A7C15ull;  // a second, unrelated mix over 8-byte words
+    for (size_t i = 0; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        b = (b ^ w) * 0xFF51AFD7ED558CCDull;
+        b ^= b >> 29;
+    }
+    for (size_t i = n & ~(size_t)7; i < n; i++) b = (b ^ (unsigned char)p[i]) * 0x100000001B3ull;
+    t.sum_b = b;
+}
+
 std::string cache_path(const std::string& src) {
     const std::string dir = cache_dir();
-    if (dir.empty()) return "";
+    if (dir.empty() || headers_hash() == 0) return "";
     uint64_t h = fnv1a(src.data(), src.size(), headers_hash());
     static const char kOpts[] = "--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics";
     h = fnv1a(kOpts, sizeof kOpts, h);
@@ -96,12 +121,20 @@ bool cache_read(const std::string& path, std::vector<char>& code) {
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    bool ok = n > 64;
+    bool ok = n > 64 + (long)sizeof(CacheTrailer);
     if (ok) {
         code.resize((size_t)n);
         ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n && !memcmp(code.data(), "\177ELF", 4);
     }
     fclose(f);
+    if (ok) {
+        CacheTrailer have, want;
+        const size_t body = (size_t)n - sizeof(CacheTrailer);
+        memcpy(&have, code.data() + body, sizeof have);
+        trailer_of(code.data(), body, want);
+        ok = !memcmp(have.magic, kTrailerMagic, 8) && have.size == body && have.sum_a == want.sum_a && have.sum_b == want.sum_b;
+        if (ok) code.resize(body);
+    }
     if (!ok) code.clear();
     return ok;
 }
@@ -109,13 +142,15 @@ bool cache_read(const std::string& path, std::vector<char>& code) {
 void cache_write(const std::string& path, const std::vector<char>& code) {
     if (path.empty() || code.empty()) return;
     const std::string dir = path.substr(0, path.rfind('/'));
-    (void)mkdir(dir.c_str(), 0777);
+    (void)mkdir(dir.c_str(), 0755);  // (only its owner writes code objects that this library will load)
     char tmp[64];
     snprintf(tmp, sizeof tmp, ".tmp.%d.%p", (int)getpid(), (void*)&code);
     const std::string t = dir + "/" + tmp;
     FILE* f = fopen(t.c_str(), "wb");
     if (!f) return;
-    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    CacheTrailer tr;
+    trailer_of(code.data(), code.size(), tr);
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size() && fwrite(&tr, 1, sizeof tr, f) == sizeof tr;
     fclose(f);
     if (!ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
 }

@@ -316,8 +316,12 @@ namespace {
 void quote(const std::string& s, std::string& o) { json_quote(s, o); }
 
 // canonical text of the value at sc.p, appended to o
+// (Recursive, one frame of three strings per level and every object level copies its children's text: bounded at
+//  kMaxCanonDepth levels — a wanted VALUE nested deeper than that is N1K_UNSUPPORTED_DATA, not a stack overflow on a small
+//  thread stack; documents are skipped without recursion up to Go's own limit, above.)
+constexpr int kMaxCanonDepth = 256;
 bool canon(Scanner& sc, std::string& o, int depth) {
-    if (depth > (int)kMaxJsonDepth) return sc.fail("nesting too deep");
+    if (depth > kMaxCanonDepth) return sc.fail("a wanted array / object value nested deeper than 256 levels");
     sc.ws();
     if (sc.p >= sc.end) return sc.fail("value expected");
     switch (*sc.p) {

@@ -119,6 +119,8 @@ n1k_status push_json_device(n1k_handle* h, uint64_t ndocs, const uint64_t* offse
         for (size_t i = 0; i < left.size(); i++) {
             const uint64_t d = left[i];
             const long long bad = extract_json_range(h->json_paths, offsets, bytes, d, d + 1, one, err);
+            if (bad >= 0 && err.find("nested deeper than 256") != std::string::npos)
+                return fail(h, N1K_UNSUPPORTED_DATA, "document %llu: %s", (unsigned long long)d, err.c_str());
             if (bad >= 0) return fail(h, N1K_INVALID, "document %llu is not valid JSON: %s", (unsigned long long)d, err.c_str());
             for (size_t c = 0; c < np; c++) {
                 const uint8_t t = one.tags[c][0];

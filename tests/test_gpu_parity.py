@@ -1,4 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's golden cases."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,7 @@ from query_amd import _ffi
 
 pytestmark = pytest.mark.gpu
 
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = gu.load_cases()
 
 
@@ -1170,3 +1173,46 @@ def test_having_outside_the_groups_is_unsupported():
     with pytest.raises(query_amd.N1kError) as ei:
         query_amd.GpuFilterGroup(pj)
     assert ei.value.status == _ffi.UNSUPPORTED and "HAVING" in ei.value.message
+
+
+def test_code_object_cache_refuses_a_damaged_file(tmp_path):
+    """Run-time-built kernels are cached on disk (query_amd/jit_cache, or N1K_JIT_CACHE).  A cached object carries a trailer
+    (size + two checksums): a file that was truncated, or altered by as little as one byte, is compiled again instead of being
+    loaded onto the GPU — and the answer is the oracle's either way."""
+    import subprocess
+    import sys
+    script = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import parity_util as pu
+from oracle import n1o
+from query_amd import plan
+D = lambda *n: plan.field_path("default", *n)
+t = n1o.synth_table(50_000, k_cat=30)
+cond, keys, aggs = "(%%s <= 50.5)" %% D("price"), [D("cat")], sorted(["avg(%%s)" %% D("price"), "count(*)"])
+ora = n1o.run(t, cond, keys, aggs)
+gpu, st = pu.run_gpu(t, cond, keys, aggs, jit=2)
+pu.assert_same_groups(gpu, ora, aggs=aggs)
+assert st["spec_kernel"] == 2, st
+print("ok")
+''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"))
+    env = dict(os.environ, N1K_JIT_CACHE=str(tmp_path))
+
+    def run():
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+    run()
+    files = sorted(tmp_path.glob("*.co"))
+    assert files, "no code object was cached"
+    good = files[0].read_bytes()
+    assert good[-32:-24] == b"N1KCOv1\0"  # the trailer: magic, size, two checksums
+    # one byte flipped in the middle of the object; then a truncated file
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x5A
+    files[0].write_bytes(bytes(bad))
+    run()
+    assert files[0].read_bytes() == good  # compiled again and written back
+    files[0].write_bytes(good[:len(good) // 3])
+    run()
+    assert files[0].read_bytes() == good

@@ -147,8 +147,16 @@ def test_deep_nesting_is_bounded_like_the_reference():
         assert ei.value.status == _ffi.INVALID and "document 1" in ei.value.message
     op.done()
     # a wanted value nested far deeper than the 64 levels of the first version: canonical text, as the reference would key it
-    a, = _one(b'{"a": ' + nest(500, b'{"b": 1.0}') + b"}", "a")
-    assert a == (n1o.T_ARRAY, nest(500, b'{"b":1}'))
+    a, = _one(b'{"a": ' + nest(250, b'{"b": 1.0}') + b"}", "a")
+    assert a == (n1o.T_ARRAY, nest(250, b'{"b":1}'))
+    # ... up to the bound of the (recursive) re-serialiser: a wanted value nested 10 000 deep is refused as data outside the
+    # subset, whatever the size of the calling thread's stack — not a crash, and not "invalid JSON" (it is valid)
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(None, [D("a")], ["count(*)"]))
+    for deep in (nest(10_000), b'{"a":' * 9_000 + b"1" + b"}" * 9_000):
+        with pytest.raises(query_amd.N1kError) as ei:
+            op.extract_json([b'{"a": 1}', b'{"a": ' + deep + b"}"])
+        assert ei.value.status == _ffi.UNSUPPORTED_DATA and "document 1" in ei.value.message
+    op.done()
 
 
 def test_threads_agree_and_share_one_dictionary():
