@@ -451,6 +451,15 @@ int n1k_comm_world(const n1k_comm *c);
 n1k_status n1k_comm_max_u64(n1k_comm *c, n1k_handle *h, uint64_t value, uint64_t *out);
 n1k_status n1k_exchange_partials(n1k_comm *c, n1k_handle *sender, n1k_handle *receiver, uint64_t capacity_groups, int gathered);
 n1k_status n1k_exchange_rows(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver, uint64_t capacity_rows);
+/* The same with one capacity PER DESTINATION (capacity_rows[world], the same vector on every rank): every sender's region for
+ * owner d holds capacity_rows[d] rows, so an owner that receives more than its share (skewed keys) only enlarges the regions
+ * sent to IT, not all world x world of them.  n1k_exchange_sent_rows: the rows this rank's last exchange wrote per destination
+ * (waits for the stream); the ranks size the next steps' regions from the largest over the senders, per destination
+ * (n1k_comm_max_u64_v: element-wise n1k_comm_max_u64 over n <= 64 values). */
+n1k_status n1k_exchange_rows_v(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver,
+                               const uint64_t *capacity_rows);
+n1k_status n1k_exchange_sent_rows(n1k_comm *c, n1k_handle *sender, uint64_t *out);
+n1k_status n1k_comm_max_u64_v(n1k_comm *c, n1k_handle *h, uint32_t n, const uint64_t *values, uint64_t *out);
 n1k_status n1k_gather_groups(n1k_comm *c, n1k_handle *h, const n1k_result *local, n1k_result *out);
 /* The same, carrying every rank's verdict on its own step: a rank whose n1k_finish failed (data its shard alone holds, say)
  * still enters the collective with local_status != N1K_OK (local may be NULL) instead of leaving its peers waiting in it;
@@ -467,6 +476,8 @@ int n1k_failure_is_global(const n1k_handle *h);
  * with *worst_status as n1k_gather_groups_status reports it. */
 n1k_status n1k_rows_step(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver, n1k_handle *merger,
                          uint64_t capacity_rows, n1k_result *out, int *worst_status);
+n1k_status n1k_rows_step_v(n1k_comm *c, n1k_handle *sender, const n1k_batch *batch, n1k_handle *receiver, n1k_handle *merger,
+                           const uint64_t *capacity_rows, n1k_result *out, int *worst_status); /* capacities per destination */
 /* The same for partial groups: n1k_reset(receiver), n1k_reset(sender), n1k_push_device_batch(sender, batch) (InitialGroup
  * over the shard), n1k_exchange_partials, n1k_finish(receiver) and — unless `gathered`, where every rank merged every rank's
  * groups and `receiver` (a handle that carries the plan's grouped tail) holds the result — the gather through `merger`. */

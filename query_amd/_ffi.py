@@ -80,6 +80,7 @@ SYMBOLS = [
     "n1k_merge_partials_device",
     "n1k_comm_unique_id", "n1k_comm_create", "n1k_comm_destroy", "n1k_comm_last_error", "n1k_comm_rank", "n1k_comm_world",
     "n1k_comm_max_u64", "n1k_exchange_partials", "n1k_exchange_rows", "n1k_gather_groups", "n1k_gather_groups_status", "n1k_rows_step", "n1k_partials_step", "n1k_failure_is_global",
+    "n1k_exchange_rows_v", "n1k_exchange_sent_rows", "n1k_comm_max_u64_v", "n1k_rows_step_v",
     "n1k_synth_documents", "n1k_abi_version", "n1k_device_count",
 ]
 
@@ -200,6 +201,15 @@ def lib():
         L.n1k_partials_step.argtypes = [H, H, C.POINTER(Batch), H, H, C.c_uint64, C.c_int, C.POINTER(Result), C.POINTER(C.c_int)]
         L.n1k_failure_is_global.restype = C.c_int
         L.n1k_failure_is_global.argtypes = [H]
+    if hasattr(L, "n1k_rows_step_v"):
+        L.n1k_rows_step_v.restype = C.c_int
+        L.n1k_rows_step_v.argtypes = [H, H, C.POINTER(Batch), H, H, C.POINTER(C.c_uint64), C.POINTER(Result), C.POINTER(C.c_int)]
+        L.n1k_exchange_rows_v.restype = C.c_int
+        L.n1k_exchange_rows_v.argtypes = [H, H, C.POINTER(Batch), H, C.POINTER(C.c_uint64)]
+        L.n1k_exchange_sent_rows.restype = C.c_int
+        L.n1k_exchange_sent_rows.argtypes = [H, H, C.POINTER(C.c_uint64)]
+        L.n1k_comm_max_u64_v.restype = C.c_int
+        L.n1k_comm_max_u64_v.argtypes = [H, H, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.n1k_gather_groups.restype = C.c_int
     L.n1k_gather_groups.argtypes = [H, H, C.POINTER(Result), C.POINTER(Result)]
     L.n1k_synth_columns.restype = C.c_int

@@ -16,7 +16,7 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
     const uint64_t seg_rows = A.region_bytes ? A.sub_rows : 0;
     A.nsub = 1;
     if (b->nrows == 0) {
-        if (seg_rows) HIP_TRY(h, launch_dense_to_segments(A.counts, A.nparts, A.count_stride, seg_rows, h->stream));
+        if (seg_rows) HIP_TRY(h, launch_dense_to_segments(A.counts, A.nparts, A.count_stride, seg_rows, h->stream, A.per_dest ? A.dest_cap : nullptr));
         return materialize_derived(h, b);
     }
     const uint64_t n = b->nrows;
@@ -73,7 +73,7 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
         HIP_TRY(h, launch_partition(h->prog, A, grid, h->stream));
         h->stats.spec_kernel = 0;
     }
-    if (seg_rows && A.nsub == 1) HIP_TRY(h, launch_dense_to_segments(A.counts, A.nparts, A.count_stride, seg_rows, h->stream));
+    if (seg_rows && A.nsub == 1) HIP_TRY(h, launch_dense_to_segments(A.counts, A.nparts, A.count_stride, seg_rows, h->stream, A.per_dest ? A.dest_cap : nullptr));
     if (e1) (void)hipEventRecord(e1, h->stream);
     h->events.emplace_back(e0, e1);
     return N1K_OK;
@@ -305,6 +305,8 @@ struct n1k_comm {
     hipEvent_t ev_consumed = nullptr;   // on the receiving stream, behind the last kernel that reads send / recv
     bool consumed_pending = false;
     bool failure_broadcast = false;     // the last exchange failed on this rank before the collective and its peers were told
+    size_t sent_stride = 0;             // the last row exchange's regions in `send`: their distance and their capacities
+    std::vector<uint64_t> sent_cap;
     std::string last_error;
     uint64_t gather_cap = 1024;    // records per slot of n1k_gather_groups (the same on every rank, see there)
     std::vector<char> ghost;       // gathered records on the host
@@ -373,7 +375,9 @@ n1k_status all_gather_bytes(n1k_comm* c, const char* send, char* recv, size_t by
 // is how a rank whose own part failed takes part (void_regions): one region for every peer, one sink for what arrives.
 // Once the group is open it is always closed: no early return between ncclGroupStart and ncclGroupEnd.
 n1k_status all_to_all_regions(n1k_comm* c, const char* send, size_t send_stride, char* recv, size_t recv_stride, size_t region, hipStream_t st,
-                              const char** self) {
+                              const char** self, const size_t* send_bytes = nullptr) {
+    // send_bytes: the region for rank p is send_bytes[p] long (regions of per-destination capacities: every rank sizes the regions
+    // for destination p alike, so what this rank receives from everybody is `region` = send_bytes[its own rank] long)
     *self = send + (size_t)c->rank * send_stride;
     if (c->hub) {
         c->hub->stride[c->rank] = send_stride;  // (published with the pointer: read by the peers behind the first rendezvous)
@@ -391,7 +395,7 @@ n1k_status all_to_all_regions(n1k_comm* c, const char* send, size_t send_stride,
     ncclResult_t first = ncclSuccess;
     for (int p = 0; p < c->world; p++) {
         if (p == c->rank) continue;
-        ncclResult_t r = ncclSend(send + (size_t)p * send_stride, region, ncclChar, p, c->comm, st);
+        ncclResult_t r = ncclSend(send + (size_t)p * send_stride, send_bytes ? send_bytes[p] : region, ncclChar, p, c->comm, st);
         if (first == ncclSuccess) first = r;
         r = ncclRecv(recv + (size_t)p * recv_stride, region, ncclChar, p, c->comm, st);
         if (first == ncclSuccess) first = r;
@@ -496,7 +500,7 @@ n1k_status n1k_comm_create(const void* id, int rank, int world, int device, n1k_
         if (r != ncclSuccess) return bail(cfail(nullptr, N1K_DEVICE_ERROR, "ncclCommInitRank failed: %s", ncclGetErrorString(r)));
         if (hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_consumed, hipEventDisableTiming) != hipSuccess)
             return bail(cfail(nullptr, N1K_DEVICE_ERROR, "hipEventCreate failed"));
-        if (c->scalar.ensure(4) != hipSuccess) return bail(cfail(nullptr, N1K_OOM, "no device memory for the communicator"));  // (nothing of n1k_comm_max_u64 can fail before its collective)
+        if (c->scalar.ensure(2 * (size_t)kMaxParts) != hipSuccess) return bail(cfail(nullptr, N1K_OOM, "no device memory for the communicator"));  // (nothing of n1k_comm_max_u64 can fail before its collective)
         *out = c;
         return N1K_OK;
     });
@@ -703,7 +707,8 @@ bool batch_kinds_ok(const n1k_handle* h, const n1k_batch* b) {
     return true;
 }
 
-n1k_status exchange_rows_impl(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, uint64_t capacity_rows, n1k_status failed) {
+n1k_status exchange_rows_impl(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, const uint64_t* capacity_rows,
+                              n1k_status failed) {
     c->failure_broadcast = false;
     sender->failure_global = false;
     if (!sender->plan.has_group) return fail(sender, N1K_INVALID, "the row exchange partitions on group keys");
@@ -720,11 +725,23 @@ n1k_status exchange_rows_impl(n1k_comm* c, n1k_handle* sender, const n1k_batch* 
         st = fix_layout(sender, batch);  // (sets the column kinds first, then the key layout)
         if (st != N1K_OK && local == N1K_OK) local = st;
     }
-    const uint64_t cap = (capacity_rows + 16 * kRowSubs - 1) / (16 * kRowSubs) * (16 * kRowSubs);  // kRowSubs sub-regions of whole 16-row groups
-    if (cap >= (1ull << 31)) return fail(sender, N1K_INVALID, "row regions hold fewer than 2^31 rows");  // (the same on every rank)
-    std::vector<size_t> off_a, off_b;
-    const size_t region = row_region_layout(sender, cap, off_a, off_b);
+    // Every destination has its own capacity (the same vector on every rank): the regions for owner d — one per sender — are
+    // sized for what THAT owner receives, so a hot owner (skewed keys) does not inflate the regions of the other P - 1.
     const uint32_t P = (uint32_t)c->world;
+    const uint64_t quantum = 16ull * kRowSubs;  // kRowSubs sub-regions of whole 16-row groups
+    std::vector<uint64_t> cap(P);
+    uint64_t cap_max = 0;
+    for (uint32_t d = 0; d < P; d++) {
+        if (capacity_rows[d] == 0) return fail(sender, N1K_INVALID, "a region capacity of zero rows");  // (the same on every rank)
+        cap[d] = (capacity_rows[d] + quantum - 1) / quantum * quantum;
+        cap_max = std::max(cap_max, cap[d]);
+    }
+    if (cap_max >= (1ull << 31)) return fail(sender, N1K_INVALID, "row regions hold fewer than 2^31 rows");  // (the same on every rank)
+    std::vector<size_t> off_a, off_b, wire(P);
+    const size_t stride = row_region_layout(sender, cap_max, off_a, off_b);  // distance between the regions in the send buffer
+    for (uint32_t d = 0; d < P; d++) wire[d] = row_region_layout(sender, cap[d], off_a, off_b);
+    const uint64_t cap_me = cap[(uint32_t)c->rank];
+    const size_t region = row_region_layout(sender, cap_me, off_a, off_b);  // what this rank receives from every sender (off_*: its layout)
     const size_t header = (size_t)kRowSubs * kCursorStride * 8;
     st = wait_consumed(c, sender);
     if (st != N1K_OK && local == N1K_OK) local = fail(sender, st, "%s", c->last_error.c_str());
@@ -736,50 +753,54 @@ n1k_status exchange_rows_impl(n1k_comm* c, n1k_handle* sender, const n1k_batch* 
         s = prepare_receiver(sender, receiver);
         if (s != N1K_OK) return s;
         if (injected(sender, 1)) return fail(sender, N1K_OOM, "injected failure: buffers of the exchange");
-        HIP_TRY(sender, c->send.ensure(region * P));
+        HIP_TRY(sender, c->send.ensure(stride * P));
         HIP_TRY(sender, c->recv.ensure(region * P));
-        for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * region, 0, header, sender->stream));
+        for (uint32_t d = 0; d < P; d++) HIP_TRY(sender, hipMemsetAsync(c->send.p + (size_t)d * stride, 0, header, sender->stream));
         s = bind_columns(sender, batch, true);
         if (s != N1K_OK) return s;
         s = ensure_rank(sender);
         if (s != N1K_OK) return s;
         PartArgs A{};
         A.nrows = batch->nrows;
-        A.capacity = cap;
+        A.capacity = cap_max;
         A.nparts = P;
         A.ncopy = (uint32_t)sender->plan.paths.size();
         A.counts = (unsigned long long*)c->send.p;
-        A.count_stride = (uint32_t)(region / 8);
-        A.region_bytes = region;
-        A.sub_rows = cap / kRowSubs;
+        A.count_stride = (uint32_t)(stride / 8);
+        A.region_bytes = stride;
+        A.sub_rows = cap_max / kRowSubs;
+        A.per_dest = 1;
+        A.hdr_bytes = (uint32_t)header;
+        for (uint32_t d = 0; d < P; d++) A.dest_cap[d] = (uint32_t)cap[d];
         A.err_flags = sender->d_errp;
-        for (uint32_t i = 0; i < A.ncopy; i++) {
-            if (sender->col_kinds[i] == N1K_COL_DICT32) A.out_codes[i] = (uint32_t*)(c->send.p + off_a[i]);
-            else {
-                A.out_payload[i] = (uint64_t*)(c->send.p + off_a[i]);
-                A.out_tags[i] = (uint8_t*)(c->send.p + off_b[i]);
-            }
-        }
         s = run_partition(sender, batch, A);
         if (s != N1K_OK) return s;
         if (injected(sender, 2)) return fail(sender, N1K_DEVICE_ERROR, "injected failure: the partition");
         sender->stats.rows_in += batch->nrows;
         sender->stats.batches += 1;
         // what the partition itself found (rows whose key does not pack, values the Filter cannot order) joins the verdicts
-        HIP_TRY(sender, launch_stamp_verdict((unsigned long long*)c->send.p, P, region / 8, sender->d_errp, 0, sender->stream));
+        HIP_TRY(sender, launch_stamp_verdict((unsigned long long*)c->send.p, P, stride / 8, sender->d_errp, 0, sender->stream));
         return N1K_OK;
     };
     if (local == N1K_OK) local = local_part();
+    c->sent_stride = stride;
+    c->sent_cap = cap;
     // 2. ONE all-to-all, always: counts, verdicts and rows of every column travel in the same region
     const char* send = c->send.p;
     char* recv = c->recv.p;
-    size_t sstride = region, rstride = region;
+    size_t sstride = stride, rstride = region;
     if (local != N1K_OK) {
-        st = void_regions(c, sender, region, header, P, P, local, &send, &sstride, &recv, &rstride, false);
-        if (st != N1K_OK) return local;  // (not even one region: the peers are not told — see the comment above)
+        c->sent_cap.clear();
+        if (c->send.n >= stride * P && c->recv.n >= region * P) {
+            for (uint32_t d = 0; d < P; d++) (void)hipMemsetAsync(c->send.p + (size_t)d * stride, 0, header, sender->stream);
+            (void)launch_stamp_verdict((unsigned long long*)c->send.p, P, stride / 8, nullptr, (uint32_t)local, sender->stream);
+        } else {
+            st = void_regions(c, sender, stride, header, 1, 1, local, &send, &sstride, &recv, &rstride, false);
+            if (st != N1K_OK) return local;  // (not even one region: the peers are not told — see the comment above)
+        }
     }
     const char* self = nullptr;
-    st = all_to_all_regions(c, send, sstride, recv, rstride, region, sender->stream, &self);
+    st = all_to_all_regions(c, send, sstride, recv, rstride, region, sender->stream, &self, wire.data());
     if (local != N1K_OK) {
         c->failure_broadcast = st == N1K_OK;
         sender->failure_global = st == N1K_OK;
@@ -811,12 +832,12 @@ n1k_status exchange_rows_impl(n1k_comm* c, n1k_handle* sender, const n1k_batch* 
             }
         }
         n1k_batch rb{};
-        rb.nrows = cap;
+        rb.nrows = cap_me;
         rb.ncols = rnc;
         rb.cols = cols.data();
         receiver->push_seg_counts = (const unsigned long long*)src[sidx];  // (the region's header)
         receiver->push_nseg = kRowSubs;
-        receiver->push_seg_rows = cap / kRowSubs;
+        receiver->push_seg_rows = cap_me / kRowSubs;
         st = push_device(receiver, &rb);
         receiver->push_seg_counts = nullptr;
         receiver->push_nseg = 0;
@@ -831,6 +852,33 @@ n1k_status exchange_rows_impl(n1k_comm* c, n1k_handle* sender, const n1k_batch* 
 
 }  // namespace
 
+n1k_status n1k_comm_max_u64_v(n1k_comm* c, n1k_handle* h, uint32_t n, const uint64_t* values, uint64_t* out) {
+    return guarded(h, [&]() -> n1k_status {
+        if (!c || !h || !values || !out || n == 0 || n > kMaxParts) return N1K_INVALID;
+        n1k_status st = ensure_device(h);
+        if (st != N1K_OK) return st;
+        if (c->hub) {  // loopback: values through the hub, one at a time
+            for (uint32_t i = 0; i < n; i++) {
+                c->hub->val[c->rank] = values[i];
+                c->hub->barrier();
+                unsigned long long mx = 0;
+                for (int p = 0; p < c->world; p++) mx = std::max(mx, c->hub->val[p]);
+                c->hub->barrier();
+                out[i] = mx;
+            }
+            return N1K_OK;
+        }
+        HIP_TRY(h, c->scalar.ensure(2 * (size_t)kMaxParts));
+        std::vector<unsigned long long> m(n);
+        HIP_TRY(h, hipMemcpyAsync(c->scalar.p, values, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+        NCCL_TRY(c, ncclAllReduce(c->scalar.p, c->scalar.p + kMaxParts, n, ncclUint64, ncclMax, c->comm, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(m.data(), c->scalar.p + kMaxParts, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (uint32_t i = 0; i < n; i++) out[i] = m[i];
+        return N1K_OK;
+    });
+}
+
 n1k_status n1k_exchange_partials(n1k_comm* c, n1k_handle* sender, n1k_handle* receiver, uint64_t capacity_groups, int gathered) {
     return guarded(sender, [&]() -> n1k_status {
         if (!c || !sender || !receiver || capacity_groups == 0) return N1K_INVALID;
@@ -838,10 +886,38 @@ n1k_status n1k_exchange_partials(n1k_comm* c, n1k_handle* sender, n1k_handle* re
     });
 }
 
-n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, uint64_t capacity_rows) {
+n1k_status n1k_exchange_rows_v(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, const uint64_t* capacity_rows) {
     return guarded(sender, [&]() -> n1k_status {
-        if (!c || !sender || !receiver || capacity_rows == 0) return N1K_INVALID;
+        if (!c || !sender || !receiver || !capacity_rows) return N1K_INVALID;
         return exchange_rows_impl(c, sender, batch, receiver, capacity_rows, N1K_OK);
+    });
+}
+
+n1k_status n1k_exchange_rows(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, uint64_t capacity_rows) {
+    if (!c || capacity_rows == 0) return N1K_INVALID;
+    const std::vector<uint64_t> caps((size_t)c->world, capacity_rows);
+    return n1k_exchange_rows_v(c, sender, batch, receiver, caps.data());
+}
+
+// rows this rank's last n1k_exchange_rows wrote for every destination (its own included): what the ranks size the regions of
+// the following steps from (the largest over the senders, per destination: n1k_comm_max_u64_v)
+n1k_status n1k_exchange_sent_rows(n1k_comm* c, n1k_handle* sender, uint64_t* out) {
+    return guarded(sender, [&]() -> n1k_status {
+        if (!c || !sender || !out) return N1K_INVALID;
+        const uint32_t P = (uint32_t)c->world;
+        if (c->sent_cap.size() != P || !c->send.p) return fail(sender, N1K_INVALID, "no completed row exchange on this communicator");
+        std::vector<unsigned long long> hdr((size_t)P * kRowSubs * kCursorStride);
+        for (uint32_t d = 0; d < P; d++)
+            HIP_TRY(sender, hipMemcpyAsync(hdr.data() + (size_t)d * kRowSubs * kCursorStride, c->send.p + (size_t)d * c->sent_stride,
+                                           (size_t)kRowSubs * kCursorStride * 8, hipMemcpyDeviceToHost, sender->stream));
+        HIP_TRY(sender, hipStreamSynchronize(sender->stream));
+        for (uint32_t d = 0; d < P; d++) {
+            uint64_t n = 0;
+            for (uint32_t x = 0; x < kRowSubs; x++)
+                n += std::min<uint64_t>(hdr[((size_t)d * kRowSubs + x) * kCursorStride], c->sent_cap[d] / kRowSubs);
+            out[d] = n;
+        }
+        return N1K_OK;
     });
 }
 
@@ -867,7 +943,14 @@ static n1k_status finish_and_gather(n1k_comm* c, n1k_status st, n1k_handle* rece
 
 n1k_status n1k_rows_step(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, n1k_handle* merger,
                          uint64_t capacity_rows, n1k_result* out, int* worst_status) {
-    if (!c || !sender || !batch || !receiver || !merger || !out || !worst_status || capacity_rows == 0) return N1K_INVALID;
+    if (!c || capacity_rows == 0) return N1K_INVALID;
+    const std::vector<uint64_t> caps((size_t)c->world, capacity_rows);
+    return n1k_rows_step_v(c, sender, batch, receiver, merger, caps.data(), out, worst_status);
+}
+
+n1k_status n1k_rows_step_v(n1k_comm* c, n1k_handle* sender, const n1k_batch* batch, n1k_handle* receiver, n1k_handle* merger,
+                           const uint64_t* capacity_rows, n1k_result* out, int* worst_status) {
+    if (!c || !sender || !batch || !receiver || !merger || !out || !worst_status || !capacity_rows) return N1K_INVALID;
     *worst_status = N1K_OK;
     n1k_status st = n1k_reset(receiver);
     if (st == N1K_OK) st = n1k_reset(sender);  // (the sender holds no groups in this mode; its counters and timers start over)

@@ -99,7 +99,8 @@ struct HeaderList { unsigned long long* h[kMaxParts]; };  // the headers of the 
 hipError_t launch_exchange_verdict(const HeaderList& H, uint32_t nregions, uint32_t* err_flags, hipStream_t st);
 hipError_t launch_stamp_verdict(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, const uint32_t* err_flags,
                                 uint32_t host_status, hipStream_t st);
-hipError_t launch_dense_to_segments(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows, hipStream_t st);
+hipError_t launch_dense_to_segments(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows, hipStream_t st,
+                                    const uint32_t* dest_cap = nullptr);  // dest_cap: regions of their own capacities (PartArgs::per_dest)
 struct SpecEntry {
     const char* name;
     SpecSig sig;

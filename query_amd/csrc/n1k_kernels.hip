@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
         for (int j = 0; j < R; j++) {
             if (!pass[j]) continue;
             uint64_t r = s_base[dest[j]] + pos[j];
-            if (r >= A.capacity) {
+            if (r >= (A.per_dest ? (uint64_t)A.dest_cap[dest[j]] : A.capacity)) {
                 if (!(atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL) & ERR_TABLE_FULL) && A.region_bytes)
                     for (uint32_t q = 0; q < A.nparts; q++)  // every receiver reads the verdict in the header it gets
                         atomicOr(&A.counts[(size_t)q * A.count_stride + 1], 1ull);
@@ -1337,6 +1337,9 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
         __syncthreads();
         for (uint32_t d = tid; d < A.nparts; d += BLOCK) s_cnt[d] = 0;
         // (the next tile's first barrier orders this reset before its counters are read)
+        uint64_t roff[R];  // per_dest: where the next array of the row's region starts
+#pragma unroll
+        for (int j = 0; j < R; j++) roff[j] = A.hdr_bytes;
         for (uint32_t c = 0; c < A.ncopy; c++) {
             Operand o{};
             o.is_const = 0;
@@ -1347,6 +1350,20 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const Program P, const
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 if (!pass[j]) continue;
+                if (A.per_dest) {  // the region is laid out for its own destination's capacity
+                    char* const reg = (char*)A.counts + (size_t)dest[j] * A.region_bytes;
+                    const uint64_t capd = A.dest_cap[dest[j]];
+                    if (P.cols[c].kind == COLK_DICT32) {
+                        ((uint32_t*)(reg + roff[j]))[pos[j]] = (uint32_t)vp[j];
+                        roff[j] = part_region_next(roff[j], capd, 4);
+                    } else {
+                        ((uint64_t*)(reg + roff[j]))[pos[j]] = vp[j];
+                        roff[j] = part_region_next(roff[j], capd, 8);
+                        ((uint8_t*)(reg + roff[j]))[pos[j]] = (uint8_t)vt[j];
+                        roff[j] = part_region_next(roff[j], capd, 1);
+                    }
+                    continue;
+                }
                 const size_t shift = (size_t)dest[j] * A.region_bytes;  // (0 without packed regions)
                 if (P.cols[c].kind == COLK_DICT32) {
                     ((uint32_t*)((char*)A.out_codes[c] + shift))[pos[j]] = (uint32_t)vp[j];
@@ -3153,20 +3170,28 @@ hipError_t launch_stamp_verdict(unsigned long long* headers, uint32_t nregions, 
 
 // A region written as ONE dense run of header[0] rows (the interpreting partition kernel; small batches) read as kRowSubs
 // segments of sub_rows rows: the first ones full, then a partial one, then empty ones.
-__global__ void dense_to_segments_kernel(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows) {
+struct DestCaps { uint32_t per_dest, cap[kMaxParts]; };
+__global__ void dense_to_segments_kernel(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows, const DestCaps C) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nregions * kRowSubs) return;
     unsigned long long* h = headers + (size_t)(i / kRowSubs) * stride_words;
     const uint32_t x = i % kRowSubs;
+    if (C.per_dest) sub_rows = C.cap[i / kRowSubs] / kRowSubs;
     const unsigned long long total = h[0];
     __syncthreads();  // (a region's kRowSubs threads sit in one workgroup: everybody has read the total before word 0 changes)
     const unsigned long long lo = (unsigned long long)x * sub_rows;
     h[(size_t)x * kCursorStride] = total <= lo ? 0ull : (total - lo < sub_rows ? total - lo : sub_rows);
 }
 
-hipError_t launch_dense_to_segments(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows, hipStream_t st) {
+hipError_t launch_dense_to_segments(unsigned long long* headers, uint32_t nregions, uint64_t stride_words, uint64_t sub_rows, hipStream_t st,
+                                    const uint32_t* dest_cap) {
     const uint32_t n = nregions * kRowSubs;
-    hipLaunchKernelGGL(dense_to_segments_kernel, dim3((n + 63) / 64), dim3(64), 0, st, headers, nregions, stride_words, sub_rows);
+    DestCaps C{};
+    if (dest_cap) {
+        C.per_dest = 1;
+        for (uint32_t d = 0; d < nregions && d < kMaxParts; d++) C.cap[d] = dest_cap[d];
+    }
+    hipLaunchKernelGGL(dense_to_segments_kernel, dim3((n + 63) / 64), dim3(64), 0, st, headers, nregions, stride_words, sub_rows, C);
     return hipGetLastError();
 }
 

@@ -446,11 +446,24 @@ struct PartArgs {
     // dense run per destination.
     uint32_t nsub;
     uint64_t sub_rows;
+    // Regions of DIFFERENT capacities (per_dest: the row exchange under skew — every destination's regions are sized for what
+    // THAT owner receives, so that a hot owner does not inflate the other P - 1 regions of every sender): region d still starts
+    // d * region_bytes into the send buffer, but is laid out for dest_cap[d] rows (a multiple of 16 * nsub): a header of
+    // hdr_bytes, then per input column its arrays, each padded to 16 bytes (part_region_next below; the host's
+    // row_region_layout).  capacity / sub_rows / out_* are not used then.
+    uint32_t per_dest, hdr_bytes;
+    uint32_t dest_cap[kMaxParts];
     uint32_t* err_flags;
     uint8_t* out_tags[kMaxCols];
     uint64_t* out_payload[kMaxCols];
     uint32_t* out_codes[kMaxCols];
 };
+
+// a region's arrays, one after the other: the array of `width`-byte elements that starts at `off` ends at the next 16-byte boundary
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+__host__ __device__
+#endif
+inline uint64_t part_region_next(uint64_t off, uint64_t cap, uint32_t width) { return (off + cap * width + 15ull) / 16ull * 16ull; }
 
 // compile-time shape of a plan handled by scan_spec_kernel (see n1k_spec.h)
 struct SpecTerm {

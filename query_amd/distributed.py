@@ -114,6 +114,7 @@ class ShardedFilterGroup:
         self.partial_capacity = None  # groups per region: agreed on in the first step
         self.row_capacity = None      # rows per region
         self._first_row_capacity = None
+        self._caps, self._caps_agreed = None, False  # per-destination capacities agreed after the first step
         self._sbatch = None
 
     GATHER_LIMIT = 32 << 20  # partial groups of ALL ranks within this many bytes per rank: all-gather them
@@ -187,33 +188,45 @@ class ShardedFilterGroup:
 
     # ------------------------------------------------------------------ exchange of rows
     def run_rows(self, nrows: int, cols_by_path: Dict[str, tuple]) -> Tuple[dict, dict]:
-        """n1k_exchange_rows: Filter + hash partition + ONE all-to-all + InitialGroup on the owner, then the gather.  The
-        first step ships regions sized for the whole shard; later steps for what the owners really received (+ 10 %)."""
+        """n1k_rows_step_v: Filter + hash partition + ONE all-to-all + InitialGroup on the owner, then the gather.  The first step
+        ships regions sized for the whole shard; from then on every DESTINATION has its own capacity: what the sender that sends
+        it most really wrote for it (+ 10 %) — under skewed keys the hot owner's regions grow, the other world - 1 stay small."""
         from query_amd import _ffi
-        from query_amd.gpu_operator import N1kError
         snd, rcv, lib = self.sender, self.receiver, self.sender._lib
         batch = self._batch(nrows, cols_by_path)
-        if self.row_capacity is None and self._first_row_capacity is None:
-            # the regions of one all-to-all have ONE size on every rank: the first step sizes them from the LARGEST shard
+        W = self.world
+        if self.row_capacity is None and self._caps is None and self._first_row_capacity is None:
+            # the regions for one destination have ONE size on every rank: the first step sizes them from the LARGEST shard
             # (shards differ by a row under strong scaling; found by the loopback test — RCCL would have hung on it)
-            self._first_row_capacity = max(4096, int(self._max(snd, nrows) * 1.1 / self.world) + 4096)
+            self._first_row_capacity = max(4096, int(self._max(snd, nrows) * 1.1 / W) + 4096)
         out, worst = _ffi.Result(), C.c_int(0)
+        fixed = self.row_capacity is not None  # (a caller's own capacity — an int or one per destination — is kept as it is)
         while True:
-            cap = self.row_capacity if self.row_capacity is not None else self._first_row_capacity
-            # n1k_rows_step: both resets, the exchange, the owner's n1k_finish and the gather in ONE call through the ABI
-            st = int(lib.n1k_rows_step(self.comm._h, snd._h, C.byref(batch[0]), rcv._h, self.merger._h, cap, C.byref(out), C.byref(worst)))
-            if st == _ffi.REGION_FULL:
-                self.row_capacity = cap * 2  # (a region overflowed: on every rank alike, no gather took place)
+            if fixed:
+                caps = [int(self.row_capacity)] * W if isinstance(self.row_capacity, (int, np.integer)) else [int(x) for x in self.row_capacity]
+            else:
+                caps = self._caps if self._caps is not None else [self._first_row_capacity] * W
+            arr = (C.c_uint64 * W)(*caps)
+            # n1k_rows_step_v: both resets, the exchange, the owner's n1k_finish and the gather in ONE call through the ABI
+            st = int(lib.n1k_rows_step_v(self.comm._h, snd._h, C.byref(batch[0]), rcv._h, self.merger._h, arr, C.byref(out), C.byref(worst)))
+            if st == _ffi.REGION_FULL:  # (a region overflowed: on every rank alike, no gather took place)
+                if fixed:
+                    self.row_capacity = [c * 2 for c in caps]
+                else:
+                    self._caps = [c * 2 for c in caps]
                 continue
             break
-        if self.row_capacity is None and st == _ffi.OK and worst.value == 0:  # (a failed step is known as such on every rank)
-            got = self._max(rcv, int(rcv.stats()["rows_selected"]))
-            # `got` is the LARGEST owner's total, and every source sees the same split of the keys over the owners: a source's
-            # region for that owner holds about got / world rows (+ 10 %: shards are not identical; an overflow doubles it)
-            self.row_capacity = min(cap, max(4096, int(got / self.world * 1.1) + 4096)) if self.world > 1 else max(4096, int(got * 1.02) + 4096)
+        if not fixed and not self._caps_agreed and st == _ffi.OK and worst.value == 0:  # (a failed step is known as such on every rank)
+            sent = (C.c_uint64 * W)()
+            snd._check(lib.n1k_exchange_sent_rows(self.comm._h, snd._h, sent))
+            most = (C.c_uint64 * W)()
+            snd._check(lib.n1k_comm_max_u64_v(self.comm._h, snd._h, W, sent, most))
+            slack = 1.1 if W > 1 else 1.02  # (shards are not identical; an overflow doubles the capacities)
+            self._caps = [min(caps[d], max(4096, int(int(most[d]) * slack) + 4096)) for d in range(W)]
+            self._caps_agreed = True
         self._raise(st, worst.value, (rcv, snd, self.merger))
         stats = snd.stats()
-        return self._result_dict(out), {"mode": "rows", "region_rows": cap, "scan_ms": float(stats["device_ms"]),
+        return self._result_dict(out), {"mode": "rows", "region_rows": list(caps), "scan_ms": float(stats["device_ms"]),
                                         "recv_rows": int(rcv.stats()["rows_selected"])}
 
     @staticmethod
@@ -318,6 +331,16 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                 "low-cardinality keys); not the reported value"}
         except Exception as e:  # never costs the headline line
             ablation = {"error": repr(e)[:200]}
+    # skew: what every owner received in the last step, and the per-destination capacities the ranks agreed on
+    share = None
+    if info.get("mode") == "rows":
+        mine = torch.tensor([int(info.get("recv_rows", 0))], dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        got = [int(x.item()) for x in every]
+        mean = sum(got) / max(1, world)
+        share = {"recv_rows": got, "largest_over_mean": (max(got) / mean) if mean else None, "region_rows": info.get("region_rows"),
+                 "what": "rows every owner received in the last step; region capacities are per destination (a hot owner's regions alone grow)"}
     if rank == 0:
         how = {"gathered partials": "per-GPU partial groups merged after ONE RCCL all-gather (every rank holds the result)",
                "partials": "partial groups hash-partitioned on the group key by ONE RCCL all-to-all, final groups all-gathered",
@@ -355,6 +378,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                "ms": info.get("scan_ms"),
                                "what": "partition kernel (Filter + hash partition of the shard)" if info.get("mode", "").startswith("rows")
                                else "scan kernel of the shard"}}}
+        if share is not None:
+            out["owner_share"] = share
         if ablation is not None:
             out["ablation_partial_groups"] = ablation
         if not args.no_cpu:
