@@ -26,7 +26,7 @@ static n1k_status run_partition(n1k_handle* h, const n1k_batch* b, PartArgs& A) 
     if (h->opt_spec && h->opt_jit && (h->opt_jit == 2 || n >= h->opt_jit_min_rows) && n < (1ull << 31) && (!fuse || h->opt_fuse_arith) &&
         sizeof(Program) + sizeof(FastArgs) + sizeof(PartArgs) + 64 <= 4096 && build_fast_args(h, 1u << 15, F, fuse, true)) {
         // what the staging needs in LDS (n1k_spec.h PartLds: 2048 rows x (9 B per TAGGED64 column, 4 B per DICT32 column, 1))
-        size_t lds = 2048 + 2048;
+        size_t lds = 2048 + 2048 + 4096;  // (+ the per-destination tables of PartLds)
         for (uint32_t c = 0; c < F.ncols; c++) lds += 2048u * (F.cols[c].kind == COLK_DICT32 ? 4u : 9u);
         if (lds <= 60 * 1024) {
             SpecSig sig = make_plan_sig(h, F);
@@ -769,9 +769,25 @@ n1k_status exchange_rows_impl(n1k_comm* c, n1k_handle* sender, const n1k_batch* 
         A.count_stride = (uint32_t)(stride / 8);
         A.region_bytes = stride;
         A.sub_rows = cap_max / kRowSubs;
-        A.per_dest = 1;
+        bool uniform = true;
+        for (uint32_t d = 0; d < P; d++) uniform &= cap[d] == cap_max;
         A.hdr_bytes = (uint32_t)header;
-        for (uint32_t d = 0; d < P; d++) A.dest_cap[d] = (uint32_t)cap[d];
+        if (uniform) {
+            // every destination alike (uniform keys; one rank): the kernels' plain addressing — one layout, region d a whole number
+            // of strides further on — which spares them the per-destination tables (0.43 against 0.46 ms per 100 M rows)
+            std::vector<size_t> oa, ob;
+            (void)row_region_layout(sender, cap_max, oa, ob);
+            for (uint32_t i = 0; i < A.ncopy; i++) {
+                if (sender->col_kinds[i] == N1K_COL_DICT32) A.out_codes[i] = (uint32_t*)(c->send.p + oa[i]);
+                else {
+                    A.out_payload[i] = (uint64_t*)(c->send.p + oa[i]);
+                    A.out_tags[i] = (uint8_t*)(c->send.p + ob[i]);
+                }
+            }
+        } else {
+            A.per_dest = 1;
+            for (uint32_t d = 0; d < P; d++) A.dest_cap[d] = (uint32_t)cap[d];
+        }
         A.err_flags = sender->d_errp;
         s = run_partition(sender, batch, A);
         if (s != N1K_OK) return s;

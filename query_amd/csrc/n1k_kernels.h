@@ -134,7 +134,7 @@ hipError_t launch_filter_compact(const uint64_t* mask_words, const uint64_t* til
 // last one the tile counter; zeroed here)
 hipError_t launch_filter_stream(const Program& P, uint64_t nrows, uint64_t row_base, uint64_t* out_rows, unsigned long long* tile_state,
                                 unsigned long long* tile_counter, unsigned long long* total, uint32_t* err_flags, uint32_t grid,
-                                hipStream_t st);
+                                hipStream_t st, bool fast = false);  // fast: ONE TERM_NUM_* comparison of a TAGGED64 column, wide loads
 // ---- raw JSON documents -> leaf columns on the device (n1k_jsondev.hip)
 constexpr uint32_t kJsonMaxSteps = 4;  // field names of a leaf path below the keyspace alias
 struct JsonDevPath {

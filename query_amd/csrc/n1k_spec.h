@@ -515,7 +515,10 @@ struct PartLds {
     uint32_t cnt[2][64];  // survivors per destination in this tile (the other copy is zeroed for the next tile)
     uint32_t pre[64];     // first staged position of the destination
     unsigned long long gbase[64];  // first row of the tile's run in the destination's region
-    uint32_t dcap[64];             // rows a region of the destination holds (PartArgs::per_dest)
+    // PartArgs::per_dest, per destination: rows a sub-region holds, and where the region's arrays start (payload / codes, then
+    // tags, of every column) — worked out once per workgroup, not per row
+    uint32_t dsub[64];
+    uint64_t doff[2 * (spec_ncols_of<Spec>(COLK_TAGGED64) + spec_ncols_of<Spec>(COLK_DICT32)) ? 2 * (spec_ncols_of<Spec>(COLK_TAGGED64) + spec_ncols_of<Spec>(COLK_DICT32)) : 1][64];
     uint32_t total;
 };
 
@@ -530,7 +533,21 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
     __shared__ PartLds<Spec, TILE> S;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t i = tid; i < 128; i += BLOCK) (&S.cnt[0][0])[i] = 0;
-    if (tid < 64) S.dcap[tid] = A.per_dest ? A.dest_cap[tid] : 0u;
+    if (tid < 64 && A.per_dest) {
+        const uint64_t capd = A.dest_cap[tid];
+        S.dsub[tid] = (uint32_t)(capd / (A.nsub > 1u ? A.nsub : 1u));
+        uint64_t off = A.hdr_bytes;
+#pragma unroll
+        for (int c = 0; c < Spec::ncols; c++) {
+            S.doff[2 * c][tid] = off;
+            if (Spec::col_kind[c] == COLK_DICT32) off = part_region_next(off, capd, 4);
+            else {
+                off = part_region_next(off, capd, 8);
+                S.doff[2 * c + 1][tid] = off;
+                off = part_region_next(off, capd, 1);
+            }
+        }
+    }
     __syncthreads();
     uint32_t par = 0, unpackable = 0;
     const uint32_t nrows = F.nrows;
@@ -629,8 +646,7 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
         for (uint32_t q = tid; q < staged; q += BLOCK) {
             const uint32_t d = S.sdest[q];
             const unsigned long long r = S.gbase[d] + (q - S.pre[d]);
-            const uint64_t capd = S.dcap[d];  // (per_dest: this destination's own capacity)
-            if (r >= (A.per_dest ? capd / nsub : sub_cap)) {
+            if (r >= (A.per_dest ? (uint64_t)S.dsub[d] : sub_cap)) {  // (per_dest: this destination's own capacity)
                 if (!(atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL) & ERR_TABLE_FULL) && A.region_bytes)
                     for (uint32_t z = 0; z < nparts; z++)  // every receiver reads the verdict in the header it gets
                         atomicOr(&A.counts[(size_t)z * A.count_stride + 1], 1ull);
@@ -638,18 +654,13 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
             }
             if (A.per_dest) {
                 char* const reg = (char*)A.counts + (size_t)d * A.region_bytes;
-                const uint64_t at = (uint64_t)sub * (capd / nsub) + r;
-                uint64_t off = A.hdr_bytes;
+                const uint64_t at = (uint64_t)sub * S.dsub[d] + r;
 #pragma unroll
                 for (int c = 0; c < Spec::ncols; c++) {
-                    if (Spec::col_kind[c] == COLK_DICT32) {
-                        ((uint32_t*)(reg + off))[at] = S.code[spec_col_slot<Spec>(c)][q];
-                        off = part_region_next(off, capd, 4);
-                    } else {
-                        ((uint64_t*)(reg + off))[at] = S.pay[spec_col_slot<Spec>(c)][q];
-                        off = part_region_next(off, capd, 8);
-                        ((uint8_t*)(reg + off))[at] = S.tag[spec_col_slot<Spec>(c)][q];
-                        off = part_region_next(off, capd, 1);
+                    if (Spec::col_kind[c] == COLK_DICT32) ((uint32_t*)(reg + S.doff[2 * c][d]))[at] = S.code[spec_col_slot<Spec>(c)][q];
+                    else {
+                        ((uint64_t*)(reg + S.doff[2 * c][d]))[at] = S.pay[spec_col_slot<Spec>(c)][q];
+                        ((uint8_t*)(reg + S.doff[2 * c + 1][d]))[at] = S.tag[spec_col_slot<Spec>(c)][q];
                     }
                 }
                 continue;
