@@ -315,7 +315,8 @@ def roofline_of(wl: dict, rows: int, st: dict, workload: str, kcat: int, opts) -
                 nq = c.get("queries") or min(v["dispatches"] for k, v in c["FETCH_SIZE"].items() if "scan_spec" in k or "n1k_jit" in k)
                 tot = 0.0
                 for k, v in c["FETCH_SIZE"].items():
-                    if "synth_kernel" in k:
+                    # (not the query's: the data generator, and the Filter-only count bench.py checks the survivors against)
+                    if "synth_kernel" in k or ("filter_" in k and workload != "filter"):
                         continue
                     w = c["WRITE_SIZE"].get(k, {"avg_KB": 0.0})
                     tot += 1024.0 * (2.0 * v["avg_KB"] + w["avg_KB"]) * v["dispatches"] / nq
