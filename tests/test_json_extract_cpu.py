@@ -219,3 +219,42 @@ def test_random_documents_match_the_python_extraction(seed):
         for r, (x, y) in enumerate(zip(g, e)):
             assert x == y, (paths[c], r, raw[r], x, y)
     op.done()
+
+
+def test_synth_documents_round_trip_through_the_extractor():
+    """n1k_synth_documents (bench / test input: the synthetic rows as raw JSON documents) and n1k_extract_json are inverse to
+    each other on the rows' leaf values: MISSING leaves the field out, NULL prints null, floats print their shortest
+    round-trip digits (strconv.FormatFloat(f, 'f', -1, 64), value/float.go:31-48), integers their own text."""
+    import ctypes as C
+    n = 30_000
+    t = n1o.synth_table(n, k_cat=50)
+    by = {c.name: c for c in t.columns}
+    cat, price, user, region = by[D("cat")], by[D("price")], by[D("user_id")], by[D("region_id")]
+    blob = np.empty(n * 260, dtype=np.uint8)
+    offsets = np.empty(n + 1, dtype=np.uint64)
+    used = C.c_size_t(0)
+    lib = _ffi.lib()
+    codes = np.ascontiguousarray(cat.codes)
+    st = lib.n1k_synth_documents(n, 7, codes.ctypes.data, price.tags.ctypes.data, price.payload.ctypes.data, user.payload.ctypes.data,
+                                 region.payload.ctypes.data, 33, blob.ctypes.data, blob.size, offsets.ctypes.data, C.byref(used))
+    assert st == _ffi.OK and int(offsets[n]) == used.value
+    assert lib.n1k_synth_documents(n, 7, codes.ctypes.data, price.tags.ctypes.data, price.payload.ctypes.data, user.payload.ctypes.data,
+                                   region.payload.ctypes.data, 33, blob.ctypes.data, 1000, offsets.ctypes.data, C.byref(used)) == _ffi.OOM
+    raw = blob.tobytes()
+    docs = [raw[int(offsets[i]):int(offsets[i + 1])] for i in range(n)]
+    first = json.loads(docs[0])
+    assert first["id"] == "d7" and first["pad"] == "x" * 33
+    op = query_amd.GpuFilterGroup(plan.filter_group_plan(None, [D("cat")], sorted(["sum(%s)" % D("price"), "max(%s)" % D("user_id"), "min(%s)" % D("region_id")])))
+    cols = dict(zip(op.column_paths, op.extract_json(docs)))
+    # price: tags and payload bits exactly (the text round-trips every float); the "n/a" strings by their bytes
+    pt, pp = cols[D("price")]["tags"], cols[D("price")]["payload"]
+    assert np.array_equal(pt, price.tags)
+    num = (price.tags == n1o.T_INT) | (price.tags == n1o.T_FLOAT)
+    assert np.array_equal(pp[num], price.payload[num])
+    assert all(op.dict_get(int(c)) == b"n/a" for c in pp[price.tags == n1o.T_STRING][:50])
+    assert np.array_equal(cols[D("user_id")]["payload"], user.payload) and np.array_equal(cols[D("region_id")]["payload"], region.payload)
+    ct, cp = cols[D("cat")]["tags"], cols[D("cat")]["payload"]
+    assert np.array_equal(ct == n1o.T_MISSING, codes == 0xFFFFFFFF) and np.array_equal(ct == n1o.T_NULL, codes == 0xFFFFFFFE)
+    for i in np.flatnonzero(ct == n1o.T_STRING)[:200]:
+        assert op.dict_get(int(cp[i])) == b"cat_%d" % codes[i]
+    op.done()
