@@ -7,6 +7,8 @@
 // exchange take.  Reference: execution/group_initial.go:56-100 (one map per operator copy; here one LDS table per bin).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "n1k_kernels.h"
 #include "n1k_spec.h"
 
@@ -176,124 +178,269 @@ __device__ __forceinline__ void emit_single(const Program& P, const BinAggArgs& 
 
 // One workgroup per bin (persistent over bins): InitialGroup over the bin's records in an LDS table, whose groups are
 // appended to the compact region ([count][0][keys: emit_cap][accumulators]).  The table is initialised once; every slot
-// a bin used is reset as it is emitted.  U records per thread are loaded before any is processed.
-template <int BLOCK, int U>
+// a bin used is reset as it is emitted.
+//
+// The next chunk (BLOCK x U records) is requested before the current one is processed, across the ends of bins too.  Every
+// load is issued unconditionally — beyond its bin a thread re-reads the first record and drops it — and what was loaded is
+// not looked at until the copy at the head of the loop: with predicated loads, or a first chunk loaded straight into the
+// registers the loop works on, the compiler waits for everything outstanding (s_waitcnt vmcnt(0)) — the prefetch it has
+// just issued included — before the first record of every chunk.  The record counts of the workgroup's bins sit in LDS
+// before the loop (read from global memory when the walk reached a bin, each was one exposed memory latency).
+// Measured at 100 M records in 32 Ki bins: 0.60 ms, of which 0.43 ms with the records loaded but not looked at; a third
+// chunk in flight (three buffers, the loop unrolled three times) did not help (0.62 ms).
+// KIND >= 0: the plan has ONE aggregate and this is its kind — the accumulate step is then straight-line code.  The thread's
+// U records walk the table TOGETHER (one LDS wait per round of probes).  Records that cannot enter the table (it is full; an
+// integer the narrow LDS sum does not take) are rare: they are only marked, and leave as partial groups of their own from
+// ONE copy of that code.
+constexpr uint32_t kAggOwnBins = 256;  // bins per workgroup of agg_bins16_kernel, at most
+
+template <int BLOCK, int U, int KIND>
 __global__ __launch_bounds__(BLOCK) void agg_bins16_kernel(const Program P, const BinAggArgs A) {
     extern __shared__ uint64_t lds[];
-    __shared__ uint32_t lds_fill, emit_n;
+    __shared__ unsigned long long own_count[kAggOwnBins];  // (the launch gives every workgroup at most that many bins)
+    __shared__ uint32_t lds_fill;
     __shared__ unsigned long long emit_base;
     const uint32_t S = A.lds_slots, tid = threadIdx.x;
+    uint16_t* const slot_list = (uint16_t*)(lds + (size_t)S * P.lds_words);  // the slots the bin's groups took, in the order they came
     const Rec16* const rec = (const Rec16*)A.rec;
     const uint32_t cstride = A.bin_count_stride ? A.bin_count_stride : 1u;
+    const uint32_t own = blockIdx.x < A.nbins ? (A.nbins - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;  // bins blockIdx.x + i * gridDim.x
+    for (uint32_t i = tid; i < own && i < kAggOwnBins; i += BLOCK) own_count[i] = A.bin_count[(size_t)(blockIdx.x + i * gridDim.x) * cstride];
     lds_table_init<BLOCK>(P, lds, S, tid);
-    if (tid == 0) {
-        lds_fill = 0;
-        emit_n = 0;
-    }
+    if (tid == 0) lds_fill = 0;
     __syncthreads();
-    // The workgroup's chunks (BLOCK x U records of one bin) in order, the next one always requested before the current one
-    // is processed — across the end of a bin too, so that loads stay in flight through the barriers and the emit step.
     struct Chunk {
-        uint32_t bin;
+        uint32_t ord;  // ordinal among the workgroup's bins (>= own: past the end)
         uint64_t base, hi;
     };
-    auto enter = [&](Chunk& c) {  // first chunk of bin c.bin or of the next non-empty bin of this workgroup
-        while (c.bin < A.nbins) {
-            const uint64_t n = A.bin_count[(size_t)c.bin * cstride];
-            c.base = (uint64_t)c.bin * A.bin_stride;
+    auto enter = [&](Chunk& c) {  // first chunk of bin c.ord or of the next non-empty bin of this workgroup
+        while (c.ord < own) {
+            const uint32_t bin = blockIdx.x + c.ord * gridDim.x;
+            const uint64_t n = own_count[c.ord];
+            c.base = (uint64_t)bin * A.bin_stride;
             c.hi = c.base + (n < A.bin_stride ? n : A.bin_stride);
             if (c.base < c.hi) return;
-            c.bin += gridDim.x;
+            c.ord++;
         }
     };
-    auto load = [&](const Chunk& c, Rec16 (&r)[U]) {
+    auto after = [&](Chunk c) {  // the chunk behind c
+        if (c.ord >= own) return c;
+        c.base += (uint64_t)BLOCK * U;
+        if (c.base >= c.hi) {
+            c.ord++;
+            enter(c);
+        }
+        return c;
+    };
+    // (returns which of the U records are the chunk's: what was loaded is not looked at here — any use is a wait)
+    auto load = [&](const Chunk& c, Rec16 (&r)[U]) -> uint32_t {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        uint32_t mask = 0;
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const uint64_t i = c.base + (uint64_t)j * BLOCK + tid;
-            r[j].k = kEmptyKey;
-            r[j].v = 0;
-            if (c.bin < A.nbins && i < c.hi) {
-                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-                const u64x2 v = __builtin_nontemporal_load((const u64x2*)(rec + i));
-                r[j].k = v.x;
-                r[j].v = v.y;
-            }
+            const bool in = c.ord < own && i < c.hi;
+            // (issued by hand: the compiler does not know that the registers are in flight, so it places no wait of its own —
+            //  its waits drained both chunks in flight at the head of every turn of the loop; arrive() below is the wait)
+            const u64x2 v = __builtin_nontemporal_load((const u64x2*)(rec + (in ? i : 0)));
+            r[j].k = v.x;
+            r[j].v = v.y;
+            mask |= in ? 1u << j : 0u;
         }
+        return mask;
     };
-    Chunk cur;
-    cur.bin = blockIdx.x;
-    cur.base = cur.hi = 0;
-    enter(cur);
-    Rec16 r[U], rn[U];
-    load(cur, r);
-    while (cur.bin < A.nbins) {
-        Chunk nxt = cur;
-        nxt.base += (uint64_t)BLOCK * U;
-        if (nxt.base >= nxt.hi) {
-            nxt.bin += gridDim.x;
-            enter(nxt);
-        }
-        load(nxt, rn);
+    AggSpec one = P.aggs[0];  // (KIND >= 0: the plan's only aggregate, its kind a compile-time constant)
+    if (KIND >= 0) one.kind = (uint32_t)KIND;
+    constexpr bool kSplit = KIND == (int)AGG_COUNT || KIND == (int)AGG_COUNTN || KIND == (int)AGG_SUM || KIND == (int)AGG_AVG;
+    const bool one_has = A.agg_src[0] < kRecOperands;
+    constexpr uint32_t kNoSlot = 1u << 31;
+    lds_u32* const fillp = (lds_u32*)&lds_fill;
+
+    // one chunk: its records into the table; `last`: the bin ends with it
+    auto process = [&](const Rec16 (&r)[U], uint32_t mask, bool last) {
+        uint64_t key[U], p[U];
+        uint32_t t[U], hs[U], out[U];  // out: 0, kNoSlot, or the aggregates (bit a) whose contribution leaves on its own
+        uint32_t live = 0;             // bit j: record j has not found its slot yet
 #pragma unroll
         for (int j = 0; j < U; j++) {
-            if (r[j].k == kEmptyKey) continue;  // beyond the bin
-            uint64_t key, p;
-            uint32_t t;
-            rec16_decode(r[j], key, t, p);
-            const int slot = lds_find_or_insert(lds, S, key, &lds_fill, A.lds_max_fill);
-            if (slot < 0) {  // more groups in the bin than the LDS table takes
-                emit_single(P, A, key, nullptr, t, p);
-                continue;
-            }
-            for (uint32_t a = 0; a < P.naggs; a++) {
-                const bool has = A.agg_src[a] < kRecOperands;
-                if (!acc_lds(P, P.aggs[a], lds, S, (uint32_t)slot, has ? t : (uint32_t)T_NULL, has ? p : 0ull))
-                    emit_single(P, A, key, &P.aggs[a], t, p);  // |int| >= 2^40: leaves with just this contribution
+            out[j] = 0;
+            key[j] = p[j] = 0;
+            t[j] = hs[j] = 0;
+            if (!(mask >> j & 1u) || r[j].k == kEmptyKey || (A.pad1 & 1u)) continue;  // beyond the bin / padding  (pad1: timing experiments only)
+            rec16_decode(r[j], key[j], t[j], p[j]);
+            hs[j] = lds_hash(key[j], S);
+            live |= 1u << j;
+        }
+        const uint32_t valid = live;
+        uint32_t found = live;  // bit j: hs[j] is record j's slot (cleared again where the table has no room)
+#pragma unroll 1
+        for (int probe = 0; probe < 32 && live; probe++) {
+            unsigned long long seen[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) seen[j] = (live >> j & 1u) ? lds_peek(lds_word(lds, hs[j])) : 0ull;
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                if (!(live >> j & 1u)) continue;
+                if (seen[j] == key[j]) {
+                    live &= ~(1u << j);
+                    continue;
+                }
+                if (seen[j] == kEmptyKey) {
+                    if (*(volatile lds_u32*)fillp >= A.lds_max_fill) {  // the table is kept sparse: the record leaves on its own
+                        live &= ~(1u << j);
+                        found &= ~(1u << j);
+                        continue;
+                    }
+                    unsigned long long expected = kEmptyKey;
+                    if (__hip_atomic_compare_exchange_strong(lds_word(lds, hs[j]), &expected, (unsigned long long)key[j], __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        // a new group: its slot joins the list the emit step walks (no scan of the whole table per bin)
+                        const uint32_t at = __hip_atomic_fetch_add(fillp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        slot_list[at] = (uint16_t)hs[j];
+                        live &= ~(1u << j);
+                        continue;
+                    }
+                    if (expected == key[j]) {
+                        live &= ~(1u << j);
+                        continue;
+                    }
+                }
+                hs[j] = hs[j] + 1 == S ? 0 : hs[j] + 1;
             }
         }
-        if (nxt.bin != cur.bin) {
-            // end of the bin: its groups join the compact region, every slot they used is reset
-            lds_barrier();  // (LDS only: the next chunk's loads stay in flight)
-            if (tid == 0) {
-                const uint32_t n = lds_fill;
-                emit_base = n ? atomicAdd((unsigned long long*)&A.emit[0], (unsigned long long)n) : 0ull;
-                lds_fill = 0;
-                emit_n = 0;
+        found &= ~live;  // (32 slots in a row taken by other keys)
+        uint32_t any_out = 0;
+        if (kSplit) {
+            uint32_t bit[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                bit[j] = 0;
+                if (!(valid >> j & 1u)) continue;
+                if (!(found >> j & 1u)) { out[j] = kNoSlot; continue; }
+                bit[j] = acc_lds_value(one, lds, S, hs[j], one_has ? t[j] : (uint32_t)T_NULL, one_has ? p[j] : 0ull);
+                if (bit[j] == ~0u) { out[j] = 1u; bit[j] = 0; }
             }
-            lds_barrier();  // (LDS only: the next chunk's loads stay in flight)
+            if (KIND == (int)AGG_SUM || KIND == (int)AGG_AVG) {
+                // (the flags fit the word's low half: a 32-bit read costs the LDS half of what a 64-bit one does)
+                uint32_t fl[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) fl[j] = bit[j] ? *(volatile lds_u32*)lds_word(lds, (one.lds_off + 2) * S + hs[j]) : ~0u;
+#pragma unroll
+                for (int j = 0; j < U; j++)
+                    if (!(fl[j] & bit[j])) lds_or_u64(lds_word(lds, (one.lds_off + 2) * S + hs[j]), (unsigned long long)bit[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) any_out |= out[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                if (!(valid >> j & 1u)) continue;
+                if (!(found >> j & 1u)) {
+                    out[j] = kNoSlot;
+                } else if (KIND >= 0) {
+                    if (!acc_lds(P, one, lds, S, hs[j], one_has ? t[j] : (uint32_t)T_NULL, one_has ? p[j] : 0ull)) out[j] = 1u;
+                } else {
+                    for (uint32_t a = 0; a < P.naggs; a++) {
+                        const bool has = A.agg_src[a] < kRecOperands;
+                        if (!acc_lds(P, P.aggs[a], lds, S, hs[j], has ? t[j] : (uint32_t)T_NULL, has ? p[j] : 0ull))
+                            out[j] |= 1u << a;  // |int| >= 2^40: leaves with just this contribution
+                    }
+                }
+                any_out |= out[j];
+            }
+        }
+        if (any_out) {
+#pragma unroll 1
+            for (int j = 0; j < U; j++) {
+                uint64_t k1 = key[0], p1 = p[0];
+                uint32_t t1 = t[0], o = out[0];
+#pragma unroll
+                for (int i = 1; i < U; i++)
+                    if (i == j) {
+                        k1 = key[i];
+                        p1 = p[i];
+                        t1 = t[i];
+                        o = out[i];
+                    }
+                if (!o) continue;
+                if (o & kNoSlot) {
+                    emit_single(P, A, k1, nullptr, t1, p1);
+                    continue;
+                }
+                for (uint32_t a = 0; a < P.naggs; a++)
+                    if (o >> a & 1u) emit_single(P, A, k1, &P.aggs[a], t1, p1);
+            }
+        }
+        if (last) {
+            // end of the bin: its groups join the compact region, every slot they used is reset
+            lds_barrier();  // (LDS only: the chunks in flight stay in flight)
+            const uint32_t n = *(volatile lds_u32*)fillp;
+            if (tid == 0) emit_base = n && !(A.pad1 & 2u) ? atomicAdd((unsigned long long*)&A.emit[0], (unsigned long long)n) : 0ull;
+            lds_barrier();
+            if (tid == 0) lds_fill = 0;  // (every thread has read n; the next chunk is processed behind the barrier below)
             const unsigned long long q0 = emit_base;
-            for (uint32_t s = tid; s < S; s += BLOCK) {
-                const uint64_t key = lds[s];
-                if (key == kEmptyKey) continue;
-                const unsigned long long q = q0 + atomicAdd(&emit_n, 1u);
-                if (q < A.emit_cap) {
-                    A.emit[2 + q] = key;
+            for (uint32_t i = tid; i < n; i += BLOCK) {
+                const uint32_t s = slot_list[i];
+                const unsigned long long q = q0 + i;
+                if (A.pad1 & 2u) {
+                } else if (q < A.emit_cap) {
+                    A.emit[2 + q] = lds[s];
                     store_slot(P, lds, S, s, A.emit + 2 + A.emit_cap + q * P.glob_words);
                 } else
                     atomicOr(A.err_flags, (uint32_t)ERR_TABLE_FULL);
                 lds_slot_reset(P, lds, S, s);
             }
-            lds_barrier();  // (LDS only: the next chunk's loads stay in flight)
+            lds_barrier();
         }
-        cur = nxt;
+    };
+
+    Chunk cur;
+    cur.ord = 0;
+    cur.base = cur.hi = 0;
+    enter(cur);
+    Rec16 r[U], rn[U];
+    uint32_t mn = load(cur, rn);
+    while (cur.ord < own) {
+        // The only place that waits for global loads is this copy: rn is in flight when the loop comes round, r never is.
 #pragma unroll
         for (int j = 0; j < U; j++) r[j] = rn[j];
+        const uint32_t m = mn;
+        const Chunk nxt = after(cur);
+        mn = load(nxt, rn);
+        process(r, m, nxt.ord != cur.ord);
+        cur = nxt;
     }
 }
 
-hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t block, uint32_t per_thread, hipStream_t st) {
-    const size_t shmem = (size_t)A.lds_slots * P.lds_words * 8;
-#define N1K_AGG16(BB, UU)                                                                                         \
+// the per-bin table and, behind it, the list of the slots in use (16 bits each: at most 65536 slots)
+size_t agg_bins16_lds_bytes(const Program& P, uint32_t slots) { return (size_t)slots * P.lds_words * 8 + (((size_t)slots * 2 + 15) & ~(size_t)15); }
+
+hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t block, uint32_t per_thread, hipStream_t st,
+                             bool specialise) {
+    const size_t shmem = agg_bins16_lds_bytes(P, A.lds_slots);
+    grid = std::max(grid, (A.nbins + kAggOwnBins - 1) / kAggOwnBins);  // (the counts of a workgroup's bins live in LDS)
+#define N1K_AGG16(BB, UU, KK)                                                                                     \
     {                                                                                                             \
-        auto k = agg_bins16_kernel<BB, UU>;                                                                       \
+        auto k = agg_bins16_kernel<BB, UU, KK>;                                                                   \
         if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
         hipLaunchKernelGGL(k, dim3(grid), dim3(BB), shmem, st, P, A);                                              \
     }
     // (8 records in flight per thread spilled to scratch)
     if (block <= 256) {
-        if (per_thread <= 2) N1K_AGG16(256, 2) else N1K_AGG16(256, 4)
+        if (per_thread <= 2) N1K_AGG16(256, 2, -1)
+        else if (specialise && P.naggs == 1 && !P.aggs[0].distinct && P.aggs[0].kind <= AGG_MAX) {
+            // the default geometry with the plan's one aggregate fixed at compile time
+            switch (P.aggs[0].kind) {
+                case AGG_COUNT: N1K_AGG16(256, 4, (int)AGG_COUNT) break;
+                case AGG_COUNTN: N1K_AGG16(256, 4, (int)AGG_COUNTN) break;
+                case AGG_SUM: N1K_AGG16(256, 4, (int)AGG_SUM) break;
+                case AGG_AVG: N1K_AGG16(256, 4, (int)AGG_AVG) break;
+                case AGG_MIN: N1K_AGG16(256, 4, (int)AGG_MIN) break;
+                default: N1K_AGG16(256, 4, (int)AGG_MAX) break;
+            }
+        } else N1K_AGG16(256, 4, -1)
     } else {
-        if (per_thread <= 2) N1K_AGG16(512, 2) else N1K_AGG16(512, 4)
+        if (per_thread <= 2) N1K_AGG16(512, 2, -1) else N1K_AGG16(512, 4, -1)
     }
 #undef N1K_AGG16
     return hipGetLastError();

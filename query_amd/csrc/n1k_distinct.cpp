@@ -22,8 +22,8 @@ static void dedupe_counters(const n1k_handle* h, DedupeArgs& D) {
 
 // workgroups of the de-duplication kernel: as many per CU as their LDS (set + member counters) and threads allow
 static uint32_t dedupe_grid(const n1k_handle* h, const DedupeArgs& D, uint32_t nbins) {
-    const size_t shmem = distinct_dedupe_lds(D) + 512;
-    const uint32_t by_threads = 2048u / std::max(256u, h->opt_dedupe_block & ~1u);
+    const size_t shmem = distinct_dedupe_lds(D) + 512 + 4096;  // (+ the kernel's static arrays: the bounds of its bins)
+    const uint32_t by_threads = 2048u / std::max(256u, h->opt_dedupe_block & ~3u);
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(by_threads, (160 * 1024) / shmem));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nbins, (uint64_t)h->num_cus * per_cu));
 }
@@ -33,7 +33,7 @@ static uint32_t dedupe_grid(const n1k_handle* h, const DedupeArgs& D, uint32_t n
 n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64_t nwords, bool hist_counted,
                                  const uint64_t* log) {
     const uint32_t set_slots = h->opt_distinct_set_slots;
-    const uint64_t per_bin = std::max<uint64_t>(set_slots / 4, 16);  // expected distinct words per final bin: load <= 1/4
+    const uint64_t per_bin = std::max<uint64_t>((uint64_t)set_slots * h->opt_distinct_fill_pct / 100, 16);  // expected distinct words per final bin
     const uint32_t levels = h->opt_distinct_levels >= 0 ? (uint32_t)h->opt_distinct_levels
                                                         : (nwords <= per_bin ? 0u : (nwords <= 256 * per_bin ? 1u : 2u));
     if (!log) log = h->d_log_word[ag.log_index].p;
@@ -85,7 +85,7 @@ n1k_status distinct_words_finish(n1k_handle* h, const AggSpec& ag, uint64_t nwor
     D.counts = h->d_dcounts.p;
     D.overflow = d_overflow;
     dedupe_counters(h, D);
-    HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, dedupe_grid(h, D, nbins), h->opt_dedupe_block, h->stream));
+    HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, dedupe_grid(h, D, nbins), h->opt_dedupe_block | (h->opt_dedupe_unroll == 4 ? 2u : 0u), h->stream));
     uint32_t overflow = 0;
     HIP_TRY(h, hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -116,7 +116,7 @@ n1k_status distinct_regions_finish(n1k_handle* h, const AggSpec& ag, uint64_t no
     const uint64_t cap = h->wregion_cap;
     unsigned long long* const cursors = h->d_wcursor.p + (size_t)li * kWordSubs * kCursorStride;
     const uint32_t set_slots = h->opt_distinct_set_slots;
-    const uint64_t per_bin = std::max<uint64_t>(set_slots / 4, 16);
+    const uint64_t per_bin = std::max<uint64_t>((uint64_t)set_slots * h->opt_distinct_fill_pct / 100, 16);
     const bool exact = force_exact || nover > 0 || h->opt_distinct_levels == 0;
     uint32_t* d_overflow = (uint32_t*)(h->d_counters.p + 20);  // [0] an LDS set overflowed, [1] a bin of the second pass
     if (!exact) {
@@ -149,6 +149,7 @@ n1k_status distinct_regions_finish(n1k_handle* h, const AggSpec& ag, uint64_t no
         D.words = R.dst;
         D.bin_count = h->d_cursor.p;
         D.count_stride = 1;
+        D.pad1 = h->opt_spec_debug >> 8;  // (timing experiments only)
         D.bin_stride = bin_cap;
         D.nbins = (uint32_t)nbins;
         D.set_slots = set_slots;
@@ -157,7 +158,7 @@ n1k_status distinct_regions_finish(n1k_handle* h, const AggSpec& ag, uint64_t no
         D.counts = h->d_dcounts.p;
         D.overflow = d_overflow;
         dedupe_counters(h, D);
-        HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, dedupe_grid(h, D, D.nbins), h->opt_dedupe_block, h->stream));
+        HIP_TRY(h, launch_distinct_dedupe(h->prog, h->table, D, dedupe_grid(h, D, D.nbins), h->opt_dedupe_block | (h->opt_dedupe_unroll == 4 ? 2u : 0u), h->stream));
         HIP_TRY(h, launch_distinct_add_counts(h->prog, h->table, h->d_dcounts.p, ag.glob_off, h->stream, d_overflow));
         h->distinct_path |= 2u;
         *deferred = true;

@@ -843,6 +843,9 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "topk_sample") h->opt_topk_sample = value ? 1 : 0;
     else if (n == "filter_stream") h->opt_filter_stream = value ? 1 : 0;
     else if (n == "fused_tail") h->opt_fused_tail = value ? 1 : 0;
+    else if (n == "distinct_fill_pct") h->opt_distinct_fill_pct = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 75);
+    else if (n == "dedupe_unroll") h->opt_dedupe_unroll = (uint32_t)value;
+    else if (n == "agg_spec") h->opt_agg_spec = value ? 1 : 0;
     else if (n == "merge_chunks") h->opt_merge_chunks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 16);
     else if (n == "inject_failure") h->opt_inject_failure = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
     else if (n == "part_block") h->opt_part_block = value == 256 ? 256 : 512;

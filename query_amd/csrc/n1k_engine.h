@@ -162,6 +162,7 @@ struct n1k_handle {
     bool device_clean = false, clear_on_finish = false;
     uint32_t opt_filter_stream = 1; // Filter-only plans: the one-pass kernel (0: mask + scan + compaction, the ablation)
     uint32_t opt_fused_tail = 1;    // 0: finalize_kernel + publish_counters_kernel as separate launches (ablation)
+    uint32_t opt_agg_spec = 1;      // agg_bins16_kernel: the plan's one aggregate fixed at compile time (0: the generic kernel, A/B)
     uint32_t opt_merge_chunks = 0;  // merge_slabs_kernel: block rows (0 = from the grid)
     bool out_count_dirty = true;  // the finalize position counter holds a previous finish's count
     char* pin_out = nullptr;  // pinned host copy of a speculative FinalGroup (n1k_finish)
@@ -212,6 +213,8 @@ struct n1k_handle {
     uint32_t opt_spec_debug = 0;           // timing experiments: 1 words not stored, 2 word scatter skipped, 4 no workgroup cache, 8 finish skips the sets
     uint64_t opt_region_cap = 0;           // forced capacity of a hash region (tests: overflow into the plain log), 0 = from the rows
     uint32_t opt_distinct_words = 1;      // 0: every pair takes the (key, value, class) log and the global sets
+    uint32_t opt_distinct_fill_pct = 25;     // a final bin's expected words, in % of the LDS set's slots (tuning)
+    uint32_t opt_dedupe_unroll = 0;          // words per thread and chunk of the de-duplication kernel at 1024 threads: 2 (0) or 4 (tuning)
     uint32_t opt_distinct_set_slots = 8192;  // LDS set size of the de-duplication kernel (power of two; 64 KB: two workgroups per CU)
     int32_t opt_distinct_levels = -1;        // partition passes before the LDS sets: -1 = by log size, 0..2 forced (tests)
     uint32_t nw_key_bits = 0, nw_val_bits = 0;

@@ -114,7 +114,9 @@ size_t spec_records_lds_bytes();
 // per hash region, a power of two <= 256) and the per-bin LDS tables (`block` threads per bin, `per_thread` = records a thread loads at once)
 hipError_t launch_radix_scatter16(const RadixArgs& A, uint32_t wpr, uint32_t bins_per_region, hipStream_t st);
 hipError_t launch_radix_scatter_words(const RadixArgs& A, uint32_t wpr, uint32_t bins_per_region, hipStream_t st);  // the same for 8-byte member words
-hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t block, uint32_t per_thread, hipStream_t st);
+size_t agg_bins16_lds_bytes(const Program& P, uint32_t slots);  // LDS of one agg_bins16 workgroup with `slots` table slots
+hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t grid, uint32_t block, uint32_t per_thread, hipStream_t st,
+                             bool specialise = true);  // (specialise: the plan's one aggregate as a compile-time constant)
 const std::vector<SpecEntry>& spec_registry();
 hipError_t launch_finalize(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs,
                            OutPartial* out_parts, uint64_t* out_rep, unsigned long long* out_count, uint64_t max_out,

@@ -523,6 +523,8 @@ __global__ __launch_bounds__(kRadixBlock) void radix_scatter_kernel(const RadixA
 // to the groups once per workgroup (a look-up of the global group table per new member costs 0.8 ms per 100 M
 // members in scattered loads).  The first words of the NEXT bin are loaded before the current bin is processed:
 // a bin of a few thousand words is one memory latency, which would otherwise be paid bin after bin.
+constexpr uint32_t kDedupeOwn = 256;  // bins per workgroup of distinct_dedupe_kernel, at most
+
 template <int BLOCK, int U, bool TOGETHER>
 __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P, const GlobalTable G, const DedupeArgs D) {
     extern __shared__ uint64_t dl[];
@@ -538,22 +540,38 @@ __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P,
             gcnt[i] = 0;
         }
     }
-    auto bounds = [&](uint32_t bin, uint64_t& lo, uint64_t& hi) {
-        lo = hi = 0;
-        if (bin >= D.nbins) return;
-        if (D.bin_count) {
-            const uint64_t c = D.bin_count[(size_t)bin * (D.count_stride ? D.count_stride : 1u)];
-            lo = (uint64_t)bin * D.bin_stride;
-            hi = lo + (c < D.bin_stride ? c : D.bin_stride);
-        } else {
-            lo = D.bin_start[bin];
-            hi = D.bin_start[bin + 1];
+    // the bounds of the workgroup's bins (blockIdx.x + i * gridDim.x; the launch leaves it kDedupeOwn at most) go to LDS first:
+    // read from global memory when the walk reached a bin, they were one exposed memory latency per bin — in front of the
+    // request for the bin's words, which needs them
+    __shared__ unsigned long long own_lo[kDedupeOwn], own_hi[kDedupeOwn];
+    for (uint32_t i = tid; i < kDedupeOwn; i += BLOCK) {
+        const uint64_t b = (uint64_t)blockIdx.x + (uint64_t)i * gridDim.x;
+        unsigned long long l = 0, h = 0;
+        if (b < D.nbins) {
+            if (D.bin_count) {
+                const uint64_t c = D.bin_count[(size_t)b * (D.count_stride ? D.count_stride : 1u)];
+                l = b * D.bin_stride;
+                h = l + (c < D.bin_stride ? c : D.bin_stride);
+            } else {
+                l = D.bin_start[b];
+                h = D.bin_start[b + 1];
+            }
         }
+        own_lo[i] = l;
+        own_hi[i] = h;
+    }
+    __syncthreads();
+    uint32_t ord = 0;  // ordinal of the current bin among the workgroup's
+    auto bounds = [&](uint32_t o, uint64_t& lo, uint64_t& hi) {
+        lo = hi = 0;
+        if (o >= kDedupeOwn) return;
+        lo = own_lo[o];
+        hi = own_hi[o];
     };
     uint32_t overflow = 0;
     uint32_t bin = blockIdx.x;
     uint64_t lo, hi;
-    bounds(bin, lo, hi);
+    bounds(ord, lo, hi);
     uint64_t cur[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -562,7 +580,7 @@ __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P,
     }
     while (bin < D.nbins) {
         uint64_t nlo, nhi, nxt[U];
-        bounds(bin + gridDim.x, nlo, nhi);
+        bounds(ord + 1, nlo, nhi);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint64_t i = nlo + (uint64_t)u * BLOCK + tid;
@@ -570,9 +588,11 @@ __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P,
         }
         if (lo != hi) {
             // (LDS-only barriers: __syncthreads() would also drain the loads of the next bin's words just issued)
+            if (!(D.pad1 & 2u)) {
             lds_barrier();
             for (uint32_t i = tid; i < D.set_slots; i += BLOCK) *(volatile lds_u64*)lds_word(set, i) = kEmptyKey;
             lds_barrier();
+            }
             for (uint64_t base = lo; base < hi; base += (uint64_t)BLOCK * U) {
                 if (base != lo) {
 #pragma unroll
@@ -592,22 +612,21 @@ __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P,
                     // bin differ in their value and key bits)
                     uint32_t h = ((uint32_t)w ^ ((uint32_t)(w >> 32) * 0x9E3779B1u)) * 0x85EBCA6Bu;
                     hh[u] = (h ^ (h >> 15)) & mask;
-                    state[u] = w == kEmptyKey ? 2 : 0;
+                    state[u] = (w == kEmptyKey || (D.pad1 & 1u)) ? 2 : 0;  // (pad1: timing experiments only)
                 }
                 if (!TOGETHER) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         for (int probe = 0; probe < 64 && !state[u]; probe++) {
+                            // the swap IS the look-up: most words of a bin are new members (the sets are a quarter full at
+                            // most), and what it returns tells a member from another word's slot — one LDS operation per
+                            // step instead of a read and a swap (the kernel is bound by its LDS operations)
                             lds_u64* sp = lds_word(set, hh[u]);
-                            unsigned long long c = lds_peek(sp);
-                            if (c == cur[u]) state[u] = 2;
-                            else if (c == kEmptyKey) {
-                                unsigned long long expected = kEmptyKey;
-                                if (__hip_atomic_compare_exchange_strong(sp, &expected, (unsigned long long)cur[u], __ATOMIC_RELAXED,
-                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                                    state[u] = 1;
-                                else if (expected == cur[u]) state[u] = 2;
-                            }
+                            unsigned long long expected = kEmptyKey;
+                            if (__hip_atomic_compare_exchange_strong(sp, &expected, (unsigned long long)cur[u], __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                                state[u] = 1;
+                            else if (expected == cur[u]) state[u] = 2;
                             hh[u] = (hh[u] + 1) & mask;
                         }
                     }
@@ -674,6 +693,7 @@ __global__ __launch_bounds__(BLOCK) void distinct_dedupe_kernel(const Program P,
             }
         }
         bin += gridDim.x;
+        ord++;
         lo = nlo;
         hi = nhi;
 #pragma unroll
@@ -3132,8 +3152,9 @@ size_t distinct_dedupe_lds(const DedupeArgs& D) {
 
 hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const DedupeArgs& D, uint32_t grid, uint32_t block, hipStream_t st) {
     const size_t shmem = distinct_dedupe_lds(D);
-    const bool together = !(block & 1u);
-    block &= ~1u;
+    grid = std::max(grid, (D.nbins + kDedupeOwn - 1) / kDedupeOwn);  // (the bounds of a workgroup's bins live in LDS)
+    const bool together = !(block & 1u), four = (block & 2u) != 0;  // (tuning bits in the block size)
+    block &= ~3u;
 #define N1K_DEDUPE(B, U)                                                                                              \
     do {                                                                                                              \
         auto k = together ? distinct_dedupe_kernel<B, U, true> : distinct_dedupe_kernel<B, U, false>;                 \
@@ -3141,6 +3162,7 @@ hipError_t launch_distinct_dedupe(const Program& P, const GlobalTable& G, const 
         hipLaunchKernelGGL(k, dim3(grid), dim3(B), shmem, st, P, G, D);                                               \
     } while (0)
     if (block == 256) N1K_DEDUPE(256, 8);
+    else if (block == 1024 && four) N1K_DEDUPE(1024, 4);
     else if (block == 1024) N1K_DEDUPE(1024, 2);
     else N1K_DEDUPE(512, 4);
 #undef N1K_DEDUPE

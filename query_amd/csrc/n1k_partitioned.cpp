@@ -307,6 +307,7 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
     }
     // (3) one workgroup per bin: InitialGroup in an LDS table, the bin's groups into the compact region
     B.lds_slots = slots;
+    B.pad1 = h->opt_spec_debug >> 8;  // (timing experiments only)
     B.lds_max_fill = std::max(1u, slots * 5 / 8);
     for (uint32_t a = 0; a < kMaxAggs; a++) B.agg_src[a] = a < P.naggs ? pp.agg_src[a] : 0xFFFFFFFFu;
     B.err_flags = h->d_errp;
@@ -322,11 +323,11 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
     HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 22, 0, sizeof(unsigned long long), h->stream));
     {
         const uint32_t block = h->opt_rec_block ? h->opt_rec_block : 256u;
-        const size_t shmem = (size_t)slots * P.lds_words * 8 + 1024;
+        const size_t shmem = agg_bins16_lds_bytes(P, slots) + 1024;
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / block / 2, (160 * 1024) / shmem));
         const uint32_t bgrid = (uint32_t)std::min<uint64_t>(B.nbins, (uint64_t)h->num_cus * per_cu);
         const uint64_t per_thread = mean / block + 1;
-        HIP_TRY(h, launch_agg_bins16(P, B, bgrid, block, h->opt_rec_unroll ? h->opt_rec_unroll : (uint32_t)std::min<uint64_t>(per_thread, 4), h->stream));
+        HIP_TRY(h, launch_agg_bins16(P, B, bgrid, block, h->opt_rec_unroll ? h->opt_rec_unroll : (uint32_t)std::min<uint64_t>(per_thread, 4), h->stream, h->opt_agg_spec != 0));
     }
     // one copy of the counters into pinned memory (the region's group count joins them first): one host round trip
     {

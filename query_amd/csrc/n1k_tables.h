@@ -39,6 +39,7 @@ N1K_DEV uint32_t lds_hash(uint64_t key, uint32_t S) {
 N1K_DEV int lds_find_or_insert(uint64_t* lds, uint32_t S, uint64_t key, uint32_t* fill, uint32_t max_fill) {
     uint32_t h = lds_hash(key, S);
     lds_u32* fillp = (lds_u32*)fill;
+#pragma unroll 1  // (unrolled, 32 copies of the probe per record were most of the kernels' code)
     for (int probe = 0; probe < 32; probe++) {
         lds_u64* p = lds_word(lds, h);
         unsigned long long cur = lds_peek(p);
@@ -252,6 +253,34 @@ N1K_DEV bool acc_lds(const Program& P, const AggSpec& ag, uint64_t* lds, uint32_
             return true;
         }
     }
+}
+
+// The VALUE part of CumulateInitial for COUNT / COUNTN / SUM / AVG (no returning LDS operation: nothing to wait for).  Returns
+// the bit the slot's SUM / AVG flags word has to carry (0: none; lds_set_flag on word lds_off + 2 is the caller's, so that it
+// can read the flags of several records with one wait), or ~0u when the value must take the global path (|int| >= 2^40).
+N1K_DEV uint32_t acc_lds_value(const AggSpec& ag, uint64_t* lds, uint32_t S, uint32_t slot, uint32_t tag, uint64_t p) {
+    lds_u64* w = lds_word(lds, ag.lds_off * S + slot);  // word i at w[i * S]
+    if (ag.kind == AGG_COUNT) {
+        if (!ag.has_operand || tag > T_NULL) lds_add_u64(w, 1ull);
+        return 0u;
+    }
+    if (ag.kind == AGG_COUNTN) {
+        if (tag == T_INT || tag == T_FLOAT) lds_add_u64(w, 1ull);
+        return 0u;
+    }
+    if (tag == T_INT) {
+        const int64_t x = (int64_t)p;
+        if (x >= (1ll << 40) || x <= -(1ll << 40)) return ~0u;
+        lds_add_u64(w, (unsigned long long)x);
+        if (ag.kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
+        return x < 0 ? (uint32_t)SF_NEG_INT : (uint32_t)SF_NONNEG_INT;
+    }
+    if (tag == T_FLOAT) {
+        lds_add_f64(w + S, as_f64(p));
+        if (ag.kind == AGG_AVG) lds_add_u64(w + 3 * S, 1ull);
+        return (uint32_t)SF_FLOAT;
+    }
+    return 0u;
 }
 
 // CumulateIntermediate: fold one LDS slot into its global row (algebra/agg_*.go CumulateIntermediate)
