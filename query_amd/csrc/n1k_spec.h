@@ -33,9 +33,11 @@ namespace n1k {
     }
 
 // flag bits: fire-and-forget ds_or (no LDS read, so the row loop never waits on lgkmcnt)
-// (experiment switch: two tiles in flight for every shape, not only those whose tiles end in barriers)
+// Two tiles in flight for every shape (0: only for those whose tiles end in barriers — the A/B switch).  With the tiles issued
+// unconditionally and decoded when they are processed (spec_issue_tile / spec_decode_tile) the second tile really is in flight
+// while the first is processed: config 2 at 100 M rows 0.270 -> 0.258 ms (scan + merge, three alternations on one box).
 #ifndef N1K_SPEC_PIPE_ALL
-#define N1K_SPEC_PIPE_ALL 0
+#define N1K_SPEC_PIPE_ALL 1
 #endif
 #ifndef SPEC_FLAG
 #define SPEC_FLAG(ptr, bit) lds_or_u64((ptr), (bit))
@@ -261,17 +263,20 @@ N1K_DEV void spec_row(const Program& P, const FastArgs& F, const GlobalTable& G,
 // tags are derived in a second phase behind a scheduling barrier.  (Without it the compiler interleaved the first item's
 // tag arithmetic with the loads and waited for the first item's data — s_waitcnt vmcnt(0) — before it had issued the
 // second item's loads: two memory latencies per tile instead of one, config 2's scan 237 -> 283 us.)
+// Issue: R items per thread x the Spec's columns, every load unconditional — an item beyond the tile re-reads the first item
+// (of the segment) and is dropped through valid[] — and NOTHING is computed from what was loaded: `tt` holds the tag bytes as
+// they come (WIDE: two rows' tags in one 16-bit load), `pv` payloads / codes.  A tile issued this way can stay in flight while
+// another one is processed: with predicated loads the compiler cannot count what is outstanding and waits for everything
+// (s_waitcnt vmcnt(0)), and any arithmetic on a loaded value is a wait at that spot.
 template <class Spec, int R, int BLOCK, bool WIDE>
-N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, uint32_t tid,
-                            uint32_t (&tg)[R][WIDE ? 2 : 1][kSpecCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kSpecCols], bool (&valid)[R],
-                            uint32_t item0 = 0) {  // item0: first item of the segment the tile belongs to (segmented batches)
-    constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
-    uint32_t tt[R][kFastCols];  // TAGGED64 columns: the item's tag bytes as loaded (WIDE: two rows' tags in one 16-bit load)
+N1K_DEV void spec_issue_tile(const FastArgs& F, uint32_t base, uint32_t nitems, uint32_t tid, uint32_t (&tt)[R][kFastCols],
+                             uint64_t (&pv)[R][WIDE ? 2 : 1][kSpecCols], bool (&valid)[R],
+                             uint32_t item0 = 0) {  // item0: first item of the segment the tile belongs to (segmented batches)
 #pragma unroll
     for (int j = 0; j < R; j++) {
         const uint32_t il = base + (uint32_t)j * BLOCK + tid;
         valid[j] = il < nitems;
-        const uint32_t i = il + item0;
+        const uint32_t i = (valid[j] ? il : 0u) + item0;
 #pragma unroll
         for (int c = 0; c < kFastCols; c++) {
             tt[j][c] = 0;
@@ -279,33 +284,53 @@ N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, u
                 if (Spec::col_kind[c] == COLK_DICT32) {
                     if (WIDE) {
                         typedef uint32_t n1k_u32x2 __attribute__((ext_vector_type(2)));
-                        n1k_u32x2 cc = {0xFFFFFFFFu, 0xFFFFFFFFu};
-                        if (valid[j]) cc = __builtin_nontemporal_load((const n1k_u32x2*)F.cols[c].codes + i);
+                        const n1k_u32x2 cc = __builtin_nontemporal_load((const n1k_u32x2*)F.cols[c].codes + i);
                         pv[j][0][c] = cc.x;
                         pv[j][WIDE ? 1 : 0][c] = cc.y;
                     } else {
-                        pv[j][0][c] = valid[j] ? F.cols[c].codes[i] : 0xFFFFFFFFu;
+                        pv[j][0][c] = __builtin_nontemporal_load(F.cols[c].codes + i);
                     }
                 } else {
                     if (WIDE) {
                         typedef unsigned long long n1k_u64x2 __attribute__((ext_vector_type(2)));
-                        n1k_u64x2 pp = {0ull, 0ull};
-                        if (valid[j]) pp = __builtin_nontemporal_load((const n1k_u64x2*)F.cols[c].payload + i);
-                        if (valid[j]) tt[j][c] = (uint32_t)__builtin_nontemporal_load((const uint16_t*)F.cols[c].tags + i);
+                        const n1k_u64x2 pp = __builtin_nontemporal_load((const n1k_u64x2*)F.cols[c].payload + i);
+                        tt[j][c] = (uint32_t)__builtin_nontemporal_load((const uint16_t*)F.cols[c].tags + i);
                         pv[j][0][c] = pp.x;
                         pv[j][WIDE ? 1 : 0][c] = pp.y;
                     } else {
-                        pv[j][0][c] = valid[j] ? F.cols[c].payload[i] : 0ull;
-                        tt[j][c] = valid[j] ? (uint32_t)F.cols[c].tags[i] : (uint32_t)T_MISSING;
+                        pv[j][0][c] = __builtin_nontemporal_load(F.cols[c].payload + i);
+                        tt[j][c] = (uint32_t)__builtin_nontemporal_load(F.cols[c].tags + i);
                     }
                 }
-            } else {
-#pragma unroll
-                for (int h = 0; h < (int)kRowsPerItem; h++) pv[j][h][c] = 0;
             }
         }
     }
-    __builtin_amdgcn_sched_barrier(0);  // nothing below moves up between the loads
+}
+
+// "The tile has arrived": an empty statement every register spec_issue_tile loaded passes through.  Placed right behind the
+// issue of the NEXT tile — straight-line code — it makes the compiler wait there with a count (everything but the loads just
+// issued); met first inside the rows' divergent code, the same registers cost a wait for everything outstanding.
+template <class Spec, int R, bool WIDE>
+N1K_DEV void spec_tile_arrived(uint32_t (&tt)[R][kFastCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kSpecCols]) {
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+#pragma unroll
+        for (int c = 0; c < kFastCols; c++) {
+            if (c >= Spec::ncols) continue;
+            if (Spec::col_kind[c] != COLK_DICT32) asm volatile("" : "+v"(tt[j][c]));
+#pragma unroll
+            for (int h = 0; h < (WIDE ? 2 : 1); h++) asm volatile("" : "+v"(pv[j][h][c]));
+        }
+    }
+}
+
+// Decode: the rows' tags from what spec_issue_tile loaded, and the fused arithmetic nodes (expression/arith_*.go,
+// func_num.go): column slot ncols + d from the slots before it, in registers — no derived column in HBM (the element-wise
+// arith_kernel writes 9 B per row and node and the scan reads them back).
+template <class Spec, int R, bool WIDE>
+N1K_DEV void spec_decode_tile(const FastArgs& F, const uint32_t (&tt)[R][kFastCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kSpecCols],
+                              uint32_t (&tg)[R][WIDE ? 2 : 1][kSpecCols]) {
+    constexpr uint32_t kRowsPerItem = WIDE ? 2u : 1u;
 #pragma unroll
     for (int j = 0; j < R; j++) {
 #pragma unroll
@@ -314,7 +339,7 @@ N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, u
             for (int h = 0; h < (int)kRowsPerItem; h++) {
                 if (c >= Spec::ncols) {
                     tg[j][h][c] = T_MISSING;
-                    if (c >= kFastCols) pv[j][h][c] = 0;
+                    pv[j][h][c] = 0;
                 } else if (Spec::col_kind[c] == COLK_DICT32) {
                     const uint32_t code = (uint32_t)pv[j][h][c];
                     tg[j][h][c] = code == 0xFFFFFFFFu ? (uint32_t)T_MISSING : (code == 0xFFFFFFFEu ? (uint32_t)T_NULL : (uint32_t)T_STRING);
@@ -323,9 +348,6 @@ N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, u
                 }
             }
         }
-        // fused arithmetic nodes (expression/arith_*.go, func_num.go): column slot ncols + d from the slots before it,
-        // in registers — no derived column in HBM (the element-wise arith_kernel writes 9 B per row and node and the scan
-        // reads them back)
 #pragma unroll
         for (int d = 0; d < Spec::nderived; d++) {
 #pragma unroll
@@ -352,6 +374,18 @@ N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, u
             }
         }
     }
+}
+
+// Both at once (one tile in flight per workgroup: the loads are all issued before anything is computed from them — a
+// scheduling barrier keeps the first item's tag arithmetic, and the wait it implies, from moving up between them).
+template <class Spec, int R, int BLOCK, bool WIDE>
+N1K_DEV void spec_load_tile(const FastArgs& F, uint32_t base, uint32_t nitems, uint32_t tid,
+                            uint32_t (&tg)[R][WIDE ? 2 : 1][kSpecCols], uint64_t (&pv)[R][WIDE ? 2 : 1][kSpecCols], bool (&valid)[R],
+                            uint32_t item0 = 0) {
+    uint32_t tt[R][kFastCols];
+    spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tt, pv, valid, item0);
+    __builtin_amdgcn_sched_barrier(0);  // nothing below moves up between the loads
+    spec_decode_tile<Spec, R, WIDE>(F, tt, pv, tg);
 }
 
 // ---- member words -> hash regions -------------------------------------------------------------------------------
@@ -433,8 +467,11 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
     const uint32_t nitems = WIDE ? (nrows + 1u) / 2u : nrows;
     const uint32_t tile = BLOCK * R;
     uint32_t* const flag = L.rec_overflow;
-    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kSpecCols], const uint64_t (&pv)[R][kRowsPerItem][kSpecCols],
-                       const bool (&valid)[R], uint32_t base) {
+    auto process = [&](uint32_t (&tt)[R][kFastCols], uint64_t (&pv)[R][kRowsPerItem][kSpecCols], const bool (&valid)[R],
+                       uint32_t base) {
+        spec_tile_arrived<Spec, R, WIDE>(tt, pv);
+        uint32_t tg[R][kRowsPerItem][kSpecCols];
+        spec_decode_tile<Spec, R, WIDE>(F, tt, pv, tg);
         Rec16 recs[kNW];
         uint32_t bins[kNW];
 #pragma unroll
@@ -453,21 +490,21 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
                                  L.region_cap, [=](uint32_t, const Rec16&) { *(volatile uint32_t*)flag = 1u; });
         par ^= 1u;
     };
-    // Two tiles in flight: the columns of tile t + 1 are requested before tile t's records go through LDS (three barriers
-    // and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
-    uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+    // Two tiles in flight: the columns of tile t + 1 are requested (spec_issue_tile: loads only) before tile t is decoded and
+    // its records go through LDS (three barriers and the stores to the regions).
+    uint32_t ttA[R][kFastCols], ttB[R][kFastCols];
     uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
     bool vA[R], vB[R];
     const uint32_t stride = gridDim.x * tile;
     uint32_t base = blockIdx.x * tile;
-    if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
+    if (base < nitems) spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, ttA, pvA, vA);
     while (base < nitems) {
-        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgB, pvB, vB);  // (beyond the end: no loads)
-        process(tgA, pvA, vA, base);
+        spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, ttB, pvB, vB);  // (beyond the end: dropped)
+        process(ttA, pvA, vA, base);
         base += stride;
         if (base >= nitems) break;
-        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgA, pvA, vA);
-        process(tgB, pvB, vB, base);
+        spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, ttA, pvA, vA);
+        process(ttB, pvB, vB, base);
         base += stride;
     }
     if (unpackable) atomicOr(F.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
@@ -779,8 +816,13 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
         return base < ni;  // (false: a tile of the segment's unused capacity)
     };
 
-    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kSpecCols], const uint64_t (&pv)[R][kRowsPerItem][kSpecCols],
-                       const bool (&valid)[R], uint32_t base, uint32_t nr) {
+    auto process = [&](uint32_t (&tt)[R][kFastCols], uint64_t (&pv)[R][kRowsPerItem][kSpecCols], const bool (&valid)[R],
+                       uint32_t base, uint32_t nr, bool piped) {
+        __builtin_amdgcn_sched_barrier(0);  // (nothing of the decode moves up between the loads of a tile issued just before)
+        // (another tile in flight: wait for this one here, with a count; else the compiler's own waits, item by item, do better)
+        if (piped) spec_tile_arrived<Spec, R, WIDE>(tt, pv);
+        uint32_t tg[R][kRowsPerItem][kSpecCols];
+        spec_decode_tile<Spec, R, WIDE>(F, tt, pv, tg);
         uint64_t mw[kSpecDistinct][kNW];  // this thread's member words of the tile (kEmptyKey = none) and their hash regions
         uint32_t mb[kSpecDistinct][kNW];
 #pragma unroll
@@ -813,40 +855,40 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
     if constexpr (!SEG) {
         // plain batch: tiles at base = blockIdx.x * tile, + gridDim.x * tile, ...
         const uint32_t stride = gridDim.x * tile;
-        if constexpr (kND > 0 || N1K_SPEC_PIPE_ALL) {
+        if constexpr (kND > 0 || (N1K_SPEC_PIPE_ALL && Spec::nderived == 0)) {  // (arithmetic nodes in registers: one tile, or the registers run out)
             // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
             // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
-            uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+            uint32_t ttA[R][kFastCols], ttB[R][kFastCols];
             uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
             bool vA[R], vB[R];
             uint32_t base = blockIdx.x * tile;
-            if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
+            if (base < nitems) spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, ttA, pvA, vA);
             while (base < nitems) {
-                spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgB, pvB, vB);  // (beyond the end: no loads)
-                process(tgA, pvA, vA, base, nrows);
+                spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, ttB, pvB, vB);  // (beyond the end: dropped)
+                process(ttA, pvA, vA, base, nrows, true);
                 base += stride;
                 if (base >= nitems) break;
-                spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgA, pvA, vA);
-                process(tgB, pvB, vB, base, nrows);
+                spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, ttA, pvA, vA);
+                process(ttB, pvB, vB, base, nrows, true);
                 base += stride;
             }
         } else {
             for (uint32_t base = blockIdx.x * tile; base < nitems; base += stride) {
                 // issue every load of the tile first (R items x ncols columns), then compute
-                uint32_t tg[R][kRowsPerItem][kSpecCols];
+                uint32_t tt[R][kFastCols];
                 uint64_t pv[R][kRowsPerItem][kSpecCols];
                 bool valid[R];
-                spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
-                process(tg, pv, valid, base, nrows);
+                spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tt, pv, valid);
+                process(tt, pv, valid, base, nrows, false);
             }
         }
     } else {
         // segmented batch: tiles numbered segment by segment (locate)
         const uint32_t gstride = gridDim.x;
-        if constexpr (kND > 0 || N1K_SPEC_PIPE_ALL) {
+        if constexpr (kND > 0 || (N1K_SPEC_PIPE_ALL && Spec::nderived == 0)) {  // (arithmetic nodes in registers: one tile, or the registers run out)
             // Two tiles in flight: the columns of tile t + 1 are requested before tile t's member words go through LDS (three
             // barriers and the stores to the regions), so the loads' latency hides behind that instead of adding to it.
-            uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+            uint32_t ttA[R][kFastCols], ttB[R][kFastCols];
             uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
             bool vA[R], vB[R];
             uint32_t baseA = 0, baseB = 0, nrA = 0, nrB = 0, ni, item0;
@@ -854,21 +896,21 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
             // (a tile that does not exist, or lies in unused capacity: nitems 0 -> no loads, every row invalid)
             if (t < total_tiles) {
                 const bool ok = locate(t, baseA, ni, nrA, item0);
-                spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, tgA, pvA, vA, item0);
+                spec_issue_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, ttA, pvA, vA, item0);
             }
             while (t < total_tiles) {
                 {
                     const bool ok = locate(t + gstride, baseB, ni, nrB, item0);
-                    spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseB, ok ? ni : 0u, tid, tgB, pvB, vB, item0);
+                    spec_issue_tile<Spec, R, BLOCK, WIDE>(F, baseB, ok ? ni : 0u, tid, ttB, pvB, vB, item0);
                 }
-                process(tgA, pvA, vA, baseA, nrA);
+                process(ttA, pvA, vA, baseA, nrA, true);
                 t += gstride;
                 if (t >= total_tiles) break;
                 {
                     const bool ok = locate(t + gstride, baseA, ni, nrA, item0);
-                    spec_load_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, tgA, pvA, vA, item0);
+                    spec_issue_tile<Spec, R, BLOCK, WIDE>(F, baseA, ok ? ni : 0u, tid, ttA, pvA, vA, item0);
                 }
-                process(tgB, pvB, vB, baseB, nrB);
+                process(ttB, pvB, vB, baseB, nrB, true);
                 t += gstride;
             }
         } else {
@@ -876,11 +918,11 @@ N1K_DEV void scan_spec_body(const Program& P, const FastArgs& F, const GlobalTab
                 uint32_t base, ni, nr, item0;
                 if (!locate(t, base, ni, nr, item0)) continue;
                 // issue every load of the tile first (R items x ncols columns), then compute
-                uint32_t tg[R][kRowsPerItem][kSpecCols];
+                uint32_t tt[R][kFastCols];
                 uint64_t pv[R][kRowsPerItem][kSpecCols];
                 bool valid[R];
-                spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, ni, tid, tg, pv, valid, item0);
-                process(tg, pv, valid, base, nr);
+                spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, ni, tid, tt, pv, valid, item0);
+                process(tt, pv, valid, base, nr, false);
             }
         }
     }
