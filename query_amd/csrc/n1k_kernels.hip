@@ -2621,6 +2621,10 @@ __global__ __launch_bounds__(BLOCK) void filter_mask_kernel(const Program P, uin
 // Algorithmic traffic: the predicate's columns once + 8 B per survivor.
 constexpr unsigned long long kTileAgg = 1ull << 62, kTilePrefix = 2ull << 62, kTileValue = (1ull << 62) - 1ull;
 
+// Tried and measured (100 M rows, 0.38 ms as it stands): all of a tile's loads issued at once — 179 registers, two workgroups
+// per CU: 0.74 ms; in two halves at 128 registers: 0.49 ms; the NEXT tile's ticket drawn while this one is worked on (to hide
+// the returning atomic): twice as slow — a tile drawn early publishes late, and every higher tile's look-back waits for it.
+// The kernel wants many small workgroups: the chain of look-backs, not the loads, is what a tile waits for.
 // A tile = SUB passes of BLOCK x R rows: the predicate runs pass by pass (R rows per thread in registers at a time), what it
 // leaves per pass is one bit per row and the per-(pass, j, wave) survivor counts in LDS; then ONE look-back for the tile and
 // the survivors' ordinals pass by pass.  (Tiles of 1024 rows with one ticket each were 97 k same-address atomics per 100 M

@@ -599,8 +599,12 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
     const uint64_t sub_first = (uint64_t)sub * A.sub_rows * (nsub > 1u ? 1u : 0u);
     unsigned long long* const my_counts = A.counts + (size_t)sub * kCursorStride * (nsub > 1u ? 1u : 0u);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    auto process = [&](const uint32_t (&tg)[R][kRowsPerItem][kSpecCols], const uint64_t (&pv)[R][kRowsPerItem][kSpecCols],
-                       const bool (&valid)[R], uint32_t base) {
+    auto process = [&](uint32_t (&tt)[R][kFastCols], uint64_t (&pv)[R][kRowsPerItem][kSpecCols], const bool (&valid)[R], uint32_t base,
+                       bool piped) {
+        __builtin_amdgcn_sched_barrier(0);  // (nothing of the decode moves up between the loads of a tile issued just before)
+        if (piped) spec_tile_arrived<Spec, R, WIDE>(tt, pv);  // (another tile in flight: wait for this one here, with a count)
+        uint32_t tg[R][kRowsPerItem][kSpecCols];
+        spec_decode_tile<Spec, R, WIDE>(F, tt, pv, tg);
         bool pass[kNW];
         uint32_t dest[kNW], rk[kNW];
 #pragma unroll
@@ -719,28 +723,28 @@ N1K_DEV void scan_spec_partition_body(const Program& P, const FastArgs& F, const
     };
     if constexpr (!PIPE) {
         for (uint32_t base = blockIdx.x * tile; base < nitems; base += gridDim.x * tile) {
-            uint32_t tg[R][kRowsPerItem][kSpecCols];
+            uint32_t tt[R][kFastCols];
             uint64_t pv[R][kRowsPerItem][kSpecCols];
             bool valid[R];
-            spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tg, pv, valid);
-            process(tg, pv, valid, base);
+            spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tt, pv, valid);
+            process(tt, pv, valid, base, false);
         }
         if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
         return;
     }
-    uint32_t tgA[R][kRowsPerItem][kSpecCols], tgB[R][kRowsPerItem][kSpecCols];
+    uint32_t ttA[R][kFastCols], ttB[R][kFastCols];
     uint64_t pvA[R][kRowsPerItem][kSpecCols], pvB[R][kRowsPerItem][kSpecCols];
     bool vA[R], vB[R];
     const uint32_t stride = gridDim.x * tile;
     uint32_t base = blockIdx.x * tile;
-    if (base < nitems) spec_load_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, tgA, pvA, vA);
+    if (base < nitems) spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, ttA, pvA, vA);
     while (base < nitems) {
-        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgB, pvB, vB);  // (beyond the end: no loads)
-        process(tgA, pvA, vA, base);
+        spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, ttB, pvB, vB);  // (beyond the end: dropped)
+        process(ttA, pvA, vA, base, true);
         base += stride;
         if (base >= nitems) break;
-        spec_load_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, tgA, pvA, vA);
-        process(tgB, pvB, vB, base);
+        spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, ttA, pvA, vA);
+        process(ttB, pvB, vB, base, true);
         base += stride;
     }
     if (unpackable) atomicOr(A.err_flags, (uint32_t)ERR_UNPACKABLE_KEY);
