@@ -189,10 +189,16 @@ redo_sets:
             char* d = h->d_out.p;
             if (h->out_count_dirty) HIP_TRY(h, hipMemsetAsync(h->d_counters.p + 2, 0, sizeof(unsigned long long), h->stream));
             h->out_count_dirty = true;  // (reopen zeroes every counter in its one launch)
-            if (lean)
+            if (lean) {
+                // (the order image of the first ORDER BY term straight from FinalGroup: 8 B per group written, one kernel less)
+                HIP_TRY(h, h->d_images.ensure(ng));
+                n1k_status rst = ensure_rank(h);
+                if (rst != N1K_OK) return rst;
                 HIP_TRY(h, launch_finalize_region(h->prog, h->d_emit.p, h->pending.cap, ng, nullptr, nullptr, nullptr, nullptr, h->d_errp,
-                                                  h->stream, nullptr, (OutValue*)d, pl.order[0].key_index >= 0,
-                                                  (uint32_t)(pl.order[0].key_index >= 0 ? pl.order[0].key_index : pl.order[0].agg_index)));
+                                                  h->stream, nullptr, nullptr, pl.order[0].key_index >= 0,
+                                                  (uint32_t)(pl.order[0].key_index >= 0 ? pl.order[0].key_index : pl.order[0].agg_index),
+                                                  h->d_images.p, pl.order[0].desc));
+            }
             else if (h->pending.count)
                 HIP_TRY(h, launch_finalize_region(h->prog, h->d_emit.p, h->pending.cap, ng, (OutValue*)d, (OutValue*)(d + off_aggs),
                                                   (OutPartial*)(d + off_parts), (uint64_t*)(d + off_rep), h->d_errp, h->stream));
@@ -217,7 +223,7 @@ redo_sets:
                 for (int attempt = sampled ? 0 : 1; attempt < 2; attempt++) {
                     HIP_TRY(h, launch_topk_select(h->prog, vals, lean ? 1u : (t0.key_index >= 0 ? nk : na),
                                                   lean ? 0u : (uint32_t)(t0.key_index >= 0 ? t0.key_index : t0.agg_index), ng, t0.desc, keep,
-                                                  h->d_images.p, h->d_topk.p, h->d_cand.p, h->stream, attempt == 0, attempt == 1 && sampled));
+                                                  h->d_images.p, h->d_topk.p, h->d_cand.p, h->stream, attempt == 0, lean || (attempt == 1 && sampled)));
                     HIP_TRY(h, hipMemcpyAsync(h->pin_counters + kCounters, h->d_topk.p + topk_ncand_offset(), sizeof ncand, hipMemcpyDeviceToHost, h->stream));
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                     ncand = h->pin_counters[kCounters];

@@ -53,7 +53,8 @@ hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalT
 // high-cardinality GROUP BY: rows -> records (key + operands), [radix passes], per-bin LDS aggregation
 hipError_t launch_finalize_region(const Program& P, const uint64_t* region, uint64_t cap, uint64_t count, OutValue* out_keys,
                                   OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags, hipStream_t st,
-                                  const uint32_t* cand = nullptr, OutValue* ord = nullptr, bool ord_is_key = false, uint32_t ord_index = 0);
+                                  const uint32_t* cand = nullptr, OutValue* ord = nullptr, bool ord_is_key = false, uint32_t ord_index = 0,
+                                  uint64_t* images = nullptr, bool desc = false);  // (images: order images of the ORDER BY term instead of ord)
 hipError_t launch_add_counter(unsigned long long* p, unsigned long long v, hipStream_t st);
 hipError_t launch_probe_keys(const Program& P, uint64_t nrows, const GlobalTable& G, uint32_t* err_flags, unsigned long long* ngroups,
                              uint32_t grid, hipStream_t st);

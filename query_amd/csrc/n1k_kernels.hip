@@ -1956,21 +1956,27 @@ hipError_t launch_finalize_small(const Program& P, const GlobalTable& G, OutValu
 // the top-k candidates need rows; writing every group's row was 0.72 GB per 6.4 M groups):
 //   ord != nullptr   every group is finalised (errors are raised as ever) but only the value of the first ORDER BY term
 //                    is stored, ord[i] — what the top-k selection reads;
+//                    is stored, ord[i] — what the top-k selection reads; with `images` its 64-bit order image instead (8 B per
+//                    group, and no second kernel that turns 16-byte values into images);
 //   cand != nullptr  the groups cand[0 .. count) only, group cand[j] as output row j.
+N1K_DEV uint64_t order_image(const Program& P, uint64_t tag, uint64_t p, bool desc);
 __global__ void finalize_region_kernel(const Program P, const uint64_t* region, uint64_t cap, uint64_t count, OutValue* out_keys,
                                        OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags,
-                                       const uint32_t* cand, OutValue* ord, uint32_t ord_is_key, uint32_t ord_index) {
+                                       const uint32_t* cand, OutValue* ord, uint32_t ord_is_key, uint32_t ord_index, uint64_t* images,
+                                       uint32_t desc) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     const uint64_t i = cand ? (uint64_t)cand[j] : j;
     const uint64_t key = region[2 + i];
     const uint64_t* g = region + 2 + cap + i * P.glob_words;
-    if (ord) {
-        OutValue v;
+    if (ord || images) {
+        OutValue v, term;
         OutPartial part;
+        term.tag = T_MISSING;
+        term.payload = 0;
         for (uint32_t a = 0; a < P.naggs; a++) {
             finalize_agg(P, P.aggs[a], g, &v, &part, err_flags);
-            if (!ord_is_key && a == ord_index) ord[i] = v;
+            if (!ord_is_key && a == ord_index) term = v;
         }
         if (ord_is_key) {
             const KeySpec& ks = P.keys[ord_index];
@@ -1978,8 +1984,10 @@ __global__ void finalize_region_kernel(const Program P, const uint64_t* region, 
             uint32_t tag;
             uint64_t p;
             unpack_key_field(P, ks.mode, field, tag, p);
-            put_value(&ord[i], tag, p);
+            put_value(&term, tag, p);
         }
+        if (images) images[i] = order_image(P, term.tag, term.payload, desc != 0);
+        else ord[i] = term;
         return;
     }
     for (uint32_t k = 0; k < P.nkeys; k++) {
@@ -2391,15 +2399,17 @@ constexpr uint32_t kTopkSample = 16384;
 
 // the rank-th smallest (1-based) of the n <= kTopkSample images in LDS; all 1024 threads of the workgroup call it.  Lanes of a
 // wave that count the same bin add once (early passes put every image in one bin: 16 k same-address LDS atomics were 27 us).
+// `passes` < 8: only the high bytes are selected and the bytes below are all ones — an UPPER bound of the rank-th image (what the
+// sample needs: a few more candidates, half the passes).
 N1K_DEV uint64_t lds_radix_select(const uint64_t* smp, uint32_t n, unsigned long long rank, uint32_t* h, unsigned long long* s_prefix,
-                                  unsigned long long* s_rem) {
+                                  unsigned long long* s_rem, uint32_t passes = 8) {
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) {
         *s_prefix = 0;
         *s_rem = rank;
     }
     __syncthreads();
-    for (uint32_t pass = 0; pass < 8; pass++) {
+    for (uint32_t pass = 0; pass < passes; pass++) {
         const uint32_t shift = 56 - 8 * pass;
         if (tid < 256) h[tid] = 0;
         __syncthreads();
@@ -2409,14 +2419,18 @@ N1K_DEV uint64_t lds_radix_select(const uint64_t* smp, uint32_t n, unsigned long
             const uint64_t x = i < n ? smp[i] : 0;
             const bool in = i < n && (pass == 0 || (x >> (shift + 8)) == (prefix >> (shift + 8)));
             const uint32_t bin = (uint32_t)(x >> shift) & 255u;
+            // lanes with one digit count themselves with ONE atomic (the high digits of images are all alike: thousands of
+            // atomics on one counter); what is left after the leader's digit is spread out and goes in lane by lane (a wave whose
+            // 64 digits all differ would otherwise spend 64 rounds here)
             unsigned long long todo = __ballot(in);
-            while (todo) {
+            for (int round = 0; todo && round < 1; round++) {
                 const int leader = __ffsll((long long)todo) - 1;
                 const uint32_t lb = (uint32_t)__shfl((int)bin, leader, 64);
                 const unsigned long long same = __ballot(in && bin == lb) & todo;
                 if ((int)lane == leader) atomicAdd(&h[lb], (uint32_t)__popcll(same));
                 todo &= ~same;
             }
+            if (todo >> lane & 1ull) atomicAdd(&h[bin], 1u);
         }
         __syncthreads();
         if (tid < 64) {  // one wave: lane l owns bins 4l .. 4l + 3 (as topk_pick_kernel)
@@ -2457,7 +2471,7 @@ N1K_DEV uint64_t lds_radix_select(const uint64_t* smp, uint32_t n, unsigned long
         }
         __syncthreads();
     }
-    return *s_prefix;
+    return passes < 8 ? (*s_prefix | ((1ull << (64 - 8 * passes)) - 1ull)) : *s_prefix;
 }
 
 __global__ __launch_bounds__(1024) void topk_sample_kernel(const uint64_t* images, uint64_t n, uint32_t rank, TopkState* st) {
@@ -2466,13 +2480,17 @@ __global__ __launch_bounds__(1024) void topk_sample_kernel(const uint64_t* image
     __shared__ unsigned long long s_prefix, s_rem;
     const uint32_t tid = threadIdx.x;
     const uint32_t stride = (uint32_t)(n / kTopkSample);  // (the caller made sure that 4 * kTopkSample <= n < 2^32)
-#pragma unroll 4
-    for (uint32_t i = tid; i < kTopkSample; i += 1024) {
+    uint64_t mine[kTopkSample / 1024];  // (all loads first: one memory latency, not one per image)
+#pragma unroll
+    for (uint32_t k = 0; k < kTopkSample / 1024; k++) {
+        const uint32_t i = k * 1024 + tid;
         const uint32_t off = (uint32_t)mix64(0x5EEDull + i) % stride;  // one image out of every `stride`, at a scattered place
-        smp[i] = images[(uint64_t)i * stride + off];
+        mine[k] = images[(uint64_t)i * stride + off];
     }
+#pragma unroll
+    for (uint32_t k = 0; k < kTopkSample / 1024; k++) smp[k * 1024 + tid] = mine[k];
     __syncthreads();
-    const uint64_t t = lds_radix_select(smp, kTopkSample, rank, h, &s_prefix, &s_rem);
+    const uint64_t t = lds_radix_select(smp, kTopkSample, rank, h, &s_prefix, &s_rem, 4);  // (32 bits of the image: 20 of a number's mantissa)
     if (tid == 0) {
         st->prefix = t;
         st->ncand = 0;
@@ -2522,14 +2540,18 @@ __global__ __launch_bounds__(1024) void topk_refine_kernel(const uint64_t* image
     __syncthreads();
     const uint32_t M = off[kTopkSegs];
     const bool refine = M >= keep && M <= kTopkSample;
-    // pack: four threads per segment
-    for (uint32_t sg = tid >> 2; sg < kTopkSegs; sg += 256) {
-        const uint32_t c = off[sg + 1] - off[sg];
-        for (uint32_t j = tid & 3u; j < c; j += 4) {
-            const uint32_t g = seg_lists[(size_t)sg * seg_cap + j];
-            cand[off[sg] + j] = g;
-            if (refine) smp[off[sg] + j] = images[g];
+    // pack: candidate i of all lies in the segment whose offsets bracket i (binary search in LDS) — every thread takes every
+    // 1024-th candidate, so that the two dependent loads per candidate (its group, then the group's image) overlap across
+    // candidates instead of queueing up behind each other in four threads per segment
+    for (uint32_t i = tid; i < M; i += 1024) {
+        uint32_t lo = 0, hi = kTopkSegs;  // off[lo] <= i < off[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= i) lo = mid; else hi = mid;
         }
+        const uint32_t g = seg_lists[(size_t)lo * seg_cap + (i - off[lo])];
+        cand[i] = g;
+        if (refine) smp[i] = images[g];
     }
     __syncthreads();
     if (!refine) {
@@ -3017,10 +3039,10 @@ hipError_t launch_add_counter(unsigned long long* p, unsigned long long v, hipSt
 
 hipError_t launch_finalize_region(const Program& P, const uint64_t* region, uint64_t cap, uint64_t count, OutValue* out_keys,
                                   OutValue* out_aggs, OutPartial* out_parts, uint64_t* out_rep, uint32_t* err_flags, hipStream_t st,
-                                  const uint32_t* cand, OutValue* ord, bool ord_is_key, uint32_t ord_index) {
+                                  const uint32_t* cand, OutValue* ord, bool ord_is_key, uint32_t ord_index, uint64_t* images, bool desc) {
     if (!count) return hipSuccess;
     hipLaunchKernelGGL(finalize_region_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, st, P, region, cap, count,
-                       out_keys, out_aggs, out_parts, out_rep, err_flags, cand, ord, ord_is_key ? 1u : 0u, ord_index);
+                       out_keys, out_aggs, out_parts, out_rep, err_flags, cand, ord, ord_is_key ? 1u : 0u, ord_index, images, desc ? 1u : 0u);
     return hipGetLastError();
 }
 
