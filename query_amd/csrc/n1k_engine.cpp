@@ -738,6 +738,7 @@ n1k_status n1k_reset(n1k_handle* h) {
     if (!h) return N1K_INVALID;
     h->stop_flag.store(0);
     h->failure_global = false;
+    h->tail_in_merge = false;
     h->row_base = 0;
     h->merged_groups_bound = 0;
     h->selected.clear();
@@ -845,6 +846,7 @@ n1k_status n1k_set_option(n1k_handle* h, const char* name, int64_t value) {
     else if (n == "fused_tail") h->opt_fused_tail = value ? 1 : 0;
     else if (n == "distinct_fill_pct") h->opt_distinct_fill_pct = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 75);
     else if (n == "dedupe_unroll") h->opt_dedupe_unroll = (uint32_t)value;
+    else if (n == "tail_in_merge") h->opt_tail_in_merge = value ? 1 : 0;
     else if (n == "agg_spec") h->opt_agg_spec = value ? 1 : 0;
     else if (n == "merge_chunks") h->opt_merge_chunks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 16);
     else if (n == "inject_failure") h->opt_inject_failure = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
@@ -953,7 +955,10 @@ n1k_status n1k_run_device_batch(n1k_handle* h, const n1k_batch* batch, n1k_resul
     const double t0 = trace ? now() : 0;
     n1k_status st = n1k_reset(h);
     const double t1 = trace ? now() : 0;
+    h->one_call = true;  // (the batch is the whole query: the scan's merge may run the tail, n1k_scan.cpp)
+    h->tail_in_merge = false;
     if (st == N1K_OK) st = n1k_push_device_batch(h, batch);
+    h->one_call = false;
     const double t2 = trace ? now() : 0;
     if (st == N1K_OK) {
         h->clear_on_finish = true;  // the result leaves the device; the state behind it is the next execution's reset

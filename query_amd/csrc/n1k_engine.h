@@ -162,6 +162,16 @@ struct n1k_handle {
     bool device_clean = false, clear_on_finish = false;
     uint32_t opt_filter_stream = 1; // Filter-only plans: the one-pass kernel (0: mask + scan + compaction, the ablation)
     uint32_t opt_fused_tail = 1;    // 0: finalize_kernel + publish_counters_kernel as separate launches (ablation)
+    // the speculative FinalGroup of a small table: where its pieces land (n1k_finish.cpp small_tail_layout) ...
+    struct SmallTailState { bool ok = false, fused = false, clear = false; uint64_t spec_groups = 0; size_t off_aggs = 0, off_parts = 0, off_rep = 0, total = 0; };
+    SmallTailState tail_done;     // ... and, when the merge kernel's last workgroup has run it already (tail_in_merge), what it used
+    bool tail_in_merge = false;
+    bool one_call = false;        // inside n1k_run_device_batch: the batch is the whole query and its result leaves the device next
+    // 1: the merge kernel's last workgroup runs the tail (scan -> merge+tail: two launches per query).  Measured, three
+    // alternations on one box: 0.311-0.319 vs 0.305-0.309 ms per step at 100 M rows, 0.107-0.112 vs 0.103 at 10 M — the fences
+    // and the wait for the last workgroup cost what the saved launch gains: off.
+    uint32_t opt_tail_in_merge = 0;
+    DevBuf<unsigned int> d_merge_done;
     uint32_t opt_agg_spec = 1;      // agg_bins16_kernel: the plan's one aggregate fixed at compile time (0: the generic kernel, A/B)
     uint32_t opt_merge_chunks = 0;  // merge_slabs_kernel: block rows (0 = from the grid)
     bool out_count_dirty = true;  // the finalize position counter holds a previous finish's count
@@ -301,6 +311,9 @@ n1k_status ensure_table(n1k_handle* h, uint64_t incoming_rows);
 n1k_status ensure_table_groups(n1k_handle* h, uint64_t groups);
 hipEvent_t get_event(n1k_handle* h);
 n1k_status ensure_pinned_counters(n1k_handle* h);
+typedef n1k_handle::SmallTailState SmallTail;
+bool small_tail_layout(n1k_handle* h, SmallTail& t);       // n1k_finish.cpp
+n1k_status small_tail_pinned(n1k_handle* h, const SmallTail& t);
 void drain_events(n1k_handle* h);
 n1k_status validate_batch(n1k_handle* h, const n1k_batch* b);
 uint64_t batch_bytes_per_row(const n1k_handle* h);

@@ -10,6 +10,38 @@ static void mark_query_end(n1k_handle* h) {
     if (h->q0_recorded && h->ev_q1 && hipEventRecord(h->ev_q1, h->stream) == hipSuccess) h->q1_recorded = true;
 }
 
+namespace n1k_eng {
+
+// The speculative FinalGroup of a small table (n1k_finish below; with the one-call path the merge kernel's last workgroup runs
+// it, n1k_scan.cpp): whether the plan and the handle's state allow it, and where its pieces land in the pinned buffer.
+bool small_tail_layout(n1k_handle* h, SmallTail& t) {
+    const ParsedPlan& pl = h->plan;
+    const uint32_t nk = (uint32_t)pl.keys.size(), na = (uint32_t)pl.aggs.size();
+    const bool topk_forced = pl.has_order && pl.limit >= 0 && !pl.has_having && h->opt_topk_min_groups < 4096;  // tests
+    t.ok = pl.has_group && !h->has_distinct && h->table.capacity && h->table.capacity <= (1u << 20) && !topk_forced && !h->pending.count;
+    if (!t.ok) return false;
+    t.spec_groups = std::min<uint64_t>(h->table.capacity, 4096);
+    t.off_aggs = t.spec_groups * nk * sizeof(OutValue);
+    t.off_parts = t.off_aggs + t.spec_groups * na * sizeof(OutValue);
+    t.off_rep = t.off_parts + t.spec_groups * na * sizeof(OutPartial);
+    t.total = t.off_rep + t.spec_groups * 8;
+    t.fused = h->opt_pinned_out && h->opt_fused_tail && h->table.capacity <= 8192;
+    return true;
+}
+
+n1k_status small_tail_pinned(n1k_handle* h, const SmallTail& t) {
+    if (h->pin_cap < t.total + kCounters * sizeof(unsigned long long)) {
+        if (h->pin_out) (void)hipHostFree(h->pin_out);
+        h->pin_out = nullptr;
+        h->pin_cap = 0;
+        HIP_TRY(h, hipHostMalloc((void**)&h->pin_out, t.total + kCounters * sizeof(unsigned long long), hipHostMallocDefault));
+        h->pin_cap = t.total + kCounters * sizeof(unsigned long long);
+    }
+    return N1K_OK;
+}
+
+}  // namespace n1k_eng
+
 extern "C" {
 
 n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
@@ -42,22 +74,23 @@ n1k_status n1k_finish(n1k_handle* h, n1k_result* out) {
             n1k_status pst = ensure_pinned_counters(h);
             if (pst != N1K_OK) return pst;
         }
-        const bool topk_forced = pl.has_order && pl.limit >= 0 && !pl.has_having && h->opt_topk_min_groups < 4096;  // tests
         // (a table of millions of slots is not worth scanning twice: the sized pass alone then)
-        if (pl.has_group && !h->has_distinct && h->table.capacity && h->table.capacity <= (1u << 20) && !topk_forced && !h->pending.count) {
-            spec_groups = std::min<uint64_t>(h->table.capacity, 4096);
-            const size_t off_aggs = spec_groups * rec_keys, off_parts = off_aggs + spec_groups * rec_aggs,
-                         off_rep = off_parts + spec_groups * rec_parts, total = off_rep + spec_groups * 8;
-            HIP_TRY(h, h->d_out.ensure(total + 16));
-            if (h->pin_cap < total + sizeof counters) {
-                if (h->pin_out) (void)hipHostFree(h->pin_out);
-                h->pin_out = nullptr;
-                h->pin_cap = 0;
-                HIP_TRY(h, hipHostMalloc((void**)&h->pin_out, total + sizeof counters, hipHostMallocDefault));
-                h->pin_cap = total + sizeof counters;
+        SmallTail tl;
+        if (h->tail_in_merge ? (tl = h->tail_done, true) : small_tail_layout(h, tl)) {
+            spec_groups = tl.spec_groups;
+            const size_t off_aggs = tl.off_aggs, off_parts = tl.off_parts, off_rep = tl.off_rep, total = tl.total;
+            const bool fused_tail = tl.fused;
+            if (!h->tail_in_merge) {
+                HIP_TRY(h, h->d_out.ensure(total + 16));
+                n1k_status ps = small_tail_pinned(h, tl);
+                if (ps != N1K_OK) return ps;
             }
-            const bool fused_tail = h->opt_pinned_out && h->opt_fused_tail && h->table.capacity <= 8192;
-            if (fused_tail) {
+            if (h->tail_in_merge) {
+                // the merge kernel's last workgroup has run the tail already (n1k_scan.cpp): nothing to launch
+                h->tail_in_merge = false;
+                h->out_count_dirty = !tl.clear;
+                h->device_clean = tl.clear;
+            } else if (fused_tail) {
                 // small tables: FinalGroup, the counters behind it and — for a one-call execution, when nothing else on the
                 // device needs a reset (no wide-value tables) — the state the next execution starts from, in ONE last kernel
                 const bool clear = h->clear_on_finish && !h->prog.wide_int;

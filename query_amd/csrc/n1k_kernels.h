@@ -46,8 +46,18 @@ hipError_t launch_scan_group(const Program& P, const ScanArgs& A, const GlobalTa
                              uint32_t grid, uint32_t block, uint32_t rows_per_lane, bool direct, hipStream_t st);
 hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTable& G, unsigned long long* ngroups,
                             uint32_t grid, uint32_t block, uint32_t rows_per_lane, hipStream_t st);
+// (tail: the query's last kernel — launch_finalize_small's work — done by the merge's last workgroup; null: merge only)
+struct TailArgs {
+    OutValue *out_keys, *out_aggs;
+    OutPartial* out_parts;
+    uint64_t* out_rep;
+    unsigned long long *counters, *host_counters;
+    uint64_t max_out;
+    unsigned int* done;  // workgroups finished (zero before the launch; the last workgroup leaves it zero)
+    uint32_t clear, enabled;
+};
 hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalTable& G, uint32_t nblocks,
-                              unsigned long long* ngroups, hipStream_t st, uint32_t ychunks_opt = 0);
+                              unsigned long long* ngroups, hipStream_t st, uint32_t ychunks_opt = 0, const TailArgs* tail = nullptr);
 // ORDER BY ... LIMIT over the finalised groups: order images of the first sort term, radix select of the keep-th image,
 // candidate indices (image <= threshold) and compaction of their records
 // high-cardinality GROUP BY: rows -> records (key + operands), [radix passes], per-bin LDS aggregation

@@ -1431,8 +1431,15 @@ N1K_DEV uint64_t reduce_over_y(uint64_t (*red)[64], uint64_t v) {
     return out;
 }
 
+// (defined with finalize_small_kernel below: FinalGroup of a small table by ONE workgroup of 1024 threads)
+N1K_DEV void finalize_small_body(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs, OutPartial* out_parts,
+                                 uint64_t* out_rep, unsigned long long* counters, unsigned long long* host_counters, uint64_t max_out,
+                                 uint32_t* err_flags, uint32_t clear, uint32_t tid);
+
+// T.enabled: the workgroup that finishes LAST goes on to run the query's tail (finalize_small_body) — the merge and FinalGroup of a
+// small table are then one launch, without the ~ 6 us between two dependent kernels.
 __global__ __launch_bounds__(1024) void merge_slabs_kernel(const Program P, const FastArgs F, const GlobalTable G,
-                                                          uint32_t nblocks_total, unsigned long long* ngroups) {
+                                                          uint32_t nblocks_total, unsigned long long* ngroups, const TailArgs T) {
     // block = 64 slots (x) x 16 chunks (y); thread (x, y) folds workgroup slabs y', y' + Y, ... (y' = its global chunk,
     // Y = 16 * gridDim.y chunks) with unconditional, unrolled loads; the 16 chunks of a block meet through an LDS tree
     // and thread y == 0 applies the result to the global row (a handful of atomics per slot and block row).
@@ -1535,6 +1542,24 @@ __global__ __launch_bounds__(1024) void merge_slabs_kernel(const Program P, cons
                 break;
             }
         }
+    }
+    if (T.enabled) {
+        // every workgroup: its atomics are out (fence), then one ticket; the last one sees everybody's (fence) and runs the tail
+        __shared__ uint32_t s_last;
+        const uint32_t lt = threadIdx.y * 64 + threadIdx.x;
+        // (one release fence per workgroup, behind the barrier that has every wave's atomics out; a fence by every thread —
+        //  4096 L2 write-backs and invalidations per CU's worth of workgroups — made the kernel 50 us longer)
+        __syncthreads();
+        if (lt == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            s_last = atomicAdd(T.done, 1u) == gridDim.x * gridDim.y - 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (lt == 0) *T.done = 0;  // (the next launch counts from zero)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        finalize_small_body(P, G, T.out_keys, T.out_aggs, T.out_parts, T.out_rep, T.counters, T.host_counters, T.max_out, F.err_flags,
+                            T.clear, lt);
     }
 }
 
@@ -1890,12 +1915,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const Program P, const Gl
 // finalize_kernel + publish_counters_kernel (+ the next init_table_kernel): three dependent launches of a few microseconds
 // each, which is what a query over 10 M cached rows is made of.
 constexpr uint32_t kFinalizeSmallMax = 8192;
-__global__ __launch_bounds__(1024) void finalize_small_kernel(const Program P, const GlobalTable G, OutValue* out_keys, OutValue* out_aggs,
-                                                             OutPartial* out_parts, uint64_t* out_rep, unsigned long long* counters,
-                                                             unsigned long long* host_counters, uint64_t max_out, uint32_t* err_flags,
-                                                             uint32_t clear) {
+N1K_DEV void finalize_small_body(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs, OutPartial* out_parts,
+                                 uint64_t* out_rep, unsigned long long* counters, unsigned long long* host_counters, uint64_t max_out,
+                                 uint32_t* err_flags, uint32_t clear, uint32_t tid) {
     __shared__ uint32_t wave_cnt[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
     unsigned long long next = 0;
     for (uint64_t s0 = 0; s0 < G.capacity; s0 += 1024) {
         const uint64_t s = s0 + tid;
@@ -1940,6 +1964,13 @@ __global__ __launch_bounds__(1024) void finalize_small_kernel(const Program P, c
         host_counters[tid] = __hip_atomic_load(&counters[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (clear) counters[tid] = 0;
     }
+}
+
+__global__ __launch_bounds__(1024) void finalize_small_kernel(const Program P, const GlobalTable G, OutValue* out_keys, OutValue* out_aggs,
+                                                             OutPartial* out_parts, uint64_t* out_rep, unsigned long long* counters,
+                                                             unsigned long long* host_counters, uint64_t max_out, uint32_t* err_flags,
+                                                             uint32_t clear) {
+    finalize_small_body(P, G, out_keys, out_aggs, out_parts, out_rep, counters, host_counters, max_out, err_flags, clear, threadIdx.x);
 }
 
 hipError_t launch_finalize_small(const Program& P, const GlobalTable& G, OutValue* out_keys, OutValue* out_aggs, OutPartial* out_parts,
@@ -3020,13 +3051,15 @@ hipError_t launch_scan_fast(const Program& P, const FastArgs& F, const GlobalTab
 }
 
 hipError_t launch_merge_slabs(const Program& P, const FastArgs& F, const GlobalTable& G, uint32_t nblocks,
-                              unsigned long long* ngroups, hipStream_t st, uint32_t ychunks_opt) {
+                              unsigned long long* ngroups, hipStream_t st, uint32_t ychunks_opt, const TailArgs* tail) {
+    TailArgs T{};
+    if (tail && G.capacity <= kFinalizeSmallMax) T = *tail;
     uint32_t blocks = (F.lds_slots + 63) / 64;
     // 16 * ychunks parallel chunks of workgroups; enough blocks for every CU (64 blocks read 25 MB of slabs at 1.25 TB/s)
     uint32_t ychunks = nblocks >= 512 ? 4 : (nblocks >= 128 ? 2 : 1);
     while (ychunks < 16 && blocks * ychunks < 256 && nblocks >= 32 * ychunks) ychunks *= 2;
     if (ychunks_opt) ychunks = ychunks_opt;
-    hipLaunchKernelGGL(merge_slabs_kernel, dim3(blocks, ychunks), dim3(64, 16), 0, st, P, F, G, nblocks, ngroups);
+    hipLaunchKernelGGL(merge_slabs_kernel, dim3(blocks, ychunks), dim3(64, 16), 0, st, P, F, G, nblocks, ngroups, T);
     return hipGetLastError();
 }
 

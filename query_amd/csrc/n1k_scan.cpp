@@ -397,7 +397,36 @@ n1k_status run_group_batch(n1k_handle* h, const n1k_batch* b) {
                 }
                 if (spec) HIP_TRY(h, spec->launch(P, F, h->table, h->d_counters.p + 1, g, fblock, wide, L, h->stream));
                 else HIP_TRY(h, jit_launch(jit, P, F, h->table, h->d_counters.p + 1, g, wide, L, ndist, h->stream));
-                if (F.slabs) HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream, h->opt_merge_chunks));
+                if (F.slabs) {
+                    // One-call execution of a small-table plan, and this merge is the query's last device work: its last
+                    // workgroup runs the tail too (FinalGroup into pinned memory, the counters, the next execution's reopen).
+                    TailArgs T{};
+                    SmallTail tl;
+                    const bool last_work = h->one_call && h->opt_tail_in_merge && n_main == n && off + n == b->nrows && !ndist &&
+                                           !h->has_array_agg && h->push_nseg <= 1 && !h->push_nrows_dev;
+                    if (last_work && small_tail_layout(h, tl) && tl.fused && ensure_pinned_counters(h) == N1K_OK &&
+                        small_tail_pinned(h, tl) == N1K_OK) {
+                        if (!h->d_merge_done.p) {
+                            HIP_TRY(h, h->d_merge_done.ensure(4));
+                            HIP_TRY(h, hipMemsetAsync(h->d_merge_done.p, 0, 16, h->stream));
+                        }
+                        char* d = h->pin_out;
+                        tl.clear = !h->prog.wide_int;
+                        T.out_keys = (OutValue*)d;
+                        T.out_aggs = (OutValue*)(d + tl.off_aggs);
+                        T.out_parts = (OutPartial*)(d + tl.off_parts);
+                        T.out_rep = (uint64_t*)(d + tl.off_rep);
+                        T.counters = h->d_counters.p;
+                        T.host_counters = (unsigned long long*)(h->pin_out + tl.total);
+                        T.max_out = tl.spec_groups;
+                        T.done = h->d_merge_done.p;
+                        T.clear = tl.clear ? 1u : 0u;
+                        T.enabled = 1;
+                        h->tail_done = tl;
+                        h->tail_in_merge = true;
+                    }
+                    HIP_TRY(h, launch_merge_slabs(P, F, h->table, g, h->d_counters.p + 1, h->stream, h->opt_merge_chunks, T.enabled ? &T : nullptr));
+                }
                 F.slabs = nullptr;
                 if (n_main < n) {
                     for (uint32_t c = 0; c < F.ncols; c++) {

@@ -497,7 +497,10 @@ N1K_DEV void scan_spec_records_body(const Program& P, const FastArgs& F, const W
     bool vA[R], vB[R];
     const uint32_t stride = gridDim.x * tile;
     uint32_t base = blockIdx.x * tile;
-    if (base < nitems) spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, ttA, pvA, vA);
+    if (base < nitems) {
+        spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base, nitems, tid, ttA, pvA, vA);
+        spec_tile_arrived<Spec, R, WIDE>(ttA, pvA);  // (nothing in flight at the loop's head on the way in)
+    }
     while (base < nitems) {
         spec_issue_tile<Spec, R, BLOCK, WIDE>(F, base + stride, nitems, tid, ttB, pvB, vB);  // (beyond the end: dropped)
         process(ttA, pvA, vA, base);

@@ -408,14 +408,16 @@ def test_fused_arithmetic_directed_shapes(case):
     assert st["spec_kernel"] == 3, st
 
 
-def test_run_device_batch_is_reset_push_finish():
-    """n1k_run_device_batch = n1k_reset + n1k_push_device_batch + n1k_finish: same groups as the three calls, every time."""
+@pytest.mark.parametrize("tail_in_merge", [0, 1], ids=["merge-then-tail", "tail-in-the-merge"])
+def test_run_device_batch_is_reset_push_finish(tail_in_merge):
+    """n1k_run_device_batch = n1k_reset + n1k_push_device_batch + n1k_finish: same groups as the three calls, every time —
+    with the query's tail as its own kernel and (option tail_in_merge) run by the merge kernel's last workgroup."""
     import torch
     cond, keys = "(50 < %s)" % D("price"), [D("cat")]
     aggs = sorted(["sum(%s)" % D("price"), "count(*)", "min(%s)" % D("user_id")])
     t = n1o.synth_table(200_003, k_cat=40)
     ora = n1o.run(t, cond, keys, aggs)
-    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(cond, keys, aggs))
+    op = query_amd.GpuFilterGroup(query_amd.plan.filter_group_plan(cond, keys, aggs), tail_in_merge=tail_in_merge)
     op.intern(list(t.dictionary))
     by = {c.name: c for c in t.columns}
     keep, cols = [], []
