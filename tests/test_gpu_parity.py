@@ -988,6 +988,46 @@ def test_partitioned_high_cardinality_group_by(keys, cond, levels):
     assert stats["agg_mode"] == 4 and stats["rows_selected"] == ora.rows_passed
 
 
+def _records_table(n, seed=7):
+    """Many groups (an int key), ONE operand column holding every kind of value the per-bin tables meet: small ints, ints beyond
+    2^40 (they leave the LDS sum on their own), floats, NULL / MISSING, a boolean and a string now and then."""
+    rng = np.random.default_rng(seed)
+    key = rng.integers(0, n // 6, n).astype(np.int64)
+    kind = rng.integers(0, 100, n)
+    tags = np.full(n, n1o.T_INT, np.uint8)
+    pay = rng.integers(-1000, 1000, n).astype(np.int64).view(np.uint64).copy()
+    big = kind < 3
+    pay[big] = (rng.integers(1, 1 << 20, big.sum()).astype(np.int64) << 41).view(np.uint64)
+    fl = (kind >= 3) & (kind < 40)
+    tags[fl] = n1o.T_FLOAT
+    pay[fl] = np.round(rng.uniform(-50, 50, fl.sum()), 3).view(np.uint64)
+    tags[(kind >= 40) & (kind < 45)] = n1o.T_NULL
+    tags[(kind >= 45) & (kind < 50)] = n1o.T_MISSING
+    tags[kind == 50] = n1o.T_TRUE
+    st = kind == 51
+    tags[st] = n1o.T_STRING
+    pay[st] = rng.integers(0, 3, st.sum()).astype(np.uint64)
+    pay[(tags == n1o.T_NULL) | (tags == n1o.T_MISSING) | (tags == n1o.T_TRUE)] = 0
+    return n1o.Table([n1o.Column(D("k"), n1o.COL_TAGGED64, tags=np.full(n, n1o.T_INT, np.uint8), payload=key.view(np.uint64)),
+                      n1o.Column(D("v"), n1o.COL_TAGGED64, tags=tags, payload=pay)], [b"a", b"b", b"c"])
+
+
+@pytest.mark.parametrize("aggs", [["sum(%s)"], ["avg(%s)"], ["count(%s)"], ["countn(%s)"], ["min(%s)"], ["max(%s)"], ["count(*)"],
+                                  ["count(*)", "max(%s)", "sum(%s)"]],
+                         ids=["sum", "avg", "count", "countn", "min", "max", "count-star", "three-of-them"])
+@pytest.mark.parametrize("opts", [{}, {"agg_spec": 0}, {"rec_slots": 64}], ids=["specialised", "generic", "tiny-tables"])
+def test_per_bin_tables_over_16_byte_records(aggs, opts):
+    """agg_bins16_kernel (the partitioned GROUP BY over (key, operand) records): every aggregate kind as the plan's ONE aggregate
+    (fixed at compile time) and through the generic form, several at once, operands of every kind — ints beyond 2^40 leave the
+    narrow LDS sum as partial groups of their own — and per-bin tables too small for their bins (the rest leaves the same way)."""
+    aggs = sorted(a % D("v") if "%s" in a else a for a in aggs)
+    t = _records_table(120_000)
+    ora = n1o.run(t, None, [D("k")], aggs, threads=2)
+    gpu, stats = pu.run_gpu(t, None, [D("k")], aggs, batches=2, agg_mode=4, jit=2, **opts)
+    pu.assert_same_groups(gpu, ora, aggs=aggs)
+    assert stats["agg_mode"] == 4
+
+
 def test_partitioned_path_is_chosen_from_the_data():
     """AUTO: the first rows of a large batch run through the scan kernels; many new groups there send the rest of
     the batch through the partitioned path, few keep the scan kernels."""
