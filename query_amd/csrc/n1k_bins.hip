@@ -103,6 +103,15 @@ hipError_t launch_radix_scatter_words(const RadixArgs& A, uint32_t wpr, uint32_t
 
 namespace {
 
+// slot of a key in a bin's table: one multiply and the high half of another (lds_hash takes four: at ~ 100 vector instructions
+// per record — what bounds the kernel — they were a tenth of them).  The keys of a bin share the bits of part_hash the two
+// partition passes took; this is another function of the key.
+__device__ __forceinline__ uint32_t bin_slot(uint64_t key, uint32_t S) {
+    const uint32_t hi = (uint32_t)(key >> 32);
+    const uint32_t x = ((uint32_t)key ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u;
+    return __umulhi(x ^ (x >> 15), S);
+}
+
 // one LDS slot back to "empty": key and the accumulators' identities (what lds_table_init writes for every slot)
 __device__ __forceinline__ void lds_slot_reset(const Program& P, uint64_t* lds, uint32_t S, uint32_t s) {
     lds[s] = kEmptyKey;
@@ -186,7 +195,7 @@ __device__ __forceinline__ void emit_single(const Program& P, const BinAggArgs& 
 // registers the loop works on, the compiler waits for everything outstanding (s_waitcnt vmcnt(0)) — the prefetch it has
 // just issued included — before the first record of every chunk.  The record counts of the workgroup's bins sit in LDS
 // before the loop (read from global memory when the walk reached a bin, each was one exposed memory latency).
-// Measured at 100 M records in 32 Ki bins: 0.60 ms, of which 0.43 ms with the records loaded but not looked at; a third
+// Measured at 100 M records in 32 Ki bins: 0.57 ms, of which 0.285 ms with the records loaded but not looked at; a third
 // chunk in flight (three buffers, the loop unrolled three times) did not help (0.62 ms).
 // KIND >= 0: the plan has ONE aggregate and this is its kind — the accumulate step is then straight-line code.  The thread's
 // U records walk the table TOGETHER (one LDS wait per round of probes).  Records that cannot enter the table (it is full; an
@@ -261,15 +270,17 @@ __global__ __launch_bounds__(BLOCK) void agg_bins16_kernel(const Program P, cons
         uint64_t key[U], p[U];
         uint32_t t[U], hs[U], out[U];  // out: 0, kNoSlot, or the aggregates (bit a) whose contribution leaves on its own
         uint32_t live = 0;             // bit j: record j has not found its slot yet
+        // (decode and hash without a branch: the U records' arithmetic interleaves, and a record beyond the bin just is not live)
 #pragma unroll
         for (int j = 0; j < U; j++) {
             out[j] = 0;
-            key[j] = p[j] = 0;
-            t[j] = hs[j] = 0;
-            if (!(mask >> j & 1u) || r[j].k == kEmptyKey || (A.pad1 & 1u)) continue;  // beyond the bin / padding  (pad1: timing experiments only)
-            rec16_decode(r[j], key[j], t[j], p[j]);
-            hs[j] = lds_hash(key[j], S);
-            live |= 1u << j;
+            const bool is_int = (r[j].k >> 63) != 0, boxed = !is_int && (r[j].v >> 48) == 0xFFF8ull;  // (rec16_decode, n1k_tables.h)
+            key[j] = r[j].k & ~kRecIntFlag;
+            t[j] = is_int ? (uint32_t)T_INT : (boxed ? (uint32_t)(r[j].v >> 40) & 0xFFu : (uint32_t)T_FLOAT);
+            p[j] = boxed ? (r[j].v & 0xFFFFFFFFFFull) : r[j].v;
+            hs[j] = bin_slot(key[j], S);
+            const bool is_live = (mask >> j & 1u) && r[j].k != kEmptyKey && !(A.pad1 & 1u);  // beyond the bin / padding  (pad1: timing experiments only)
+            live |= is_live ? 1u << j : 0u;
         }
         const uint32_t valid = live;
         uint32_t found = live;  // bit j: hs[j] is record j's slot (cleared again where the table has no room)
@@ -321,13 +332,11 @@ __global__ __launch_bounds__(BLOCK) void agg_bins16_kernel(const Program P, cons
                 if (bit[j] == ~0u) { out[j] = 1u; bit[j] = 0; }
             }
             if (KIND == (int)AGG_SUM || KIND == (int)AGG_AVG) {
-                // (the flags fit the word's low half: a 32-bit read costs the LDS half of what a 64-bit one does)
-                uint32_t fl[U];
-#pragma unroll
-                for (int j = 0; j < U; j++) fl[j] = bit[j] ? *(volatile lds_u32*)lds_word(lds, (one.lds_off + 2) * S + hs[j]) : ~0u;
+                // the flags: a fire-and-forget OR per record (as the scan kernels do it) — reading them first to skip the OR
+                // where the bit is set already is a returning LDS operation, i.e. a wait, per chunk
 #pragma unroll
                 for (int j = 0; j < U; j++)
-                    if (!(fl[j] & bit[j])) lds_or_u64(lds_word(lds, (one.lds_off + 2) * S + hs[j]), (unsigned long long)bit[j]);
+                    if (bit[j]) lds_or_u64(lds_word(lds, (one.lds_off + 2) * S + hs[j]), (unsigned long long)bit[j]);
             }
 #pragma unroll
             for (int j = 0; j < U; j++) any_out |= out[j];
@@ -426,22 +435,23 @@ hipError_t launch_agg_bins16(const Program& P, const BinAggArgs& A, uint32_t gri
         hipLaunchKernelGGL(k, dim3(grid), dim3(BB), shmem, st, P, A);                                              \
     }
     // (8 records in flight per thread spilled to scratch)
-    if (block <= 256) {
-        if (per_thread <= 2) N1K_AGG16(256, 2, -1)
-        else if (specialise && P.naggs == 1 && !P.aggs[0].distinct && P.aggs[0].kind <= AGG_MAX) {
-            // the default geometry with the plan's one aggregate fixed at compile time
-            switch (P.aggs[0].kind) {
-                case AGG_COUNT: N1K_AGG16(256, 4, (int)AGG_COUNT) break;
-                case AGG_COUNTN: N1K_AGG16(256, 4, (int)AGG_COUNTN) break;
-                case AGG_SUM: N1K_AGG16(256, 4, (int)AGG_SUM) break;
-                case AGG_AVG: N1K_AGG16(256, 4, (int)AGG_AVG) break;
-                case AGG_MIN: N1K_AGG16(256, 4, (int)AGG_MIN) break;
-                default: N1K_AGG16(256, 4, (int)AGG_MAX) break;
-            }
-        } else N1K_AGG16(256, 4, -1)
-    } else {
-        if (per_thread <= 2) N1K_AGG16(512, 2, -1) else N1K_AGG16(512, 4, -1)
+    const bool one = specialise && P.naggs == 1 && !P.aggs[0].distinct && P.aggs[0].kind <= AGG_MAX;
+#define N1K_AGG16_KINDS(BB, UU)                                              \
+    if (!one) N1K_AGG16(BB, UU, -1)                                          \
+    else switch (P.aggs[0].kind) {  /* the plan's one aggregate fixed at compile time */ \
+        case AGG_COUNT: N1K_AGG16(BB, UU, (int)AGG_COUNT) break;             \
+        case AGG_COUNTN: N1K_AGG16(BB, UU, (int)AGG_COUNTN) break;           \
+        case AGG_SUM: N1K_AGG16(BB, UU, (int)AGG_SUM) break;                 \
+        case AGG_AVG: N1K_AGG16(BB, UU, (int)AGG_AVG) break;                 \
+        case AGG_MIN: N1K_AGG16(BB, UU, (int)AGG_MIN) break;                 \
+        default: N1K_AGG16(BB, UU, (int)AGG_MAX) break;                      \
     }
+    if (block <= 256) {
+        if (per_thread <= 2) { N1K_AGG16_KINDS(256, 2) } else { N1K_AGG16_KINDS(256, 4) }
+    } else {
+        if (per_thread <= 2) { N1K_AGG16_KINDS(512, 2) } else { N1K_AGG16_KINDS(512, 4) }
+    }
+#undef N1K_AGG16_KINDS
 #undef N1K_AGG16
     return hipGetLastError();
 }
