@@ -297,7 +297,10 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
         R.bin_cap = bin_cap;
         R.overflow = d_flags + 1;
         const uint64_t region_tiles = (n / 256 + 4095) / 4096 + kRecSubs;
-        const uint32_t wpr = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(h->opt_rec_slices ? h->opt_rec_slices : 8u, region_tiles));
+        // workgroups per region: about three tiles each, 8 to 32 (measured at 100 M rows: 8 / 16 / 32 / 64 workgroups per region take
+        // 714 / 670 / 660 / 750 us over 16-byte records — 95 tiles a region — and 382 / 375 / 393 / 452 us over 8-byte words — 48)
+        const uint64_t wpr_auto = std::min<uint64_t>(32, std::max<uint64_t>(8, region_tiles / 3));
+        const uint32_t wpr = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(h->opt_rec_slices ? h->opt_rec_slices : wpr_auto, region_tiles));
         HIP_TRY(h, launch_radix_scatter16(R, wpr, bps, h->stream));
         B.rec = h->d_rbins.p;
         B.bin_count = h->d_cursor.p;
@@ -326,8 +329,7 @@ n1k_status run_group_records(n1k_handle* h, const n1k_batch* b, const PartitionP
         const size_t shmem = agg_bins16_lds_bytes(P, slots) + 1024;
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / block / 2, (160 * 1024) / shmem));
         const uint32_t bgrid = (uint32_t)std::min<uint64_t>(B.nbins, (uint64_t)h->num_cus * per_cu);
-        const uint64_t per_thread = mean / block + 1;
-        HIP_TRY(h, launch_agg_bins16(P, B, bgrid, block, h->opt_rec_unroll ? h->opt_rec_unroll : (uint32_t)std::min<uint64_t>(per_thread, 4), h->stream, h->opt_agg_spec != 0));
+        HIP_TRY(h, launch_agg_bins16(P, B, bgrid, block, h->opt_rec_unroll ? h->opt_rec_unroll : 2u /* (2 records per thread and chunk: 554-586 us against 566-589 with 4, three boxes) */, h->stream, h->opt_agg_spec != 0));
     }
     // one copy of the counters into pinned memory (the region's group count joins them first): one host round trip
     {
