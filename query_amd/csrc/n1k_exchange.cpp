@@ -946,7 +946,11 @@ static n1k_status finish_and_gather(n1k_comm* c, n1k_status st, n1k_handle* rece
                                     int* worst_status) {
     if (st != N1K_OK && c->failure_broadcast) return st;  // this rank's own failure, told to every peer in the headers: no gather anywhere
     n1k_result local;
+    // (the step's result leaves the device here and the next step starts with a reset: a small table's tail kernel leaves the
+    //  receiver as that reset would — no reopen kernel in front of the next step)
+    receiver->clear_on_finish = true;
     const n1k_status fs = n1k_finish(receiver, &local);  // (also after a failure of the receiving part: the verdicts decide)
+    receiver->clear_on_finish = false;
     if (fs != N1K_OK && receiver->failure_global) return fs;  // learnt from the headers, by every rank alike: no gather anywhere
     if (st == N1K_OK) st = fs;
     if (!gather) {
