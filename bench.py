@@ -315,8 +315,11 @@ def roofline_of(wl: dict, rows: int, st: dict, workload: str, kcat: int, opts) -
                 nq = c.get("queries") or min(v["dispatches"] for k, v in c["FETCH_SIZE"].items() if "scan_spec" in k or "n1k_jit" in k)
                 tot = 0.0
                 for k, v in c["FETCH_SIZE"].items():
-                    # (not the query's: the data generator, and the Filter-only count bench.py checks the survivors against)
+                    # (not the query's: the data generator, the Filter-only count bench.py checks the survivors against and the
+                    #  copies of that check's ordinals to the host — a query's own copies are counters and a few rows: KBs)
                     if "synth_kernel" in k or ("filter_" in k and workload != "filter"):
+                        continue
+                    if "copyBuffer" in k and workload != "filter" and v["avg_KB"] > 1024.0:
                         continue
                     w = c["WRITE_SIZE"].get(k, {"avg_KB": 0.0})
                     tot += 1024.0 * (2.0 * v["avg_KB"] + w["avg_KB"]) * v["dispatches"] / nq
